@@ -1,0 +1,135 @@
+"""Caller-side input preparation for the HEPT operator.
+
+Host-side mirror of the step that runs immediately before
+``HEPTAttention.forward`` in the reference model shell: quantile regions in
+(eta, phi), the packed AND code ``combined_shifts`` and padding of every cloud
+to a multiple of ``block_size``.  Same names, argument meaning and return
+values as the reference (``example/transformer.py:10-63``,
+``example/hept_utils.py:6-31``); written with torch tensor ops only, so it runs
+on whatever device the inputs live on (no per-cloud Python loops over sorts).
+
+Behavioural notes kept from the reference:
+
+* ``batch`` must be sorted (points of one cloud contiguous), as the reference
+  assumes when it slices by ``bincount().cumsum()``
+  (``example/transformer.py:40-47``).
+* Padding slots of cloud ``i`` replicate real points: the first ``pad_i`` points
+  of the window of the last ``block_size`` positions of cloud ``i`` in the
+  order sorted by table-0/head-0 AND code (``example/transformer.py:24-31``).
+  The reference sorts with an unstable ``argsort``; this mirror uses a stable
+  sort, so pads are drawn from the same code window but may be different
+  members of a tie group.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+__all__ = ["get_regions", "quantile_partition", "bit_shift", "pad_and_unpad", "prepare_input"]
+
+
+def get_regions(num_regions, num_or_hashes, num_heads, num_and_hashes=2, generator=None) -> torch.Tensor:
+    """Random (eta, phi) region counts per (table, head); shape (T, A, H).
+
+    Reference: ``example/hept_utils.py:17-31``.  Each (table, head) pair draws
+    ``num_and_hashes`` factors uniformly in ``[2, 2·R^(1/A) - 2]``, rescales them
+    so that their product is ``num_regions`` and rounds to thirds.
+    """
+    lo = 2.0
+    hi = 2.0 * num_regions ** (1.0 / num_and_hashes) - lo
+    draws = torch.rand(num_or_hashes * num_heads, num_and_hashes, generator=generator)
+    factors = draws * (hi - lo) + lo
+    scale = (num_regions / factors.prod(dim=1, keepdim=True)) ** (1.0 / num_and_hashes)
+    factors = torch.round(scale * factors * 3) / 3
+    # rows are ordered (head-major inside a table): "(h c) a -> c a h"
+    return factors.reshape(num_heads, num_or_hashes, num_and_hashes).permute(1, 2, 0).contiguous()
+
+
+def quantile_partition(sorted_indices: torch.Tensor, num_regions: torch.Tensor) -> torch.Tensor:
+    """Region id (1-based, float) of every point from its rank; ``example/hept_utils.py:6-14``.
+
+    ``sorted_indices``: (n,) argsort of one coordinate.  ``num_regions``: (R, 1)
+    target region counts.  Returns (R, n): ``rank // ceil(n / num_regions) + 1``.
+    """
+    n = sorted_indices.shape[-1]
+    # the reference writes ``n / num_regions`` with a Python int numerator, which torch
+    # evaluates as ``num_regions.reciprocal() * n`` (one extra rounding); keep that form
+    width = torch.ceil(num_regions.reciprocal() * n)
+    rank = torch.empty_like(sorted_indices)
+    rank[sorted_indices] = torch.arange(n, device=sorted_indices.device)
+    return rank[None] // width + 1
+
+
+def bit_shift(base: torch.Tensor, shift_idx: torch.Tensor) -> torch.Tensor:
+    """Pack ``shift_idx`` above the bits used by ``base`` (row-wise); ``example/transformer.py:10-13``."""
+    top = base.max(dim=1, keepdim=True).values
+    n_bits = torch.ceil(torch.log2(top + 1)).long()
+    return (shift_idx << n_bits) | base
+
+
+def pad_and_unpad(batch, block_size, region_indices, raw_sizes) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Gather index that pads each cloud to a multiple of ``block_size`` and the mask that undoes it.
+
+    Reference: ``example/transformer.py:16-32``.
+    """
+    dev = batch.device
+    padded = ((raw_sizes + block_size - 1) // block_size) * block_size
+    n_pad = padded - raw_sizes
+    raw_end = raw_sizes.cumsum(0)
+    raw_start = raw_end - raw_sizes
+    pad_end = padded.cumsum(0)
+    pad_start = pad_end - padded
+    total = int(pad_end[-1])
+
+    cloud = torch.repeat_interleave(torch.arange(len(raw_sizes), device=dev), padded)
+    slot = torch.arange(total, device=dev) - pad_start[cloud]
+    is_real = slot < raw_sizes[cloud]
+
+    by_code = torch.sort(region_indices, stable=True).indices
+    # pad slot j of cloud i copies the point at sorted position raw_end[i] - block_size + j
+    src_sorted = raw_end[cloud] - block_size + (slot - raw_sizes[cloud])
+    src_sorted = torch.where(is_real, torch.zeros_like(src_sorted), src_sorted)
+    pad_seq = torch.where(is_real, raw_start[cloud] + slot, by_code[src_sorted])
+    return pad_seq, is_real
+
+
+def _rank_within_cloud(values: torch.Tensor, batch: torch.Tensor, raw_start: torch.Tensor) -> torch.Tensor:
+    """Rank of each point among the points of its own cloud, ordered by ``values`` (segmented argsort)."""
+    by_val = torch.sort(values, stable=True).indices
+    by_cloud = torch.sort(batch[by_val], stable=True).indices
+    order = by_val[by_cloud]  # grouped by cloud, ascending value inside
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(order.numel(), device=values.device)
+    return rank - raw_start[batch]
+
+
+def prepare_input(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+    """Padded features, ``{"combined_shifts", "coords"}`` and the un-pad mask.
+
+    Reference: ``example/transformer.py:35-63``.  ``helper_params`` carries
+    ``block_size``, ``num_heads`` and ``regions`` of shape (T, 2, H).
+    """
+    regions = helper_params["regions"]
+    block_size, num_heads = helper_params["block_size"], helper_params["num_heads"]
+    n_tables = regions.shape[0]
+    per_axis = regions.permute(1, 0, 2).reshape(2, n_tables * num_heads)  # "c a h -> a (c h)"
+    with torch.no_grad():
+        sizes = batch.bincount()
+        raw_end = sizes.cumsum(0)
+        raw_start = raw_end - sizes
+        n_in_cloud = sizes[batch]
+
+        region_ids = []
+        for axis in (0, 1):
+            rank = _rank_within_cloud(coords[:, axis], batch, raw_start)
+            # reciprocal-times-n, as in quantile_partition (see the note there)
+            width = torch.ceil(per_axis[axis][:, None].reciprocal() * n_in_cloud[None])
+            region_ids.append((rank[None] // width + 1).long())
+        codes = bit_shift(region_ids[0], region_ids[1])
+        codes = bit_shift(codes, batch[None])
+        codes = codes.reshape(n_tables, num_heads, -1)
+
+        pad_seq, unpad_seq = pad_and_unpad(batch, block_size, codes[0, 0], sizes)
+        kwargs = {"combined_shifts": codes[..., pad_seq], "coords": coords[pad_seq]}
+        return x[pad_seq], kwargs, unpad_seq
