@@ -1,0 +1,71 @@
+"""ctypes binding of the C ABI declared in ``include/hept_hip.h``.
+
+There is deliberately no fallback: if the HIP library is missing or a symbol is
+absent this raises, so a GPU box can never silently run a different code path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_size_t, c_void_p
+
+from .build import LIB_PATH
+
+ABI_VERSION = 1
+PREC_F32, PREC_BF16 = 0, 1
+ROW = 32
+MAX_TABLES = 8
+MAX_BLOCK = 256
+PREP_GRID = 1024
+
+_ERRORS = {
+    1: "HEPT_ERR_SHAPE: unsupported or inconsistent sizes",
+    2: "HEPT_ERR_LAUNCH: HIP reported a launch error",
+    3: "HEPT_ERR_ARG: null pointer or workspace too small",
+}
+
+_P = c_void_p
+# name -> (restype, argtypes); must list every symbol of include/hept_hip.h
+SIGNATURES = {
+    "hept_abi_version": (c_int, []),
+    "hept_check_shape": (c_int, [c_int] * 6),
+    "hept_workspace_bytes": (c_size_t, [c_int] * 7),
+    "hept_rpe_scale": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "hept_prep_hash": (c_int, [_P] * 6 + [c_int] * 8 + [_P] * 6),
+    "hept_sort_workspace_bytes": (c_size_t, [c_int] * 3),
+    "hept_sort_tables": (c_int, [_P] * 4 + [c_int] * 5 + [_P] * 4),
+    "hept_block_attn": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P]),
+    "hept_reduce_tables": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "hept_combine_out": (c_int, [_P] + [c_int] * 6 + [_P] * 4),
+    "hept_forward": (c_int, [_P] * 9 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
+    "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load ``libhept_hip.so`` (built in-tree by ``hept_amd.build``) and bind every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m hept_amd.build` "
+            "(or __graft_entry__.build()). hept_amd has no CPU/PyTorch fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.hept_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libhept_hip.so ABI version {got}, Python binding expects {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERRORS.get(rc, f'error code {rc}')}")

@@ -1,0 +1,241 @@
+// block_attn: gather -> block-local RBF attention on MFMA -> scatter to original order.
+//
+// Replaces, per (table, head, block) (reference file:line):
+//   sort_to_buckets x3 / batched_index_select   example/hept.py:70-72, example/hept_utils.py:74-92
+//   qkv_res                                      example/hept.py:7-18
+//   invert_permutation + unsort_from_buckets x2  example/hept.py:76-78, example/hept_utils.py:50-61,95-97
+//
+// One workgroup = one block of B sorted queries x the B sorted keys of the same rank range
+// (queries and keys are sorted independently, as in the reference).  NKT = ceil(B/32) waves;
+// wave w owns queries [32w, 32w+32) and walks the NKT 32-key tiles:
+//
+//   X  = K^ . Q^T      (keys on rows -> accumulator registers, queries on lanes)
+//        accumulator initialised with (-0.5|q|^2) + (-0.5|k|^2), so X is the full logit
+//   P  = exp(min(X,0)) in registers; the accumulator layout of X is already the A-operand
+//        layout of the next product (k index = key), no LDS bounce, no shuffles
+//   Z += P^T-as-A . V  where V carries a 1.0 column at index D: Z[:, D] is the row sum
+//
+// K^ and V tiles are staged once per block in LDS (rows gathered by kpos, 16 B per lane,
+// one kvhat row = K^ row | V row, contiguous); the wave's 32 Q^ rows go straight from HBM to
+// registers in B-operand layout.  No row max is needed: logits are clamped to <= 0
+// (example/hept.py:12) and the reference combines un-normalised numerators/denominators.
+// Output rows (32 floats = one 128-B line: numer[0..D-1], denom at D) are written straight to
+// part[t][qpos[row]][h][:], which fuses the un-sort.
+//
+// bf16 path: v_mfma_f32_32x32x16_bf16, V fragments by ds_read_b64_tr_b16.
+// fp32 path: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), plain ds_read_b32 for V.
+// blockIdx % H = head: with H = 8 every XCD (round-robin dispatch) gathers from one head's
+// qhat/kvhat slab only (speed only; nothing depends on placement).
+#include "common.h"
+
+namespace {
+
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+template <int NKT, bool BF16>
+__global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __restrict__ qhat,
+                                                              const char* __restrict__ kvhat,
+                                                              const int* __restrict__ qpos,
+                                                              const int* __restrict__ kpos,
+                                                              float* __restrict__ part, int N, int H, int D, int B,
+                                                              int nb) {
+    constexpr int NT = 64 * NKT;
+    constexpr int KEYS = 32 * NKT;
+    constexpr int ESZ = BF16 ? 2 : 4;
+    constexpr int QROW = 32 * ESZ;    // bytes of a q^ (or k^, or v) row
+    constexpr int KVROW = 2 * QROW;   // k^ row | v row
+    constexpr int CH = QROW / 16;     // 16-B chunks per k^ (or v) row: 4 / 8
+    constexpr int CPR = 2 * CH;       // chunks per kvhat row
+
+    // all LDS in one dynamic array (fp32 tiles at B=256 need 66 KB > the 64 KB static limit)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_s = smem;
+    char* v_s = smem + KEYS * QROW;
+    float* kn_s = reinterpret_cast<float*>(smem + 2 * KEYS * QROW);
+    int* qidx_s = reinterpret_cast<int*>(smem + 2 * KEYS * QROW + KEYS * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
+    const int bid = blockIdx.x;
+    const int h = bid % H;
+    const int rest = bid / H;
+    const int b = rest % nb, t = rest / nb;
+    const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
+    const int* __restrict__ kp = kpos + seg;
+    const int* __restrict__ qp = qpos + seg;
+    const char* __restrict__ qbase = qhat + (size_t)h * N * QROW;
+    const char* __restrict__ kvbase = kvhat + (size_t)h * N * KVROW;
+
+    // ---- this wave's 32 query rows: HBM -> registers (B-operand layout), norm from the row tail
+    const int qi = w * 32 + li;
+    const bool qvalid = qi < B;
+    const int qsrc = qp[qvalid ? qi : 0];
+    if (hh == 0) qidx_s[qi] = qvalid ? qsrc : -1;
+    const char* qrow = qbase + (size_t)qsrc * QROW;
+    const float qn = *reinterpret_cast<const float*>(qrow + QROW - 4);
+    u32x4 qraw[BF16 ? 2 : 4];
+#pragma unroll
+    for (int s = 0; s < (BF16 ? 2 : 4); ++s)
+        qraw[s] = *reinterpret_cast<const u32x4*>(qrow + (BF16 ? (s * 32 + hh * 16) : (hh * 64 + s * 16)));
+    if (hh == 1) qraw[BF16 ? 1 : 3][3] = 0u;  // the norm slot is not a feature
+
+    // ---- stage K^ and V tiles: gathered rows, 16 B per lane, K^ XOR-swizzled against bank conflicts
+#pragma unroll
+    for (int it = 0; it < CPR / 2; ++it) {
+        const int ci = it * NT + tid;
+        const int key = ci / CPR, c = ci % CPR;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (key < B) {
+            const int src = kp[key];
+            val = *reinterpret_cast<const u32x4*>(kvbase + (size_t)src * KVROW + c * 16);
+        }
+        if (c < CH) {
+            if (c == CH - 1) {
+                kn_s[key] = __uint_as_float(val[3]);
+                val[3] = 0u;
+            }
+            const int sw = BF16 ? ((key >> 2) & 3) : ((key >> 1) & 7);
+            *reinterpret_cast<u32x4*>(k_s + key * QROW + ((c ^ sw) * 16)) = val;
+        } else {
+            *reinterpret_cast<u32x4*>(v_s + key * QROW + (c - CH) * 16) = val;
+        }
+    }
+    __syncthreads();
+
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (kt * 32 >= B) break;  // uniform
+        const int key = kt * 32 + li;
+        f32x16 x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = qn + kn_s[kt * 32 + hept_acc_row(r, hh)];
+
+        if constexpr (BF16) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int c = 2 * s + hh;
+                const u32x4 kraw =
+                    *reinterpret_cast<const u32x4*>(k_s + key * QROW + ((c ^ ((key >> 2) & 3)) * 16));
+                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kraw),
+                                                            __builtin_bit_cast(bf16x8, qraw[s]), x, 0, 0, 0);
+            }
+        } else {
+            float kf[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(
+                    k_s + key * QROW + (((4 * hh + c) ^ ((key >> 1) & 7)) * 16));
+                kf[4 * c] = kk[0]; kf[4 * c + 1] = kk[1]; kf[4 * c + 2] = kk[2]; kf[4 * c + 3] = kk[3];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                x = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], __uint_as_float(qraw[s >> 2][s & 3]), x, 0, 0, 0);
+        }
+
+        float pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = __expf(fminf(x[r], 0.f));
+        if ((kt + 1) * 32 > B) {  // ragged last tile (B not a multiple of 32): padded keys carry no weight
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt * 32 + hept_acc_row(r, hh) >= B) pr[r] = 0.f;
+        }
+
+        if constexpr (BF16) {
+            const int g = lane >> 4, l16 = lane & 15;
+            const int vrow = kt * 32 + 4 * hh + (l16 >> 2);
+            const int vcol = 32 * (g & 1) + 8 * (l16 & 3);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4 pw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[j] = hept_pack_bf16(pr[8 * s + 2 * j], pr[8 * s + 2 * j + 1]);
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4_ptr)(v_s + (vrow + 16 * s) * QROW + vcol));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4_ptr)(v_s + (vrow + 16 * s + 8) * QROW + vcol));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pw),
+                                                            __builtin_bit_cast(bf16x8, vv), z, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float vv =
+                    *reinterpret_cast<const float*>(v_s + (kt * 32 + hept_acc_row(r, hh)) * QROW + li * 4);
+                z = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[r], vv, z, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
+    float* __restrict__ pt = part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q2 = w * 32 + hept_acc_row(r, hh);
+        if (q2 < B) {
+            const int dst = qidx_s[q2];
+            float val = z[r];
+            if (li == D) val += 1e-20f;  // example/hept.py:14
+            pt[(size_t)dst * H * 32] = val;
+        }
+    }
+}
+
+template <bool BF16>
+int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
+                const int* kpos, float* part, int N, int H, int D, int B, int nb) {
+#define HEPT_ATTN_CASE(K)                                                                                    \
+    case K: {                                                                                                \
+        constexpr size_t lds = (size_t)2 * 32 * K * 32 * (BF16 ? 2 : 4) + 32 * K * 8;                        \
+        if (lds > 65536) {                                                                                   \
+            static bool raised = false;                                                                      \
+            if (!raised) {                                                                                   \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_kernel<K, BF16>),          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                    return HEPT_ERR_LAUNCH;                                                                  \
+                raised = true;                                                                               \
+            }                                                                                                \
+        }                                                                                                    \
+        hipLaunchKernelGGL((block_attn_kernel<K, BF16>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
+                           kpos, part, N, H, D, B, nb);                                                      \
+        break;                                                                                               \
+    }
+    switch (nkt) {
+        HEPT_ATTN_CASE(1)
+        HEPT_ATTN_CASE(2)
+        HEPT_ATTN_CASE(3)
+        HEPT_ATTN_CASE(4)
+        HEPT_ATTN_CASE(5)
+        HEPT_ATTN_CASE(6)
+        HEPT_ATTN_CASE(7)
+        HEPT_ATTN_CASE(8)
+        default:
+            return HEPT_ERR_SHAPE;
+    }
+#undef HEPT_ATTN_CASE
+    return hept_launch_status();
+}
+
+}  // namespace
+
+extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
+                               int H, int D, int Tl, int B, int precision, float* part, void* stream) {
+    if (!qhat || !kvhat || !qpos || !kpos || !part) return HEPT_ERR_ARG;
+    if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
+        return HEPT_ERR_SHAPE;
+    const int nb = N / B, nkt = (B + 31) / 32;
+    const dim3 grid((unsigned)((size_t)Tl * nb * H));
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == HEPT_PREC_BF16)
+        return launch_attn<true>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H, D, B,
+                                 nb);
+    if (precision == HEPT_PREC_F32)
+        return launch_attn<false>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H, D,
+                                  B, nb);
+    return HEPT_ERR_SHAPE;
+}

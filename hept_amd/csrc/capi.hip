@@ -1,0 +1,109 @@
+// Whole-operator entry points of the C ABI (include/hept_hip.h): workspace carving + launch order.
+// Replaces HEPTAttention.forward, reference example/hept.py:43-81.
+#include "common.h"
+
+namespace {
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+    float* sqrt_w;
+    void* qhat;
+    void* kvhat;
+    float* qproj;
+    float* kproj;
+    float* minmax;
+    int32_t* pos;   // (2, Tl, H, N): q then k
+    void* sort_ws;
+    float* part;    // (Tl, N, H, 32)
+    size_t bytes;
+};
+
+Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
+    const size_t esz = precision == HEPT_PREC_BF16 ? 2 : 4;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* r = p ? p + off : nullptr;
+        off += up256(bytes);
+        return r;
+    };
+    Workspace w;
+    w.sqrt_w = reinterpret_cast<float*>(take((size_t)H * C * 4));
+    w.qhat = take((size_t)H * N * 32 * esz);
+    w.kvhat = take((size_t)H * N * 64 * esz);
+    w.qproj = reinterpret_cast<float*>(take((size_t)Tl * H * N * 4));
+    w.kproj = reinterpret_cast<float*>(take((size_t)Tl * H * N * 4));
+    w.minmax = reinterpret_cast<float*>(take((size_t)HEPT_PREP_GRID * Tl * H * 2 * 4));
+    w.pos = reinterpret_cast<int32_t*>(take((size_t)2 * Tl * H * N * 4));
+    w.sort_ws = take(hept_sort_workspace_bytes(N, H, Tl));
+    w.part = reinterpret_cast<float*>(take((size_t)Tl * N * H * 32 * 4));
+    w.bytes = off;
+    return w;
+}
+
+// stages shared by hept_forward / hept_forward_partial; leaves per-table partials in w.part
+int run_tables(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
+               const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
+               int precision, const Workspace& w, float* part, void* stream) {
+    int rc = hept_rpe_scale(w_rpe, H, D, C, K, w.sqrt_w, stream);
+    if (rc) return rc;
+    rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, N, H, D, C, T, t0, Tl, precision, w.qhat, w.kvhat, w.qproj,
+                        w.kproj, w.minmax, stream);
+    if (rc) return rc;
+    int32_t* qpos = w.pos;
+    int32_t* kpos = w.pos + (size_t)Tl * H * N;
+    rc = hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0, Tl, w.sort_ws, qpos, kpos, stream);
+    if (rc) return rc;
+    return hept_block_attn(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, part, stream);
+}
+
+}  // namespace
+
+extern "C" int hept_abi_version(void) { return 1; }
+
+extern "C" int hept_check_shape(int N, int H, int D, int C, int Tl, int B) {
+    if (N < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0) return HEPT_ERR_SHAPE;
+    if (H != 8) return HEPT_ERR_SHAPE;
+    if (Tl < 1 || Tl > HEPT_MAX_TABLES) return HEPT_ERR_SHAPE;
+    const bool dc = (D == 24 && (C == 6 || C == 4 || C == 2)) || (D == 16 && (C == 6 || C == 4)) || (D == 8 && C == 4);
+    return dc ? HEPT_OK : HEPT_ERR_SHAPE;
+}
+
+extern "C" size_t hept_workspace_bytes(int N, int H, int D, int C, int Tl, int B, int precision) {
+    (void)D;
+    (void)B;
+    return carve(nullptr, N, H, C, Tl, precision).bytes;
+}
+
+extern "C" int hept_forward(const float* q, const float* k, const float* v, const float* coords,
+                            const int64_t* codes, const float* w_rpe, const float* alpha, const float* out_weight,
+                            const float* out_bias, int N, int H, int D, int C, int K, int T, int B, int precision,
+                            void* workspace, size_t workspace_bytes, float* out, void* stream) {
+    if (!q || !k || !v || !coords || !codes || !w_rpe || !alpha || !out_weight || !workspace || !out)
+        return HEPT_ERR_ARG;
+    int rc = hept_check_shape(N, H, D, C, T, B);
+    if (rc) return rc;
+    const Workspace w = carve(workspace, N, H, C, T, precision);
+    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+    rc = run_tables(q, k, v, coords, codes, w_rpe, alpha, N, H, D, C, K, T, 0, T, B, precision, w, w.part, stream);
+    if (rc) return rc;
+    return hept_combine_out(w.part, T, N, H, D, 0, N, out_weight, out_bias, out, stream);
+}
+
+extern "C" int hept_forward_partial(const float* q, const float* k, const float* v, const float* coords,
+                                    const int64_t* codes, const float* w_rpe, const float* alpha, int N, int H,
+                                    int D, int C, int K, int T, int t0, int Tl, int B, int precision,
+                                    void* workspace, size_t workspace_bytes, float* acc, void* stream) {
+    if (!q || !k || !v || !coords || !codes || !w_rpe || !alpha || !workspace || !acc) return HEPT_ERR_ARG;
+    int rc = hept_check_shape(N, H, D, C, Tl, B);
+    if (rc) return rc;
+    if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    const Workspace w = carve(workspace, N, H, C, Tl, precision);
+    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+    // one local table: block_attn scatters straight into acc, no reduction pass
+    float* part = Tl == 1 ? acc : w.part;
+    rc = run_tables(q, k, v, coords, codes, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B, precision, w, part, stream);
+    if (rc || Tl == 1) return rc;
+    return hept_reduce_tables(w.part, Tl, N, H, acc, stream);
+}

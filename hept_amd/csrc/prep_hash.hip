@@ -1,0 +1,263 @@
+// prep_hash: coordinate augmentation + E2LSH projection + hash range partials.
+//
+// Replaces, for one call (reference file:line):
+//   prep_qk                    example/hept.py:21-28
+//   "n h d -> h n d" views     example/hept.py:57-59
+//   E2LSH.forward (bmm)        example/hept_utils.py:45-47
+//   min / max of lsh_mapping   example/hept_utils.py:66-69
+//
+// HBM-bound streaming kernel: reads q,k,v (N,H*D) once, writes the
+// head-major augmented rows that block_attn gathers later:
+//   qhat  (H,N,32)  : [ q | sqrt_w*coords | 0 .. | -0.5*|q^|^2 (f32 bits in the last 4 bytes) ]
+//   kvhat (H,N,64)  : [ k^ row as above | v | 1.0 at column D | 0 .. ]
+// The 1.0 column makes the P.V MFMA also produce the row sum (denominator).
+// For bf16 tiles the norm is taken of the *rounded* values, so that
+// q.k - 0.5|q|^2 - 0.5|k|^2 is exactly -0.5|q_r - k_r|^2 <= 0 up to fp32 rounding.
+// Hashes are always computed from the unrounded fp32 values.
+#include "common.h"
+
+namespace {
+
+constexpr int PREP_THREADS = 256;
+constexpr int PREP_POINTS = 32;  // points per tile; thread = (head = tid >> 5, point = tid & 31)
+
+__global__ void rpe_scale_kernel(const float* __restrict__ w, int H, int D, int C, int K,
+                                 float* __restrict__ sqrt_w) {
+    const int R = C - 1;
+    for (int i = threadIdx.x; i < H * R; i += blockDim.x) {
+        const int h = i / R, r = i % R;
+        float tot = 0.f;
+        for (int kk = 0; kk < K; ++kk) {
+            float s = 0.f;
+            for (int d = 0; d < D; ++d) s += w[(size_t)(h * D + d) * (R * K) + r * K + kk];
+            tot += expf(fminf(s, 50.f));
+        }
+        const float val = sqrtf(2.f * tot);
+        sqrt_w[h * C + r + 1] = val;
+        if (r == 0) sqrt_w[h * C] = val;  // eta and phi share the dR weight
+    }
+}
+
+template <int HD>
+__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ src, int rows, int tid) {
+    // linear, fully coalesced 16-B loads of `rows` consecutive points; LDS row stride HD+4 floats
+    constexpr int V4 = HD / 4;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    const int total = rows * V4;
+    for (int i = tid; i < total; i += PREP_THREADS) {
+        const int row = i / V4, c4 = i - row * V4;
+        *reinterpret_cast<f32x4*>(tile + row * (HD + 4) + c4 * 4) = s4[i];
+    }
+}
+
+template <int D, int C, bool BF16>
+__global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
+    int N, int T, int t0, int Tl, void* __restrict__ qhat_, void* __restrict__ kvhat_,
+    float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
+    constexpr int H = 8, E = D + C, HD = H * D, LDT = HD + 4, D4 = D / 4;
+    static_assert(D % 4 == 0 && E <= 30 && D <= 28, "row packing needs D%4==0, E<=30");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                                    // [32][LDT]
+    float* alpha_s = smem + PREP_POINTS * LDT;             // [H][E][HEPT_MAX_TABLES]
+    float* sw_s = alpha_s + H * E * HEPT_MAX_TABLES;       // [H][C]
+
+    const int tid = threadIdx.x, h = tid >> 5, p = tid & 31;
+    for (int i = tid; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
+        const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
+        alpha_s[i] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
+    }
+    for (int i = tid; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
+
+    float mn[HEPT_MAX_TABLES], mx[HEPT_MAX_TABLES];
+#pragma unroll
+    for (int t = 0; t < HEPT_MAX_TABLES; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; }
+
+    const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
+    for (int tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+        const int n0 = tile_i * PREP_POINTS;
+        const int rows = min(PREP_POINTS, N - n0);
+        const int n = n0 + p;
+        const bool live = p < rows;
+        float qa[32], ka[32], va[D];
+
+        __syncthreads();  // previous tile's readers are done (also covers alpha_s / sw_s on entry)
+        stage_tile<HD>(tile, q + (size_t)n0 * HD, rows, tid);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < D4; ++j) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(tile + p * LDT + h * D + 4 * j);
+            qa[4 * j] = x[0]; qa[4 * j + 1] = x[1]; qa[4 * j + 2] = x[2]; qa[4 * j + 3] = x[3];
+        }
+        __syncthreads();
+        stage_tile<HD>(tile, k + (size_t)n0 * HD, rows, tid);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < D4; ++j) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(tile + p * LDT + h * D + 4 * j);
+            ka[4 * j] = x[0]; ka[4 * j + 1] = x[1]; ka[4 * j + 2] = x[2]; ka[4 * j + 3] = x[3];
+        }
+        __syncthreads();
+        stage_tile<HD>(tile, v + (size_t)n0 * HD, rows, tid);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < D4; ++j) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(tile + p * LDT + h * D + 4 * j);
+            va[4 * j] = x[0]; va[4 * j + 1] = x[1]; va[4 * j + 2] = x[2]; va[4 * j + 3] = x[3];
+        }
+        if (!live) continue;  // barriers of the next iteration are still reached by every thread
+
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float s = sw_s[h * C + c] * coords[(size_t)n * C + c];
+            qa[D + c] = s;
+            ka[D + c] = s;
+        }
+#pragma unroll
+        for (int e = E; e < 32; ++e) { qa[e] = 0.f; ka[e] = 0.f; }
+
+        // E2LSH projections from the unrounded fp32 rows; ascending-e fma chain.
+#pragma unroll
+        for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
+            if (t < Tl) {
+                float aq = 0.f, ak = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float a = alpha_s[(h * E + e) * HEPT_MAX_TABLES + t];
+                    aq = fmaf(qa[e], a, aq);
+                    ak = fmaf(ka[e], a, ak);
+                }
+                qproj[((size_t)t * H + h) * N + n] = aq;
+                kproj[((size_t)t * H + h) * N + n] = ak;
+                mn[t] = fminf(mn[t], fminf(aq, ak));
+                mx[t] = fmaxf(mx[t], fmaxf(aq, ak));
+            }
+        }
+
+        if (BF16) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { qa[e] = hept_bf16_round(qa[e]); ka[e] = hept_bf16_round(ka[e]); }
+#pragma unroll
+            for (int d = 0; d < D; ++d) va[d] = hept_bf16_round(va[d]);
+        }
+        float qs = 0.f, ks = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { qs = fmaf(qa[e], qa[e], qs); ks = fmaf(ka[e], ka[e], ks); }
+        const float qn = -0.5f * qs, kn = -0.5f * ks;
+
+        const size_t row = (size_t)h * N + n;
+        if (BF16) {
+            u32x4* qd = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(qhat_) + row * 64);
+            u32x4* kd = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(kvhat_) + row * 128);
+            unsigned int qw[16], kw[16], vw[16];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                qw[i] = hept_pack_bf16(qa[2 * i], qa[2 * i + 1]);
+                kw[i] = hept_pack_bf16(ka[2 * i], ka[2 * i + 1]);
+            }
+            qw[15] = __float_as_uint(qn);
+            kw[15] = __float_as_uint(kn);
+            float vv[32];
+#pragma unroll
+            for (int d = 0; d < 32; ++d) vv[d] = d < D ? va[d] : (d == D ? 1.f : 0.f);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vw[i] = hept_pack_bf16(vv[2 * i], vv[2 * i + 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qd[j] = u32x4{qw[4 * j], qw[4 * j + 1], qw[4 * j + 2], qw[4 * j + 3]};
+                kd[j] = u32x4{kw[4 * j], kw[4 * j + 1], kw[4 * j + 2], kw[4 * j + 3]};
+                kd[4 + j] = u32x4{vw[4 * j], vw[4 * j + 1], vw[4 * j + 2], vw[4 * j + 3]};
+            }
+        } else {
+            f32x4* qd = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(qhat_) + row * 128);
+            f32x4* kd = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(kvhat_) + row * 256);
+            qa[31] = qn;
+            ka[31] = kn;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                qd[j] = f32x4{qa[4 * j], qa[4 * j + 1], qa[4 * j + 2], qa[4 * j + 3]};
+                kd[j] = f32x4{ka[4 * j], ka[4 * j + 1], ka[4 * j + 2], ka[4 * j + 3]};
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int d = 4 * j + u;
+                    x[u] = d < D ? va[d < D ? d : 0] : (d == D ? 1.f : 0.f);
+                }
+                kd[8 + j] = x;
+            }
+        }
+    }
+
+    // per-workgroup partial hash range: each 32-lane half owns one head
+#pragma unroll
+    for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
+        if (t < Tl) {
+            float a = mn[t], b = mx[t];
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                a = fminf(a, __shfl_xor(a, off));
+                b = fmaxf(b, __shfl_xor(b, off));
+            }
+            if (p == 0) {
+                float* dst = minmax + (((size_t)blockIdx.x * Tl + t) * H + h) * 2;
+                dst[0] = a;
+                dst[1] = b;
+            }
+        }
+    }
+}
+
+template <int D, int C>
+int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w,
+                const float* alpha, int N, int T, int t0, int Tl, int precision, void* qhat, void* kvhat,
+                float* qproj, float* kproj, float* minmax, hipStream_t st) {
+    constexpr int H = 8, E = D + C;
+    const size_t lds = sizeof(float) * (PREP_POINTS * (H * D + 4) + H * E * HEPT_MAX_TABLES + H * C);
+    const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
+    // the sort kernel reduces exactly HEPT_PREP_GRID partials: idle workgroups still write theirs
+    const int grid = HEPT_PREP_GRID;
+    (void)ntiles;
+    if (precision == HEPT_PREC_BF16)
+        hipLaunchKernelGGL((prep_hash_kernel<D, C, true>), dim3(grid), dim3(PREP_THREADS), lds, st, q, k, v, coords,
+                           sqrt_w, alpha, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+    else
+        hipLaunchKernelGGL((prep_hash_kernel<D, C, false>), dim3(grid), dim3(PREP_THREADS), lds, st, q, k, v, coords,
+                           sqrt_w, alpha, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+    return hept_launch_status();
+}
+
+}  // namespace
+
+extern "C" int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, float* sqrt_w, void* stream) {
+    if (!w_rpe || !sqrt_w) return HEPT_ERR_ARG;
+    if (H < 1 || D < 1 || C < 2 || K < 1) return HEPT_ERR_SHAPE;
+    hipLaunchKernelGGL(rpe_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w_rpe, H, D, C, K, sqrt_w);
+    return hept_launch_status();
+}
+
+extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
+                              const float* sqrt_w, const float* alpha, int N, int H, int D, int C, int T, int t0,
+                              int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj,
+                              float* minmax, void* stream) {
+    if (!q || !k || !v || !coords || !sqrt_w || !alpha || !qhat || !kvhat || !qproj || !kproj || !minmax)
+        return HEPT_ERR_ARG;
+    if (H != 8 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16) return HEPT_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define HEPT_PREP_CASE(DD, CC)                                                                             \
+    if (D == DD && C == CC)                                                                                \
+        return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, alpha, N, T, t0, Tl, precision, qhat, kvhat,   \
+                                   qproj, kproj, minmax, st);
+    HEPT_PREP_CASE(24, 6)
+    HEPT_PREP_CASE(24, 4)
+    HEPT_PREP_CASE(24, 2)
+    HEPT_PREP_CASE(16, 6)
+    HEPT_PREP_CASE(16, 4)
+    HEPT_PREP_CASE(8, 4)
+#undef HEPT_PREP_CASE
+    return HEPT_ERR_SHAPE;
+}

@@ -1,0 +1,109 @@
+"""``HEPTAttention``: drop-in ``nn.Module`` for the reference operator, backed by the gfx950 HIP kernels.
+
+Mirrors the reference interface (``example/hept.py:31-81``): same constructor
+(``hash_dim`` positional, model-config kwargs ``h_dim, num_heads, block_size,
+n_hashes, num_w_per_dist``; extra keys ignored), same ``forward(query, key,
+value, **kwargs)`` with ``kwargs["w_rpe"]`` (an ``nn.Linear``; only ``.weight``
+is read), ``kwargs["coords"]`` (N, C), ``kwargs["combined_shifts"]`` (T, H, N)
+int64, optional ignored ``pe``; same attribute and state-dict names
+(``out_linear.weight``, ``out_linear.bias``, ``e2lsh.alpha``), so a reference
+checkpoint loads with ``strict=True``.
+
+Two keyword-only extensions: ``precision`` ("fp32" reference numerics /
+"bf16" MFMA tiles) and ``process_group`` (shard the ``n_hashes`` tables over
+the ranks of a ``torch.distributed`` group).
+
+Forward only (inference metric); the module runs under ``torch.no_grad()``
+semantics and raises if gradients are requested.  There is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .sharding import TableSharding
+
+__all__ = ["E2LSH", "HEPTAttention"]
+
+
+class E2LSH(nn.Module):
+    """Holds the frozen Gaussian projection ``alpha`` (H, E, T); reference ``example/hept_utils.py:38-47``.
+
+    ``forward`` keeps the reference meaning (vecs (H,N,E) -> hashes (T,H,N)) for callers that
+    use it on its own; the fused operator reads ``alpha`` directly.
+    """
+
+    def __init__(self, n_hashes, n_heads, dim, r=1):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.normal(0, 1, (n_heads, dim, n_hashes)))
+        self.alpha.requires_grad = False
+
+    def forward(self, vecs):
+        return torch.bmm(vecs, self.alpha).permute(2, 0, 1)
+
+
+class HEPTAttention(nn.Module):
+    def __init__(self, hash_dim, *, precision: str = "fp32", process_group=None, **kwargs):
+        super().__init__()
+        self.dim_per_head = kwargs["h_dim"]
+        self.num_heads = kwargs["num_heads"]
+        self.out_linear = nn.Linear(self.num_heads * self.dim_per_head, self.dim_per_head)
+
+        self.block_size = kwargs["block_size"]
+        self.n_hashes = kwargs["n_hashes"]
+        self.num_w_per_dist = kwargs["num_w_per_dist"]
+        self.e2lsh = E2LSH(n_hashes=self.n_hashes, n_heads=self.num_heads, dim=hash_dim)
+
+        self.precision = precision
+        ops.precision_code(precision)  # validate early
+        self.sharding: Optional[TableSharding] = (
+            TableSharding(self.n_hashes, process_group) if process_group is not None else None
+        )
+        self._workspace: Optional[torch.Tensor] = None
+
+    def _scratch(self, nbytes: int, device) -> torch.Tensor:
+        ws = self._workspace
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
+            self._workspace = ws
+        return ws
+
+    def forward(self, query, key, value, **kwargs):
+        if torch.is_grad_enabled() and any(
+            t.requires_grad for t in (query, key, value, kwargs["w_rpe"].weight, self.out_linear.weight)
+        ):
+            raise RuntimeError(
+                "hept_amd.HEPTAttention implements the forward (inference) path only; "
+                "call it under torch.no_grad() (backward is SURVEY.md §8 f-2, not built yet)"
+            )
+        if not query.is_cuda:
+            raise RuntimeError("hept_amd.HEPTAttention needs GPU tensors: there is no CPU fallback")
+        coords = kwargs["coords"]
+        codes = kwargs["combined_shifts"]
+        w_rpe_weight = kwargs["w_rpe"].weight
+        n = query.shape[0]
+        if n % self.block_size != 0:
+            raise ValueError(f"number of points {n} is not a multiple of block_size {self.block_size}")
+        h, d, c = self.num_heads, self.dim_per_head, coords.shape[1]
+        common = dict(block_size=self.block_size, w_per_dist=self.num_w_per_dist, precision=self.precision)
+        with torch.no_grad():
+            q2 = query.reshape(n, h * d).float()
+            k2 = key.reshape(n, h * d).float()
+            v2 = value.reshape(n, h * d).float()
+            if self.sharding is None:
+                ws = self._scratch(ops.workspace_bytes(n, h, d, c, self.n_hashes, self.block_size, self.precision),
+                                   query.device)
+                out = ops.forward(q2, k2, v2, coords.float(), codes, w_rpe_weight, self.e2lsh.alpha,
+                                  self.out_linear.weight, self.out_linear.bias, workspace=ws, **common)
+            else:
+                t0, tl = self.sharding.local_tables()
+                ws = self._scratch(ops.workspace_bytes(n, h, d, c, tl, self.block_size, self.precision), query.device)
+                acc = ops.forward_partial(q2, k2, v2, coords.float(), codes, w_rpe_weight, self.e2lsh.alpha,
+                                          t0=t0, tl=tl, workspace=ws, **common)
+                out = self.sharding.finish(
+                    acc, lambda part, n0, cnt: ops.combine_out(part, d, self.out_linear.weight,
+                                                               self.out_linear.bias, n0, cnt))
+        return out.to(query.dtype)

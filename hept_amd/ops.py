@@ -1,0 +1,197 @@
+"""Torch-tensor front end of the C ABI: argument checks, workspace from the caching allocator, current stream.
+
+PyTorch is plumbing here (device memory + streams); all arithmetic runs in the
+HIP kernels of ``csrc/``.  Stage-level functions exist so that the parity tests
+can check every stage against the oracle and inject permutations.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import PREC_BF16, PREC_F32
+
+__all__ = [
+    "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
+    "forward", "forward_partial", "workspace_bytes",
+]
+
+
+def precision_code(precision) -> int:
+    if isinstance(precision, int) and not isinstance(precision, bool) and precision in (PREC_F32, PREC_BF16):
+        return precision
+    if precision in ("fp32", "f32") or precision is torch.float32:
+        return PREC_F32
+    if precision == "bf16" or precision is torch.bfloat16:
+        return PREC_BF16
+    raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (hept_amd has no CPU path); got device {t.device}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _dims(q: torch.Tensor, coords: torch.Tensor, alpha: torch.Tensor) -> Tuple[int, int, int, int, int]:
+    n, hd = q.shape
+    h, e, t = alpha.shape
+    c = coords.shape[1]
+    if hd % h != 0 or hd // h + c != e:
+        raise ValueError(f"inconsistent sizes: q {tuple(q.shape)}, coords {tuple(coords.shape)}, alpha {tuple(alpha.shape)}")
+    return n, h, hd // h, c, t
+
+
+def workspace_bytes(n, h, d, c, tl, b, precision) -> int:
+    return int(_lib.load().hept_workspace_bytes(n, h, d, c, tl, b, precision_code(precision)))
+
+
+def rpe_scale(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dist: int) -> torch.Tensor:
+    lib = _lib.load()
+    w = _f32c(w_rpe_weight, "w_rpe.weight")
+    c = w.shape[1] // w_per_dist + 1
+    out = torch.empty(n_heads, c, device=w.device, dtype=torch.float32)
+    _lib.check(lib.hept_rpe_scale(w.data_ptr(), n_heads, head_dim, c, w_per_dist, out.data_ptr(), _stream(w)),
+               "hept_rpe_scale")
+    return out
+
+
+def prep_hash(q, k, v, coords, sqrt_w, alpha, precision="fp32", t0: int = 0, tl: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    lib = _lib.load()
+    q, k, v, coords, sqrt_w, alpha = (_f32c(x, nm) for x, nm in
+                                      ((q, "query"), (k, "key"), (v, "value"), (coords, "coords"),
+                                       (sqrt_w, "sqrt_w"), (alpha, "alpha")))
+    n, h, d, c, t = _dims(q, coords, alpha)
+    tl = t - t0 if tl is None else tl
+    prec = precision_code(precision)
+    tile = torch.bfloat16 if prec == PREC_BF16 else torch.float32
+    dev = q.device
+    qhat = torch.empty(h, n, 32, device=dev, dtype=tile)
+    kvhat = torch.empty(h, n, 64, device=dev, dtype=tile)
+    qproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
+    kproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
+    minmax = torch.empty(_lib.PREP_GRID, tl, h, 2, device=dev, dtype=torch.float32)
+    _lib.check(lib.hept_prep_hash(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), sqrt_w.data_ptr(),
+                                  alpha.data_ptr(), n, h, d, c, t, t0, tl, prec, qhat.data_ptr(), kvhat.data_ptr(),
+                                  qproj.data_ptr(), kproj.data_ptr(), minmax.data_ptr(), _stream(q)),
+               "hept_prep_hash")
+    return dict(qhat=qhat, kvhat=kvhat, qproj=qproj, kproj=kproj, minmax=minmax)
+
+
+def sort_tables(qproj, kproj, codes, minmax, t0: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable ascending permutations (Tl,H,N) int32 of ``proj + float(code) * span`` for q and k."""
+    lib = _lib.load()
+    tl, h, n = qproj.shape
+    if codes.dtype != torch.int64 or not codes.is_cuda:
+        raise TypeError("combined_shifts must be an int64 GPU tensor")
+    codes = codes.contiguous()
+    t = codes.shape[0]
+    ws = torch.empty(int(lib.hept_sort_workspace_bytes(n, h, tl)), device=qproj.device, dtype=torch.uint8)
+    pos = torch.empty(2, tl, h, n, device=qproj.device, dtype=torch.int32)
+    _lib.check(lib.hept_sort_tables(qproj.data_ptr(), kproj.data_ptr(), codes.data_ptr(), minmax.data_ptr(), n, h, t,
+                                    t0, tl, ws.data_ptr(), pos[0].data_ptr(), pos[1].data_ptr(), _stream(qproj)),
+               "hept_sort_tables")
+    return pos[0], pos[1]
+
+
+def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-table partials (Tl, N, H, 32): numer in [..., :D], denom (+1e-20) at [..., D]."""
+    lib = _lib.load()
+    h, n, _ = qhat.shape
+    tl = qpos.shape[0]
+    prec = PREC_BF16 if qhat.dtype == torch.bfloat16 else PREC_F32
+    qpos = qpos.to(torch.int32).contiguous()
+    kpos = kpos.to(torch.int32).contiguous()
+    part = torch.empty(tl, n, h, 32, device=qhat.device, dtype=torch.float32) if out is None else out
+    _lib.check(lib.hept_block_attn(qhat.data_ptr(), kvhat.data_ptr(), qpos.data_ptr(), kpos.data_ptr(), n, h,
+                                   head_dim, tl, block_size, prec, part.data_ptr(), _stream(qhat)),
+               "hept_block_attn")
+    return part
+
+
+def reduce_tables(part: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    tl, n, h, _ = part.shape
+    acc = torch.empty(n, h, 32, device=part.device, dtype=torch.float32)
+    _lib.check(lib.hept_reduce_tables(part.data_ptr(), tl, n, h, acc.data_ptr(), _stream(part)), "hept_reduce_tables")
+    return acc
+
+
+def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int = 0, n_count: Optional[int] = None) -> torch.Tensor:
+    """(sum_t numer / sum_t denom) -> Linear(H*D -> D) for points [n0, n0+n_count); part is (Tl,N,H,32) or (N,H,32)."""
+    lib = _lib.load()
+    if part.dim() == 3:
+        part = part.unsqueeze(0)
+    tl, n, h, _ = part.shape
+    n_count = n - n0 if n_count is None else n_count
+    w = _f32c(out_weight, "out_linear.weight")
+    b = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
+    out = torch.empty(n_count, head_dim, device=part.device, dtype=torch.float32)
+    _lib.check(lib.hept_combine_out(part.data_ptr(), tl, n, h, head_dim, n0, n_count, w.data_ptr(),
+                                    b.data_ptr() if b is not None else None, out.data_ptr(), _stream(part)),
+               "hept_combine_out")
+    return out
+
+
+def _prepare(q, k, v, coords, codes, w_rpe_weight, alpha, block_size, w_per_dist):
+    q, k, v, coords, w, alpha = (_f32c(x, nm) for x, nm in
+                                 ((q, "query"), (k, "key"), (v, "value"), (coords, "coords"),
+                                  (w_rpe_weight, "w_rpe.weight"), (alpha, "e2lsh.alpha")))
+    n, h, d, c, t = _dims(q, coords, alpha)
+    if k.shape != q.shape or v.shape != q.shape or coords.shape[0] != n:
+        raise ValueError("query, key, value and coords must agree on the number of points")
+    if n % block_size != 0:
+        raise ValueError(f"number of points {n} is not a multiple of block_size {block_size}")
+    if codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n):
+        raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}, got {codes.dtype} {tuple(codes.shape)}")
+    if w.shape != (h * d, (c - 1) * w_per_dist):
+        raise ValueError(f"w_rpe.weight must have shape {(h * d, (c - 1) * w_per_dist)}, got {tuple(w.shape)}")
+    return q, k, v, coords, codes.contiguous(), w, alpha, (n, h, d, c, t)
+
+
+def forward(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *, block_size: int, w_per_dist: int,
+            precision="fp32", workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Whole operator (reference ``example/hept.py:43-81``) in one C call; returns (N, D) float32."""
+    lib = _lib.load()
+    q, k, v, coords, codes, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, codes, w_rpe_weight, alpha,
+                                                                block_size, w_per_dist)
+    prec = precision_code(precision)
+    _lib.check(lib.hept_check_shape(n, h, d, c, t, block_size), "hept_check_shape")
+    need = int(lib.hept_workspace_bytes(n, h, d, c, t, block_size, prec))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
+    ow = _f32c(out_weight, "out_linear.weight")
+    ob = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
+    out = torch.empty(n, d, device=q.device, dtype=torch.float32)
+    _lib.check(lib.hept_forward(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), codes.data_ptr(),
+                                w.data_ptr(), alpha.data_ptr(), ow.data_ptr(), ob.data_ptr() if ob is not None else None,
+                                n, h, d, c, w_per_dist, t, block_size, prec, workspace.data_ptr(), workspace.numel(),
+                                out.data_ptr(), _stream(q)), "hept_forward")
+    return out
+
+
+def forward_partial(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: int, w_per_dist: int, t0: int,
+                    tl: int, precision="fp32", workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Tables [t0, t0+tl) only: returns acc (N, H, 32) = sum over those tables of [numer | denom]."""
+    lib = _lib.load()
+    q, k, v, coords, codes, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, codes, w_rpe_weight, alpha,
+                                                                block_size, w_per_dist)
+    prec = precision_code(precision)
+    _lib.check(lib.hept_check_shape(n, h, d, c, tl, block_size), "hept_check_shape")
+    need = int(lib.hept_workspace_bytes(n, h, d, c, tl, block_size, prec))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
+    acc = torch.empty(n, h, 32, device=q.device, dtype=torch.float32)
+    _lib.check(lib.hept_forward_partial(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), codes.data_ptr(),
+                                        w.data_ptr(), alpha.data_ptr(), n, h, d, c, w_per_dist, t, t0, tl, block_size,
+                                        prec, workspace.data_ptr(), workspace.numel(), acc.data_ptr(), _stream(q)),
+               "hept_forward_partial")
+    return acc

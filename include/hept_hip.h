@@ -1,0 +1,114 @@
+/*
+ * hept_hip.h — C ABI of the MI355X (gfx950) HEPT block-attention hot path.
+ *
+ * Drop-in boundary for the reference operator HEPTAttention.forward
+ * (reference example/hept.py:43-81, helpers example/hept_utils.py:38-97).  The
+ * reference is pure Python/eager PyTorch and has no FFI of its own; each entry
+ * point below replaces the sequence of ATen ops named in its comment.  Plain
+ * device pointers and sizes only — no torch types.  All functions are
+ * asynchronous on `stream` (a hipStream_t passed as void*), never allocate,
+ * never synchronise, and return 0 on success or a HEPT_ERR_* code.
+ *
+ * Notation: N points (multiple of block size B), H heads, D head dim,
+ * C coordinate dim, E = D + C hash dim, T tables ("n_hashes"), Tl tables
+ * handled by this call (table sharding: tables [t0, t0+Tl) of T).
+ *
+ * Device layouts (all row-major, contiguous):
+ *   q,k,v        (N, H*D)   f32      inputs
+ *   coords       (N, C)     f32
+ *   w_rpe        (H*D, (C-1)*K) f32  the nn.Linear weight of the caller's w_rpe
+ *   alpha        (H, E, T)  f32      E2LSH projection
+ *   codes        (T, H, N)  i64      combined_shifts (AND code)
+ *   sqrt_w       (H, C)     f32      sqrt(2*sum_k exp(min(sum_d w,50)))
+ *   qhat         (H, N, 32) tile     augmented query rows, see DESIGN.md §3
+ *   kvhat        (H, N, 64) tile     augmented key row | value row
+ *   qproj,kproj  (Tl, H, N) f32      real-valued E2LSH hashes
+ *   qpos,kpos    (Tl, H, N) i32      ascending stable sort permutations
+ *   part         (Tl, N, H, 32) f32  per-table [numer(0..D-1) | denom(D) | 0]
+ *   acc          (N, H, 32) f32      sum over tables of part
+ *   out          (N, D)     f32
+ * "tile" element type is f32 (precision 0) or bf16 (precision 1).
+ */
+#ifndef HEPT_HIP_H
+#define HEPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEPT_OK 0
+#define HEPT_ERR_SHAPE 1   /* unsupported or inconsistent sizes */
+#define HEPT_ERR_LAUNCH 2  /* HIP reported a launch error */
+#define HEPT_ERR_ARG 3     /* null pointer / workspace too small */
+
+#define HEPT_PREC_F32 0
+#define HEPT_PREC_BF16 1
+
+#define HEPT_ROW 32          /* padded row width (elements) of qhat / k / v / part rows */
+#define HEPT_MAX_TABLES 8    /* tables per call */
+#define HEPT_MAX_BLOCK 256   /* largest block_size */
+
+/* ABI version of this library (bumped on any signature change). */
+int hept_abi_version(void);
+
+/* 0 if (N,H,D,C,T_local,B) is supported by the kernels, else HEPT_ERR_SHAPE. */
+int hept_check_shape(int N, int H, int D, int C, int Tl, int B);
+
+/* Bytes of scratch hept_forward / hept_forward_partial need. */
+size_t hept_workspace_bytes(int N, int H, int D, int C, int Tl, int B, int precision);
+
+/* replaces prep_qk's weight math, example/hept.py:22-23,25 (and the rearrange at :48-54) */
+int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, float* sqrt_w, void* stream);
+
+/* replaces prep_qk (example/hept.py:25-27), the head-major rearranges (:57-59), E2LSH.forward
+ * (example/hept_utils.py:45-47) and the min/max of lsh_mapping (:66-70).
+ * minmax: (HEPT_PREP_GRID, Tl, H, 2) f32 per-workgroup partial [min,max]; reduced by hept_sort_tables. */
+int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
+                   const float* sqrt_w, const float* alpha, int N, int H, int D, int C,
+                   int T, int t0, int Tl, int precision,
+                   void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
+                   void* stream);
+#define HEPT_PREP_GRID 1024
+
+/* replaces hash_shift (example/hept_utils.py:70), the AND-shift add (example/hept.py:63-65)
+ * and both argsorts (:67-68) with a stable LSD radix sort of the fp32 keys.
+ * sort_ws: hept_sort_workspace_bytes(N, H, Tl) bytes. */
+size_t hept_sort_workspace_bytes(int N, int H, int Tl);
+int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* codes,
+                     const float* minmax, int N, int H, int T, int t0, int Tl,
+                     void* sort_ws, int32_t* qpos, int32_t* kpos, void* stream);
+
+/* replaces sort_to_buckets x3 (example/hept.py:70-72), qkv_res (:7-18), invert_permutation and
+ * unsort_from_buckets x2 (:76-78): gather -> block-local RBF attention on MFMA -> scatter. */
+int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos,
+                    int N, int H, int D, int Tl, int B, int precision, float* part, void* stream);
+
+/* acc = sum_t part[t] (table-sharded ranks reduce `acc` across GPUs afterwards). */
+int hept_reduce_tables(const float* part, int Tl, int N, int H, float* acc, void* stream);
+
+/* replaces the cross-table combine (example/hept.py:79) and out_linear (:80) for points
+ * [n0, n0+n_count): out[n] = bias + W . (sum_t numer / sum_t denom).  `part` may hold Tl >= 1
+ * tables (Tl == 1: an already reduced `acc`).  out points at row n0 of the (N, D) output. */
+int hept_combine_out(const float* part, int Tl, int N, int H, int D, int n0, int n_count,
+                     const float* out_weight, const float* out_bias, float* out, void* stream);
+
+/* Whole operator for tables [t0, t0+Tl): everything above in one call.
+ * hept_forward writes out (N, D); hept_forward_partial stops at acc (N, H, 32). */
+int hept_forward(const float* q, const float* k, const float* v, const float* coords,
+                 const int64_t* codes, const float* w_rpe, const float* alpha,
+                 const float* out_weight, const float* out_bias,
+                 int N, int H, int D, int C, int K, int T, int B, int precision,
+                 void* workspace, size_t workspace_bytes, float* out, void* stream);
+int hept_forward_partial(const float* q, const float* k, const float* v, const float* coords,
+                         const int64_t* codes, const float* w_rpe, const float* alpha,
+                         int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
+                         int precision, void* workspace, size_t workspace_bytes, float* acc,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEPT_HIP_H */
