@@ -39,6 +39,8 @@ SIGNATURES = {
     "hept_combine_out": (c_int, [_P] + [c_int] * 6 + [_P] * 4),
     "hept_forward": (c_int, [_P] * 9 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
+    "hept_profile_enable": (c_int, [c_int, c_int]),
+    "hept_profile_read": (c_int, [_P, _P]),
 }
 
 _lib = None

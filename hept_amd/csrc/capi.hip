@@ -42,10 +42,27 @@ Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
     return w;
 }
 
+// ---- optional stage timing (hept_profile_*): a pool of HIP events recorded on the caller's stream
+struct Profiler {
+    int mode = 0, max_calls = 0, n_calls = 0;
+    hipEvent_t* ev = nullptr;  // [max_calls][5]
+} g_prof;
+
+inline void prof_mark(int slot, hipStream_t st) {
+    if (g_prof.mode == 0 || g_prof.n_calls >= g_prof.max_calls) return;
+    if (g_prof.mode == 1 && slot != 2 && slot != 3) return;
+    hipEventRecord(g_prof.ev[(size_t)g_prof.n_calls * 5 + slot], st);
+}
+inline void prof_call_done() {
+    if (g_prof.mode != 0 && g_prof.n_calls < g_prof.max_calls) ++g_prof.n_calls;
+}
+
 // stages shared by hept_forward / hept_forward_partial; leaves per-table partials in w.part
 int run_tables(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
                const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
                int precision, const Workspace& w, float* part, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    prof_mark(0, st);
     int rc = hept_rpe_scale(w_rpe, H, D, C, K, w.sqrt_w, stream);
     if (rc) return rc;
     rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, N, H, D, C, T, t0, Tl, precision, w.qhat, w.kvhat, w.qproj,
@@ -53,9 +70,13 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
     if (rc) return rc;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)Tl * H * N;
+    prof_mark(1, st);
     rc = hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0, Tl, w.sort_ws, qpos, kpos, stream);
     if (rc) return rc;
-    return hept_block_attn(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, part, stream);
+    prof_mark(2, st);
+    rc = hept_block_attn(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, part, stream);
+    prof_mark(3, st);
+    return rc;
 }
 
 }  // namespace
@@ -88,7 +109,10 @@ extern "C" int hept_forward(const float* q, const float* k, const float* v, cons
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
     rc = run_tables(q, k, v, coords, codes, w_rpe, alpha, N, H, D, C, K, T, 0, T, B, precision, w, w.part, stream);
     if (rc) return rc;
-    return hept_combine_out(w.part, T, N, H, D, 0, N, out_weight, out_bias, out, stream);
+    rc = hept_combine_out(w.part, T, N, H, D, 0, N, out_weight, out_bias, out, stream);
+    prof_mark(4, (hipStream_t)stream);
+    prof_call_done();
+    return rc;
 }
 
 extern "C" int hept_forward_partial(const float* q, const float* k, const float* v, const float* coords,
@@ -104,6 +128,44 @@ extern "C" int hept_forward_partial(const float* q, const float* k, const float*
     // one local table: block_attn scatters straight into acc, no reduction pass
     float* part = Tl == 1 ? acc : w.part;
     rc = run_tables(q, k, v, coords, codes, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B, precision, w, part, stream);
-    if (rc || Tl == 1) return rc;
-    return hept_reduce_tables(w.part, Tl, N, H, acc, stream);
+    if (!rc && Tl > 1) rc = hept_reduce_tables(w.part, Tl, N, H, acc, stream);
+    prof_mark(4, (hipStream_t)stream);
+    prof_call_done();
+    return rc;
+}
+
+extern "C" int hept_profile_enable(int mode, int max_calls) {
+    if (mode < 0 || mode > 2 || max_calls < 0) return HEPT_ERR_ARG;
+    if (g_prof.ev) {
+        for (size_t i = 0; i < (size_t)g_prof.max_calls * 5; ++i) hipEventDestroy(g_prof.ev[i]);
+        delete[] g_prof.ev;
+        g_prof.ev = nullptr;
+    }
+    g_prof.mode = mode;
+    g_prof.n_calls = 0;
+    g_prof.max_calls = mode ? max_calls : 0;
+    if (g_prof.max_calls) {
+        g_prof.ev = new hipEvent_t[(size_t)g_prof.max_calls * 5];
+        for (size_t i = 0; i < (size_t)g_prof.max_calls * 5; ++i)
+            if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return HEPT_ERR_LAUNCH;
+    }
+    return HEPT_OK;
+}
+
+extern "C" int hept_profile_read(float* ms, int* n_calls) {
+    if (!ms || !n_calls) return HEPT_ERR_ARG;
+    for (int i = 0; i < 4; ++i) ms[i] = 0.f;
+    *n_calls = g_prof.n_calls;
+    for (int c = 0; c < g_prof.n_calls; ++c) {
+        hipEvent_t* e = g_prof.ev + (size_t)c * 5;
+        const int first = g_prof.mode == 1 ? 2 : 0, last = g_prof.mode == 1 ? 3 : 4;
+        if (hipEventSynchronize(e[last]) != hipSuccess) return HEPT_ERR_LAUNCH;
+        for (int sidx = first; sidx < last; ++sidx) {
+            float dt = 0.f;
+            if (hipEventElapsedTime(&dt, e[sidx], e[sidx + 1]) != hipSuccess) return HEPT_ERR_LAUNCH;
+            ms[sidx] += dt;
+        }
+    }
+    g_prof.n_calls = 0;
+    return HEPT_OK;
 }

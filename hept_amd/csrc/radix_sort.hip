@@ -67,8 +67,12 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const int n = base + i * SORT_THREADS + tid;
         if (n < N) {
-            const float off = __fmul_rn((float)code[n], span);
-            const unsigned int u = ordered_bits(__fadd_rn(proj[n], off));
+            // two separately rounded ops, as the two eager ops of the reference; HIP's __fmul_rn /
+            // __fadd_rn are plain * and + and would be contracted to one fma without
+            // -ffp-contract=off (Makefile) -- the asm barrier makes it explicit here as well
+            float off = (float)code[n] * span;
+            asm volatile("" : "+v"(off));
+            const unsigned int u = ordered_bits(proj[n] + off);
             kout[n] = u;
             atomicAdd(&h_s[u & 0xFF], 1u);
         }

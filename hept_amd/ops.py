@@ -15,7 +15,7 @@ from ._lib import PREC_BF16, PREC_F32
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
-    "forward", "forward_partial", "workspace_bytes",
+    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read",
 ]
 
 
@@ -195,3 +195,18 @@ def forward_partial(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: 
                                         prec, workspace.data_ptr(), workspace.numel(), acc.data_ptr(), _stream(q)),
                "hept_forward_partial")
     return acc
+
+
+def profile_enable(mode: int, max_calls: int = 0) -> None:
+    """Stage timing with HIP events recorded inside hept_forward (mode 1: block_attn only, 2: all stages, 0: off)."""
+    _lib.check(_lib.load().hept_profile_enable(mode, max_calls), "hept_profile_enable")
+
+
+def profile_read() -> Tuple[Dict[str, float], int]:
+    """Summed milliseconds per stage over the recorded calls, and the number of calls; resets the pool."""
+    import ctypes
+
+    ms = (ctypes.c_float * 4)()
+    n = ctypes.c_int(0)
+    _lib.check(_lib.load().hept_profile_read(ms, ctypes.byref(n)), "hept_profile_read")
+    return dict(zip(("prep_hash", "sort_tables", "block_attn", "combine"), [float(x) for x in ms])), int(n.value)

@@ -108,6 +108,16 @@ int hept_forward_partial(const float* q, const float* k, const float* v, const f
                          int precision, void* workspace, size_t workspace_bytes, float* acc,
                          void* stream);
 
+/* Optional stage timing with HIP events recorded on the caller's stream inside hept_forward /
+ * hept_forward_partial (nothing like it exists in the reference; used by bench.py for the roofline).
+ * mode 0: off (default).  mode 1: bracket the block_attn kernel only (2 events per call).
+ * mode 2: bracket all four stages (5 events per call).  `max_calls` sizes the event pool; calls
+ * beyond it are not recorded.  hept_profile_read waits for the recorded events, adds up the
+ * elapsed milliseconds per stage [prep(+rpe), sort, block_attn, combine/reduce] over the recorded
+ * calls into ms[4], stores the number of calls in *n_calls and resets the pool. */
+int hept_profile_enable(int mode, int max_calls);
+int hept_profile_read(float* ms, int* n_calls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,17 +174,20 @@ def _round_tile(x: torch.Tensor, tile_dtype: torch.dtype) -> torch.Tensor:
 
 
 def block_rbf_attention(
-    sq: torch.Tensor, sk: torch.Tensor, sv: torch.Tensor
+    sq: torch.Tensor, sk: torch.Tensor, sv: torch.Tensor, p_dtype: torch.dtype = torch.float32
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Un-normalised block attention, ``example/hept.py:7-18``.
 
     ``S = q·kᵀ - ½|q|² - ½|k|²ᵀ`` → ``exp(min(S, 0))``; returns
     ``(denom, numer)`` = (row sums + 1e-20, S·v).  No row max, no division.
+    ``p_dtype=torch.bfloat16`` rounds the weights before the row sum and S·v
+    (models the bf16 MFMA path; not reference behaviour).
     """
     qn = -0.5 * (sq**2).sum(dim=-1, keepdim=True)
     kn = -0.5 * (sk**2).sum(dim=-1, keepdim=True)
     s = torch.matmul(sq, sk.transpose(-1, -2))
     s = (s + qn + kn.transpose(-1, -2)).clamp(max=0.0).exp()
+    s = _round_tile(s, p_dtype)
     denom = s.sum(dim=-1, keepdim=True) + 1e-20
     numer = torch.matmul(s, sv)
     return denom, numer
@@ -265,7 +268,7 @@ def forward_partials(
     sq = gather_blocks(_round_tile(q_hat, tile_dtype), q_pos, block_size)
     sk = gather_blocks(_round_tile(k_hat, tile_dtype), k_pos, block_size)
     sv = gather_blocks(_round_tile(v_h, tile_dtype), k_pos, block_size)
-    denom_s, numer_s = block_rbf_attention(sq, sk, sv)
+    denom_s, numer_s = block_rbf_attention(sq, sk, sv, tile_dtype)
     del sq, sk, sv
     numer = unsort_tables(numer_s, q_pos)
     denom = unsort_tables(denom_s, q_pos)

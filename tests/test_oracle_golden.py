@@ -1,0 +1,118 @@
+"""The oracle (oracle/hept_oracle.py) against every golden vector captured from the real reference.
+
+Pinning chain: reference (imported in the build container by tests/golden/make_golden.py) -> *.npz
+-> oracle.  With the reference's own permutations injected the oracle must reproduce the reference
+bit for bit; with its own stable sort the comparison is tie-aware (SURVEY.md §7 hard part 1).
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import hept_oracle as ho
+
+FULL_CASES = ["g1_rand512", "g2_example4k", "g3_ckpt6k", "g4_pileup", "g6_block100"]
+
+
+def _oracle(inp, **kw):
+    return ho.forward(
+        inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"], inp["alpha"],
+        inp["out_weight"], inp["out_bias"], block_size=inp["block_size"], w_per_dist=inp["w_per_dist"], **kw,
+    )
+
+
+@pytest.mark.parametrize("name", FULL_CASES + ["g5_track60k"])
+def test_inputs_rebuild_exactly(name):
+    inp, fx = cases.load_case(name)
+    got = cases.input_checksums(inp)
+    np.testing.assert_allclose(got, fx["input_checksums"], rtol=1e-12, atol=1e-9)
+    assert float(inp["combined_shifts"].double().sum()) == float(fx["ref_codes_sum"]) or "random_codes" in cases.CASES[name]
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_oracle_bit_exact_with_reference_permutations(name):
+    inp, fx = cases.load_case(name)
+    qp = torch.from_numpy(fx["q_positions"].astype(np.int64))
+    kp = torch.from_numpy(fx["k_positions"].astype(np.int64))
+    res = _oracle(inp, q_positions=qp, k_positions=kp)
+    assert torch.equal(res["out"], torch.from_numpy(fx["out"]))
+    assert torch.equal(res["sqrt_w"], torch.from_numpy(fx["sqrt_w"]))
+    assert torch.equal(res["hash_span"], torch.from_numpy(fx["hash_span"]))
+    rows = torch.from_numpy(fx["rows"].astype(np.int64))
+    assert torch.equal(res["q_hashed"][..., rows], torch.from_numpy(fx["q_hashed_rows"]))
+    assert torch.equal(res["k_hashed"][..., rows], torch.from_numpy(fx["k_hashed_rows"]))
+    assert torch.equal(res["denom"].squeeze(-1)[..., rows], torch.from_numpy(fx["denom_rows"]))
+    assert torch.equal(res["per_head"][:, rows], torch.from_numpy(fx["per_head_rows"]))
+    if "numer" in fx:
+        assert torch.equal(res["numer"], torch.from_numpy(fx["numer"]))
+        assert torch.equal(res["q_keys"], torch.from_numpy(fx["q_keys"]))
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_oracle_sort_is_a_valid_sort_of_the_reference_keys(name):
+    """Stable sort: a permutation, keys non-decreasing, same sorted-key sequence as the reference's argsort."""
+    inp, fx = cases.load_case(name)
+    res = _oracle(inp)
+    n = inp["q"].shape[0]
+    for keys, pos, digest in ((res["q_keys"], res["q_positions"], fx["sorted_key_sums_q"]),
+                              (res["k_keys"], res["k_positions"], fx["sorted_key_sums_k"])):
+        assert torch.equal(torch.sort(pos, -1).values, torch.arange(n).expand_as(pos))
+        sk = torch.gather(keys, -1, pos)
+        assert bool((sk[..., 1:] >= sk[..., :-1]).all())
+        np.testing.assert_array_equal(sk.double().sum(-1).numpy(), digest)
+        # stability: equal keys keep ascending index
+        tie = sk[..., 1:] == sk[..., :-1]
+        assert bool((pos[..., 1:][tie] > pos[..., :-1][tie]).all())
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_oracle_own_sort_matches_reference_tie_aware(name):
+    """End to end with the oracle's stable sort: rows may differ from the reference only through ties
+    (unstable argsort in the reference); at these sizes >= 98 % of rows agree to 1e-5."""
+    inp, fx = cases.load_case(name)
+    res = _oracle(inp)
+    ref = torch.from_numpy(fx["out"])
+    row_err = (res["out"] - ref).abs().amax(-1)
+    frac_ok = float((row_err <= 1e-5 + 1e-4 * ref.abs().amax(-1)).float().mean())
+    assert frac_ok >= 0.98, frac_ok
+    # every differing position of the permutation sits inside a group of tied keys
+    ref_q = torch.from_numpy(fx["q_positions"].astype(np.int64))
+    diff = res["q_positions"] != ref_q
+    if diff.any():
+        k_or = torch.gather(res["q_keys"], -1, res["q_positions"])
+        k_rf = torch.gather(res["q_keys"], -1, ref_q)
+        assert torch.equal(k_or, k_rf)
+
+
+def test_oracle_60k_sampled_rows():
+    """tracking-60k (BASELINE config 3): sampled reference rows, tie-aware criterion (expect >= 99 %)."""
+    inp, fx = cases.load_case("g5_track60k")
+    res = _oracle(inp, keep=True)
+    rows = torch.from_numpy(fx["rows"].astype(np.int64))
+    assert torch.equal(res["q_hashed"][..., rows], torch.from_numpy(fx["q_hashed_rows"]))
+    np.testing.assert_array_equal(
+        torch.gather(res["q_keys"], -1, res["q_positions"]).double().sum(-1).numpy(), fx["sorted_key_sums_q"])
+    ref = torch.from_numpy(fx["out_rows"])
+    err = (res["out"][rows] - ref).abs().amax(-1)
+    frac_ok = float((err <= 1e-5 + 1e-4 * ref.abs().amax(-1)).float().mean())
+    assert frac_ok >= 0.99, frac_ok
+
+
+def test_oracle_rejects_ragged_input():
+    inp, _ = cases.load_case("g1_rand512")
+    with pytest.raises(ValueError):
+        ho.forward(inp["q"][:500], inp["k"][:500], inp["v"][:500], inp["coords"][:500], inp["combined_shifts"][..., :500],
+                   inp["w_rpe_weight"], inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=64, w_per_dist=10)
+
+
+def test_table_sharding_identity_in_oracle():
+    """Per-table partials are independent: summing partials of table subsets == all tables."""
+    inp, _ = cases.load_case("g6_block100")
+    kw = dict(block_size=inp["block_size"], w_per_dist=inp["w_per_dist"], keep=False)
+    full = ho.forward_partials(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
+                               inp["alpha"], **kw)
+    for t in range(inp["alpha"].shape[2]):
+        one = ho.forward_partials(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"][t:t + 1],
+                                  inp["w_rpe_weight"], inp["alpha"][:, :, t:t + 1].contiguous(), **kw)
+        assert torch.equal(one["numer"][0], full["numer"][t])
+        assert torch.equal(one["denom"][0], full["denom"][t])

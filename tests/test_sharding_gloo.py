@@ -1,0 +1,115 @@
+"""Table sharding over ranks (hept_amd/sharding.py) on CPU: world_size 2, gloo backend.
+
+The per-rank partials are produced by the ORACLE here (there is no GPU in this container and the
+product has no CPU compute path); what is under test is the product's sharding logic: table slices,
+the exchange step (all-reduce / reduce-scatter + all-gather), point slices and the finishing call.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+import hept_oracle as ho
+from hept_amd.sharding import TableSharding, table_slice
+
+
+def test_table_slice_partitions():
+    for t in range(1, 12):
+        for w in range(1, t + 1):
+            got = [table_slice(t, r, w) for r in range(w)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == t
+            assert all(got[i][0] + got[i][1] == got[i + 1][0] for i in range(w - 1))
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    with pytest.raises(ValueError):
+        table_slice(2, 0, 3)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _acc_from_oracle(inp, t0, tl):
+    """(N, H, 32) [numer | denom | 0] summed over tables [t0, t0+tl), the layout the HIP path produces."""
+    res = ho.forward_partials(
+        inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"][t0:t0 + tl], inp["w_rpe_weight"],
+        inp["alpha"][:, :, t0:t0 + tl].contiguous(), block_size=inp["block_size"], w_per_dist=inp["w_per_dist"], keep=False)
+    numer, denom = res["numer"].sum(0), res["denom"].sum(0)  # (H,N,D), (H,N,1)
+    h, n, d = numer.shape
+    acc = torch.zeros(n, h, 32)
+    acc[..., :d] = numer.permute(1, 0, 2)
+    acc[..., d] = denom.squeeze(-1).permute(1, 0)
+    return acc
+
+
+def _finish_cpu(inp):
+    d = inp["out_weight"].shape[0]
+
+    def fn(part, n0, cnt):
+        rows = part[n0:n0 + cnt]
+        per_head = rows[..., :d] / rows[..., d:d + 1]
+        return torch.nn.functional.linear(per_head.reshape(cnt, -1), inp["out_weight"], inp["out_bias"])
+
+    return fn
+
+
+def _worker(rank, world, port, mode, name, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        inp, _ = cases.load_case(name)
+        n_tables = inp["alpha"].shape[2]
+        sh = TableSharding(n_tables, dist.group.WORLD, mode=mode)
+        t0, tl = sh.local_tables()
+        acc = _acc_from_oracle(inp, t0, tl)
+        if mode == "reduce_scatter":
+            # gloo has no reduce_scatter: emulate the collective pair so that the slicing / padding /
+            # gather logic of TableSharding.finish still runs end to end
+            orig_rs, orig_ag = dist.reduce_scatter_tensor, dist.all_gather_into_tensor
+
+            def rs(out, inp_t, op=None, group=None):
+                full = inp_t.clone()
+                dist.all_reduce(full, group=group)
+                per = out.shape[0]
+                out.copy_(full[rank * per:(rank + 1) * per])
+
+            def ag(out, inp_t, group=None):
+                parts = [torch.empty_like(inp_t) for _ in range(world)]
+                dist.all_gather(parts, inp_t, group=group)
+                out.copy_(torch.cat(parts, 0))
+
+            dist.reduce_scatter_tensor, dist.all_gather_into_tensor = rs, ag
+        out = sh.finish(acc, _finish_cpu(inp))
+        if mode == "reduce_scatter":
+            dist.reduce_scatter_tensor, dist.all_gather_into_tensor = orig_rs, orig_ag
+        if rank == 0:
+            ret["out"] = out.clone()
+        gathered = [torch.empty_like(out) for _ in range(world)]
+        dist.all_gather(gathered, out)
+        if rank == 0:
+            ret["same_on_all_ranks"] = all(torch.equal(gathered[0], g) for g in gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,name", [("all_reduce", "g6_block100"), ("reduce_scatter", "g6_block100"),
+                                       ("all_reduce", "g1_rand512")])
+def test_two_rank_table_sharding_matches_single_process(mode, name):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), mode, name, ret), nprocs=world, join=True)
+    inp, _ = cases.load_case(name)
+    ref = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
+                     inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=inp["block_size"],
+                     w_per_dist=inp["w_per_dist"], keep=False)["out"]
+    assert ret["same_on_all_ranks"]
+    # the sharded sum adds the same per-table terms in a different association: fp32 round-off only
+    torch.testing.assert_close(ret["out"], ref, rtol=1e-5, atol=1e-6)

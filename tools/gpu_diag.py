@@ -21,7 +21,7 @@ def run_case(name, precision):
     print(f"== {name} N={inp['q'].shape[0]} B={B} T={inp['alpha'].shape[2]} precision={precision}", flush=True)
     tile = torch.bfloat16 if precision == "bf16" else torch.float32
     orc = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"], inp["alpha"],
-                     inp["out_weight"], inp["out_bias"], block_size=B, w_per_dist=K, tile_dtype=tile)
+                     inp["out_weight"], inp["out_bias"], block_size=B, w_per_dist=K, tile_dtype=tile)  # bf16: tiles and P rounded
     g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
     H, E, T = inp["alpha"].shape; D = inp["q"].shape[1] // H; N = inp["q"].shape[0]
     sw = ops.rpe_scale(g["w_rpe_weight"], H, D, K)
