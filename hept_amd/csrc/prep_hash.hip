@@ -19,98 +19,120 @@
 namespace {
 
 constexpr int PREP_THREADS = 256;
-constexpr int PREP_POINTS = 32;  // points per tile; thread = (head = tid >> 5, point = tid & 31)
+constexpr int PREP_POINTS = 8;   // points per wave iteration; lane = (point = lane >> 3, head = lane & 7)
 
-__global__ void rpe_scale_kernel(const float* __restrict__ w, int H, int D, int C, int K,
-                                 float* __restrict__ sqrt_w) {
-    const int R = C - 1;
-    for (int i = threadIdx.x; i < H * R; i += blockDim.x) {
-        const int h = i / R, r = i % R;
+// sqrt_w[h][c] = sqrt(2 * sum_k exp(min(sum_d w[h*D+d][r*K+k], 50))), column 0 duplicated (eta, phi share dR).
+// One thread per (h, r, k) term (coalesced over k), then a K-term sum per (h, r).
+__global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict__ w, int H, int D, int C, int K,
+                                                         float* __restrict__ sqrt_w) {
+    __shared__ float term_s[1024];
+    const int R = C - 1, RK = R * K, total = H * RK;
+    const int i = threadIdx.x;
+    if (i < total) {
+        const int h = i / RK, rk = i - h * RK;
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) s += w[(size_t)(h * D + d) * RK + rk];  // unrolled: loads in flight together
+        term_s[i] = expf(fminf(s, 50.f));
+    }
+    __syncthreads();
+    if (i < H * R) {
+        const int h = i / R, r = i - h * R;
         float tot = 0.f;
-        for (int kk = 0; kk < K; ++kk) {
-            float s = 0.f;
-            for (int d = 0; d < D; ++d) s += w[(size_t)(h * D + d) * (R * K) + r * K + kk];
-            tot += expf(fminf(s, 50.f));
-        }
+        for (int kk = 0; kk < K; ++kk) tot += term_s[h * RK + r * K + kk];
         const float val = sqrtf(2.f * tot);
         sqrt_w[h * C + r + 1] = val;
-        if (r == 0) sqrt_w[h * C] = val;  // eta and phi share the dR weight
+        if (r == 0) sqrt_w[h * C] = val;
     }
 }
 
-template <int HD>
-__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ src, int rows, int tid) {
-    // linear, fully coalesced 16-B loads of `rows` consecutive points; LDS row stride HD+4 floats
-    constexpr int V4 = HD / 4;
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-    const int total = rows * V4;
-    for (int i = tid; i < total; i += PREP_THREADS) {
-        const int row = i / V4, c4 = i - row * V4;
-        *reinterpret_cast<f32x4*>(tile + row * (HD + 4) + c4 * 4) = s4[i];
-    }
-}
-
+// One wave = 8 consecutive points x 8 heads per iteration, no workgroup barriers in the loop:
+//   * the 8 points' q (then k, then v) rows are one contiguous 6-KiB run of the (N, H*D) input:
+//     six fully coalesced 16-B loads per lane,
+//   * a wave-private LDS buffer turns "lane = 16-B chunk" into "lane = (point, head) row of D floats"
+//     (LDS executes one wave's accesses in order, so no barrier is needed),
+//   * lane (p = lane >> 3, h = lane & 7) then augments, hashes and writes its own rows.
 template <int D, int C, bool BF16>
 __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
     int N, int T, int t0, int Tl, void* __restrict__ qhat_, void* __restrict__ kvhat_,
     float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
-    constexpr int H = 8, E = D + C, HD = H * D, LDT = HD + 4, D4 = D / 4;
-    static_assert(D % 4 == 0 && E <= 30 && D <= 28, "row packing needs D%4==0, E<=30");
+    constexpr int H = 8, E = D + C, HD = H * D, D4 = D / 4;
+    constexpr int CHUNKS = PREP_POINTS * HD / 4;        // 16-B chunks per 8-point tile (384)
+    constexpr int LOADS = CHUNKS / HEPT_WAVE;           // per lane (6)
+    constexpr int WAVES = PREP_THREADS / HEPT_WAVE;
+    static_assert(D % 4 == 0 && E <= 30 && D <= 28 && CHUNKS % HEPT_WAVE == 0, "row packing needs D%4==0, E<=30");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                                    // [32][LDT]
-    float* alpha_s = smem + PREP_POINTS * LDT;             // [H][E][HEPT_MAX_TABLES]
-    float* sw_s = alpha_s + H * E * HEPT_MAX_TABLES;       // [H][C]
+    float* alpha_s = smem;                                        // [H][E][HEPT_MAX_TABLES]
+    float* sw_s = alpha_s + H * E * HEPT_MAX_TABLES;              // [H][C] (+ pad to 16 B)
+    float* red_s = sw_s + ((H * C + 3) & ~3);                     // [WAVES][HEPT_MAX_TABLES][H][2]
+    float* tile_s = red_s + WAVES * HEPT_MAX_TABLES * H * 2;      // [WAVES][CHUNKS * 4]
 
-    const int tid = threadIdx.x, h = tid >> 5, p = tid & 31;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int h = lane & 7, p = lane >> 3;
     for (int i = tid; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
         const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
         alpha_s[i] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
     }
     for (int i = tid; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
+    __syncthreads();
+    f32x4* buf = reinterpret_cast<f32x4*>(tile_s + (size_t)w * CHUNKS * 4);
 
     float mn[HEPT_MAX_TABLES], mx[HEPT_MAX_TABLES];
 #pragma unroll
     for (int t = 0; t < HEPT_MAX_TABLES; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; }
 
     const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
-    for (int tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+    for (int tile_i = blockIdx.x * WAVES + w; tile_i < ntiles; tile_i += gridDim.x * WAVES) {
         const int n0 = tile_i * PREP_POINTS;
         const int rows = min(PREP_POINTS, N - n0);
         const int n = n0 + p;
         const bool live = p < rows;
-        float qa[32], ka[32], va[D];
+        const int valid_chunks = rows * (HD / 4);
+        const f32x4* q4 = reinterpret_cast<const f32x4*>(q + (size_t)n0 * HD);
+        const f32x4* k4 = reinterpret_cast<const f32x4*>(k + (size_t)n0 * HD);
+        const f32x4* v4 = reinterpret_cast<const f32x4*>(v + (size_t)n0 * HD);
+        f32x4 xq[LOADS], xk[LOADS], xv[LOADS];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) xq[j] = (j * 64 + lane < valid_chunks) ? q4[j * 64 + lane] : zero4;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) xk[j] = (j * 64 + lane < valid_chunks) ? k4[j * 64 + lane] : zero4;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) xv[j] = (j * 64 + lane < valid_chunks) ? v4[j * 64 + lane] : zero4;
+        float cs[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) cs[c] = live ? coords[(size_t)n * C + c] : 0.f;
 
-        __syncthreads();  // previous tile's readers are done (also covers alpha_s / sw_s on entry)
-        stage_tile<HD>(tile, q + (size_t)n0 * HD, rows, tid);
-        __syncthreads();
+        float qa[32], ka[32], va[D];
+        const f32x4* rowp = buf + lane * D4;  // row of lane (p,h) = chunks [lane*D/4, +D/4)
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) buf[j * 64 + lane] = xq[j];
 #pragma unroll
         for (int j = 0; j < D4; ++j) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(tile + p * LDT + h * D + 4 * j);
+            const f32x4 x = rowp[j];
             qa[4 * j] = x[0]; qa[4 * j + 1] = x[1]; qa[4 * j + 2] = x[2]; qa[4 * j + 3] = x[3];
         }
-        __syncthreads();
-        stage_tile<HD>(tile, k + (size_t)n0 * HD, rows, tid);
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) buf[j * 64 + lane] = xk[j];
 #pragma unroll
         for (int j = 0; j < D4; ++j) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(tile + p * LDT + h * D + 4 * j);
+            const f32x4 x = rowp[j];
             ka[4 * j] = x[0]; ka[4 * j + 1] = x[1]; ka[4 * j + 2] = x[2]; ka[4 * j + 3] = x[3];
         }
-        __syncthreads();
-        stage_tile<HD>(tile, v + (size_t)n0 * HD, rows, tid);
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) buf[j * 64 + lane] = xv[j];
 #pragma unroll
         for (int j = 0; j < D4; ++j) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(tile + p * LDT + h * D + 4 * j);
+            const f32x4 x = rowp[j];
             va[4 * j] = x[0]; va[4 * j + 1] = x[1]; va[4 * j + 2] = x[2]; va[4 * j + 3] = x[3];
         }
-        if (!live) continue;  // barriers of the next iteration are still reached by every thread
+        if (!live) continue;
 
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float s = sw_s[h * C + c] * coords[(size_t)n * C + c];
+            const float s = sw_s[h * C + c] * cs[c];
             qa[D + c] = s;
             ka[D + c] = s;
         }
@@ -153,16 +175,17 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
             unsigned int qw[16], kw[16], vw[16];
 #pragma unroll
             for (int i = 0; i < 15; ++i) {
-                qw[i] = hept_pack_bf16(qa[2 * i], qa[2 * i + 1]);
-                kw[i] = hept_pack_bf16(ka[2 * i], ka[2 * i + 1]);
+                qw[i] = (__float_as_uint(qa[2 * i]) >> 16) | (__float_as_uint(qa[2 * i + 1]) & 0xFFFF0000u);
+                kw[i] = (__float_as_uint(ka[2 * i]) >> 16) | (__float_as_uint(ka[2 * i + 1]) & 0xFFFF0000u);
             }
             qw[15] = __float_as_uint(qn);
             kw[15] = __float_as_uint(kn);
-            float vv[32];
 #pragma unroll
-            for (int d = 0; d < 32; ++d) vv[d] = d < D ? va[d] : (d == D ? 1.f : 0.f);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) vw[i] = hept_pack_bf16(vv[2 * i], vv[2 * i + 1]);
+            for (int i = 0; i < 16; ++i) {
+                const float lo = 2 * i < D ? va[2 * i < D ? 2 * i : 0] : (2 * i == D ? 1.f : 0.f);
+                const float hi = 2 * i + 1 < D ? va[2 * i + 1 < D ? 2 * i + 1 : 0] : (2 * i + 1 == D ? 1.f : 0.f);
+                vw[i] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 qd[j] = u32x4{qw[4 * j], qw[4 * j + 1], qw[4 * j + 2], qw[4 * j + 3]};
@@ -192,22 +215,34 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
         }
     }
 
-    // per-workgroup partial hash range: each 32-lane half owns one head
+    // per-workgroup partial hash range: lane keeps one head (h = lane & 7); fold the 8 point-lanes, then the waves
 #pragma unroll
     for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
         if (t < Tl) {
             float a = mn[t], b = mx[t];
 #pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) {
+            for (int off = 8; off <= 32; off <<= 1) {
                 a = fminf(a, __shfl_xor(a, off));
                 b = fmaxf(b, __shfl_xor(b, off));
             }
             if (p == 0) {
-                float* dst = minmax + (((size_t)blockIdx.x * Tl + t) * H + h) * 2;
-                dst[0] = a;
-                dst[1] = b;
+                red_s[((w * HEPT_MAX_TABLES + t) * H + h) * 2] = a;
+                red_s[((w * HEPT_MAX_TABLES + t) * H + h) * 2 + 1] = b;
             }
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < Tl * H; i += PREP_THREADS) {
+        const int t = i / H, hh = i % H;
+        float a = INFINITY, b = -INFINITY;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) {
+            a = fminf(a, red_s[((ww * HEPT_MAX_TABLES + t) * H + hh) * 2]);
+            b = fmaxf(b, red_s[((ww * HEPT_MAX_TABLES + t) * H + hh) * 2 + 1]);
+        }
+        float* dst = minmax + (((size_t)blockIdx.x * Tl + t) * H + hh) * 2;
+        dst[0] = a;
+        dst[1] = b;
     }
 }
 
@@ -216,7 +251,8 @@ int launch_prep(const float* q, const float* k, const float* v, const float* coo
                 const float* alpha, int N, int T, int t0, int Tl, int precision, void* qhat, void* kvhat,
                 float* qproj, float* kproj, float* minmax, hipStream_t st) {
     constexpr int H = 8, E = D + C;
-    const size_t lds = sizeof(float) * (PREP_POINTS * (H * D + 4) + H * E * HEPT_MAX_TABLES + H * C);
+    const size_t lds = sizeof(float) * (H * E * HEPT_MAX_TABLES + ((H * C + 3) & ~3) +
+                                        (PREP_THREADS / HEPT_WAVE) * (HEPT_MAX_TABLES * H * 2 + PREP_POINTS * H * D));
     const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
     // the sort kernel reduces exactly HEPT_PREP_GRID partials: idle workgroups still write theirs
     const int grid = HEPT_PREP_GRID;
@@ -234,8 +270,8 @@ int launch_prep(const float* q, const float* k, const float* v, const float* coo
 
 extern "C" int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, float* sqrt_w, void* stream) {
     if (!w_rpe || !sqrt_w) return HEPT_ERR_ARG;
-    if (H < 1 || D < 1 || C < 2 || K < 1) return HEPT_ERR_SHAPE;
-    hipLaunchKernelGGL(rpe_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w_rpe, H, D, C, K, sqrt_w);
+    if (H < 1 || D < 1 || C < 2 || K < 1 || H * (C - 1) * K > 1024) return HEPT_ERR_SHAPE;
+    hipLaunchKernelGGL(rpe_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_rpe, H, D, C, K, sqrt_w);
     return hept_launch_status();
 }
 

@@ -62,7 +62,7 @@ def test_workspace_size_model(lib):
     assert fp - bf == pytest.approx(rows * 2, rel=1e-3)
     part = t * n * h * 32 * 4
     assert bf > part + rows * 2 and bf < 2.5 * (part + rows * 2)
-    assert lib.hept_sort_workspace_bytes(n, h, t) > 2 * t * h * n * (4 + 8 + 8)
+    assert lib.hept_sort_workspace_bytes(n, h, t) > 2 * t * h * n * (4 + 4 + 4)
 
 
 def test_null_pointers_are_rejected_before_any_launch(lib):
