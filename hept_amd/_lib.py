@@ -11,7 +11,7 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p
 
 from .build import LIB_PATH
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PREC_F32, PREC_BF16 = 0, 1
 ROW = 32
 MAX_TABLES = 8
@@ -31,7 +31,7 @@ SIGNATURES = {
     "hept_check_shape": (c_int, [c_int] * 6),
     "hept_workspace_bytes": (c_size_t, [c_int] * 7),
     "hept_rpe_scale": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
-    "hept_prep_hash": (c_int, [_P] * 6 + [c_int] * 8 + [_P] * 6),
+    "hept_prep_hash": (c_int, [_P] * 7 + [c_int] * 8 + [_P] * 6),
     "hept_sort_workspace_bytes": (c_size_t, [c_int] * 3),
     "hept_sort_tables": (c_int, [_P] * 4 + [c_int] * 5 + [_P] * 4),
     "hept_block_attn": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P]),

@@ -34,7 +34,7 @@ Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
     w.kvhat = take((size_t)H * N * 64 * esz);
     w.qproj = reinterpret_cast<float*>(take((size_t)Tl * H * N * 4));
     w.kproj = reinterpret_cast<float*>(take((size_t)Tl * H * N * 4));
-    w.minmax = reinterpret_cast<float*>(take((size_t)HEPT_PREP_GRID * Tl * H * 2 * 4));
+    w.minmax = reinterpret_cast<float*>(take((size_t)HEPT_PREP_GRID * Tl * H * 4 * 4));
     w.pos = reinterpret_cast<int32_t*>(take((size_t)2 * Tl * H * N * 4));
     w.sort_ws = take(hept_sort_workspace_bytes(N, H, Tl));
     w.part = reinterpret_cast<float*>(take((size_t)Tl * N * H * 32 * 4));
@@ -65,8 +65,8 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
     prof_mark(0, st);
     int rc = hept_rpe_scale(w_rpe, H, D, C, K, w.sqrt_w, stream);
     if (rc) return rc;
-    rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, N, H, D, C, T, t0, Tl, precision, w.qhat, w.kvhat, w.qproj,
-                        w.kproj, w.minmax, stream);
+    rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, codes, N, H, D, C, T, t0, Tl, precision, w.qhat, w.kvhat,
+                        w.qproj, w.kproj, w.minmax, stream);
     if (rc) return rc;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)Tl * H * N;
@@ -81,7 +81,7 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 1; }
+extern "C" int hept_abi_version(void) { return 2; }
 
 extern "C" int hept_check_shape(int N, int H, int D, int C, int Tl, int B) {
     if (N < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0) return HEPT_ERR_SHAPE;

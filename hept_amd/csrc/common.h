@@ -17,17 +17,17 @@ static inline int hept_launch_status() {
     return e == hipSuccess ? HEPT_OK : HEPT_ERR_LAUNCH;
 }
 
-// float -> bf16 bits, round to nearest even (inputs are finite here).
-__device__ __forceinline__ unsigned int hept_bf16_bits(float x) {
-    unsigned int u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float hept_bf16_round(float x) {
-    return __uint_as_float(hept_bf16_bits(x) << 16);
-}
+// float -> bf16, round to nearest even, on the hardware converter (v_cvt_pk_bf16_f32)
+typedef __attribute__((ext_vector_type(2))) float hept_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 hept_bf16x2;
 __device__ __forceinline__ unsigned int hept_pack_bf16(float lo, float hi) {
-    return hept_bf16_bits(lo) | (hept_bf16_bits(hi) << 16);
+    const hept_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hept_bf16x2));
 }
+__device__ __forceinline__ float hept_bf16_round(float x) { return (float)(__bf16)x; }
+// the two bf16 halves of a packed dword, widened back to fp32
+__device__ __forceinline__ float hept_bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hept_bf16_hi(unsigned int w) { return __uint_as_float(w & 0xFFFF0000u); }
 
 // Row of the 32x32 MFMA accumulator held in register r by lane-half hh
 // (C/D layout of v_mfma_f32_32x32x*: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).

@@ -50,24 +50,27 @@ __global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict
 //   * the 8 points' q (then k, then v) rows are one contiguous 6-KiB run of the (N, H*D) input:
 //     six fully coalesced 16-B loads per lane,
 //   * a wave-private LDS buffer turns "lane = 16-B chunk" into "lane = (point, head) row of D floats"
-//     (LDS executes one wave's accesses in order, so no barrier is needed),
-//   * lane (p = lane >> 3, h = lane & 7) then augments, hashes and writes its own rows.
+//     (LDS executes one wave's accesses in order, so no barrier is needed); rows are padded to an odd
+//     number of 16-B slots so that the row reads are bank-conflict free,
+//   * lane (p = lane >> 3, h = lane & 7) then augments, hashes and writes its own rows; q, k and v
+//     are finished one after the other to keep the register footprint (and so the occupancy) in check.
 template <int D, int C, bool BF16>
 __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
-    int N, int T, int t0, int Tl, void* __restrict__ qhat_, void* __restrict__ kvhat_,
-    float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
+    const int64_t* __restrict__ codes, int N, int T, int t0, int Tl, void* __restrict__ qhat_,
+    void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
     constexpr int H = 8, E = D + C, HD = H * D, D4 = D / 4;
     constexpr int CHUNKS = PREP_POINTS * HD / 4;        // 16-B chunks per 8-point tile (384)
     constexpr int LOADS = CHUNKS / HEPT_WAVE;           // per lane (6)
     constexpr int WAVES = PREP_THREADS / HEPT_WAVE;
+    constexpr int ROW4 = D4 | 1;                        // LDS row pitch in 16-B slots (odd: 7 for D = 24)
     static_assert(D % 4 == 0 && E <= 30 && D <= 28 && CHUNKS % HEPT_WAVE == 0, "row packing needs D%4==0, E<=30");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* alpha_s = smem;                                        // [H][E][HEPT_MAX_TABLES]
     float* sw_s = alpha_s + H * E * HEPT_MAX_TABLES;              // [H][C] (+ pad to 16 B)
-    float* red_s = sw_s + ((H * C + 3) & ~3);                     // [WAVES][HEPT_MAX_TABLES][H][2]
-    float* tile_s = red_s + WAVES * HEPT_MAX_TABLES * H * 2;      // [WAVES][CHUNKS * 4]
+    float* red_s = sw_s + ((H * C + 3) & ~3);                     // [WAVES][HEPT_MAX_TABLES][H][4]
+    float* tile_s = red_s + WAVES * HEPT_MAX_TABLES * H * 4;      // [WAVES][64 rows][ROW4 * 4]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = lane & 7, p = lane >> 3;
@@ -77,11 +80,19 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     }
     for (int i = tid; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
     __syncthreads();
-    f32x4* buf = reinterpret_cast<f32x4*>(tile_s + (size_t)w * CHUNKS * 4);
-
-    float mn[HEPT_MAX_TABLES], mx[HEPT_MAX_TABLES];
+    f32x4* buf = reinterpret_cast<f32x4*>(tile_s) + (size_t)w * 64 * ROW4;
+    // chunk c of the tile belongs to row c / D4 (= lane of the reader), slot c % D4
+    int wslot[LOADS];
 #pragma unroll
-    for (int t = 0; t < HEPT_MAX_TABLES; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; }
+    for (int j = 0; j < LOADS; ++j) {
+        const int c = j * 64 + lane;
+        wslot[j] = (c / D4) * ROW4 + (c % D4);
+    }
+    const f32x4* rowp = buf + lane * ROW4;
+
+    float mn[HEPT_MAX_TABLES], mx[HEPT_MAX_TABLES], cm[HEPT_MAX_TABLES];
+#pragma unroll
+    for (int t = 0; t < HEPT_MAX_TABLES; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; cm[t] = 0.f; }
 
     const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
     for (int tile_i = blockIdx.x * WAVES + w; tile_i < ntiles; tile_i += gridDim.x * WAVES) {
@@ -93,124 +104,103 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
         const f32x4* q4 = reinterpret_cast<const f32x4*>(q + (size_t)n0 * HD);
         const f32x4* k4 = reinterpret_cast<const f32x4*>(k + (size_t)n0 * HD);
         const f32x4* v4 = reinterpret_cast<const f32x4*>(v + (size_t)n0 * HD);
-        f32x4 xq[LOADS], xk[LOADS], xv[LOADS];
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 xq[LOADS], xk[LOADS], xv[LOADS];
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) xq[j] = (j * 64 + lane < valid_chunks) ? q4[j * 64 + lane] : zero4;
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) xk[j] = (j * 64 + lane < valid_chunks) ? k4[j * 64 + lane] : zero4;
+        float sc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) sc[c] = live ? sw_s[h * C + c] * coords[(size_t)n * C + c] : 0.f;
+        // largest AND code of this (table, head): bounds the sort-key range for sort_tables
+#pragma unroll
+        for (int t = 0; t < HEPT_MAX_TABLES; ++t)
+            if (t < Tl && live) cm[t] = fmaxf(cm[t], __ll2float_ru(codes[((size_t)(t0 + t) * H + h) * N + n]));
+
+        // ---- one augmented row (q^ or k^): projections, rounding, norm, store
+        auto finish_row = [&](const f32x4* xin, float* __restrict__ proj, char* __restrict__ dst) {
+            float a[32];
+#pragma unroll
+            for (int j = 0; j < LOADS; ++j) buf[wslot[j]] = xin[j];
+#pragma unroll
+            for (int j = 0; j < D4; ++j) {
+                const f32x4 x = rowp[j];
+                a[4 * j] = x[0]; a[4 * j + 1] = x[1]; a[4 * j + 2] = x[2]; a[4 * j + 3] = x[3];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) a[D + c] = sc[c];
+#pragma unroll
+            for (int e = E; e < 32; ++e) a[e] = 0.f;
+            if (!live) return;
+            // E2LSH projections from the unrounded fp32 row; ascending-e fma chain
+#pragma unroll
+            for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
+                if (t < Tl) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc = fmaf(a[e], alpha_s[(h * E + e) * HEPT_MAX_TABLES + t], acc);
+                    proj[((size_t)t * H + h) * N + n] = acc;
+                    mn[t] = fminf(mn[t], acc);
+                    mx[t] = fmaxf(mx[t], acc);
+                }
+            }
+            float ss = 0.f;
+            if (BF16) {
+                unsigned int wd[16];
+#pragma unroll
+                for (int i = 0; i < 15; ++i) {
+                    wd[i] = hept_pack_bf16(a[2 * i], a[2 * i + 1]);
+                    const float r0 = hept_bf16_lo(wd[i]), r1 = hept_bf16_hi(wd[i]);  // norm of the ROUNDED values
+                    ss = fmaf(r0, r0, ss);
+                    ss = fmaf(r1, r1, ss);
+                }
+                wd[15] = __float_as_uint(-0.5f * ss);
+                u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d4[j] = u32x4{wd[4 * j], wd[4 * j + 1], wd[4 * j + 2], wd[4 * j + 3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) ss = fmaf(a[e], a[e], ss);
+                a[31] = -0.5f * ss;
+                f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d4[j] = f32x4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
+            }
+        };
+
+        const size_t row = (size_t)h * N + (live ? n : 0);
+        constexpr int QROW = BF16 ? 64 : 128;
+        char* qdst = reinterpret_cast<char*>(qhat_) + row * QROW;
+        char* kdst = reinterpret_cast<char*>(kvhat_) + row * 2 * QROW;
+        finish_row(xq, qproj, qdst);
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) xv[j] = (j * 64 + lane < valid_chunks) ? v4[j * 64 + lane] : zero4;
-        float cs[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) cs[c] = live ? coords[(size_t)n * C + c] : 0.f;
+        finish_row(xk, kproj, kdst);
 
-        float qa[32], ka[32], va[D];
-        const f32x4* rowp = buf + lane * D4;  // row of lane (p,h) = chunks [lane*D/4, +D/4)
+        // ---- value row: [v | 1.0 at column D | 0]
 #pragma unroll
-        for (int j = 0; j < LOADS; ++j) buf[j * 64 + lane] = xq[j];
+        for (int j = 0; j < LOADS; ++j) buf[wslot[j]] = xv[j];
+        float vv[32];
 #pragma unroll
         for (int j = 0; j < D4; ++j) {
             const f32x4 x = rowp[j];
-            qa[4 * j] = x[0]; qa[4 * j + 1] = x[1]; qa[4 * j + 2] = x[2]; qa[4 * j + 3] = x[3];
+            vv[4 * j] = x[0]; vv[4 * j + 1] = x[1]; vv[4 * j + 2] = x[2]; vv[4 * j + 3] = x[3];
         }
+        vv[D] = 1.f;
 #pragma unroll
-        for (int j = 0; j < LOADS; ++j) buf[j * 64 + lane] = xk[j];
+        for (int d = D + 1; d < 32; ++d) vv[d] = 0.f;
+        if (live) {
+            if (BF16) {
+                u32x4* d4 = reinterpret_cast<u32x4*>(kdst + QROW);
 #pragma unroll
-        for (int j = 0; j < D4; ++j) {
-            const f32x4 x = rowp[j];
-            ka[4 * j] = x[0]; ka[4 * j + 1] = x[1]; ka[4 * j + 2] = x[2]; ka[4 * j + 3] = x[3];
-        }
+                for (int j = 0; j < 4; ++j)
+                    d4[j] = u32x4{hept_pack_bf16(vv[8 * j], vv[8 * j + 1]), hept_pack_bf16(vv[8 * j + 2], vv[8 * j + 3]),
+                                  hept_pack_bf16(vv[8 * j + 4], vv[8 * j + 5]), hept_pack_bf16(vv[8 * j + 6], vv[8 * j + 7])};
+            } else {
+                f32x4* d4 = reinterpret_cast<f32x4*>(kdst + QROW);
 #pragma unroll
-        for (int j = 0; j < LOADS; ++j) buf[j * 64 + lane] = xv[j];
-#pragma unroll
-        for (int j = 0; j < D4; ++j) {
-            const f32x4 x = rowp[j];
-            va[4 * j] = x[0]; va[4 * j + 1] = x[1]; va[4 * j + 2] = x[2]; va[4 * j + 3] = x[3];
-        }
-        if (!live) continue;
-
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float s = sw_s[h * C + c] * cs[c];
-            qa[D + c] = s;
-            ka[D + c] = s;
-        }
-#pragma unroll
-        for (int e = E; e < 32; ++e) { qa[e] = 0.f; ka[e] = 0.f; }
-
-        // E2LSH projections from the unrounded fp32 rows; ascending-e fma chain.
-#pragma unroll
-        for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
-            if (t < Tl) {
-                float aq = 0.f, ak = 0.f;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const float a = alpha_s[(h * E + e) * HEPT_MAX_TABLES + t];
-                    aq = fmaf(qa[e], a, aq);
-                    ak = fmaf(ka[e], a, ak);
-                }
-                qproj[((size_t)t * H + h) * N + n] = aq;
-                kproj[((size_t)t * H + h) * N + n] = ak;
-                mn[t] = fminf(mn[t], fminf(aq, ak));
-                mx[t] = fmaxf(mx[t], fmaxf(aq, ak));
-            }
-        }
-
-        if (BF16) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) { qa[e] = hept_bf16_round(qa[e]); ka[e] = hept_bf16_round(ka[e]); }
-#pragma unroll
-            for (int d = 0; d < D; ++d) va[d] = hept_bf16_round(va[d]);
-        }
-        float qs = 0.f, ks = 0.f;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { qs = fmaf(qa[e], qa[e], qs); ks = fmaf(ka[e], ka[e], ks); }
-        const float qn = -0.5f * qs, kn = -0.5f * ks;
-
-        const size_t row = (size_t)h * N + n;
-        if (BF16) {
-            u32x4* qd = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(qhat_) + row * 64);
-            u32x4* kd = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(kvhat_) + row * 128);
-            unsigned int qw[16], kw[16], vw[16];
-#pragma unroll
-            for (int i = 0; i < 15; ++i) {
-                qw[i] = (__float_as_uint(qa[2 * i]) >> 16) | (__float_as_uint(qa[2 * i + 1]) & 0xFFFF0000u);
-                kw[i] = (__float_as_uint(ka[2 * i]) >> 16) | (__float_as_uint(ka[2 * i + 1]) & 0xFFFF0000u);
-            }
-            qw[15] = __float_as_uint(qn);
-            kw[15] = __float_as_uint(kn);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float lo = 2 * i < D ? va[2 * i < D ? 2 * i : 0] : (2 * i == D ? 1.f : 0.f);
-                const float hi = 2 * i + 1 < D ? va[2 * i + 1 < D ? 2 * i + 1 : 0] : (2 * i + 1 == D ? 1.f : 0.f);
-                vw[i] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                qd[j] = u32x4{qw[4 * j], qw[4 * j + 1], qw[4 * j + 2], qw[4 * j + 3]};
-                kd[j] = u32x4{kw[4 * j], kw[4 * j + 1], kw[4 * j + 2], kw[4 * j + 3]};
-                kd[4 + j] = u32x4{vw[4 * j], vw[4 * j + 1], vw[4 * j + 2], vw[4 * j + 3]};
-            }
-        } else {
-            f32x4* qd = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(qhat_) + row * 128);
-            f32x4* kd = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(kvhat_) + row * 256);
-            qa[31] = qn;
-            ka[31] = kn;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                qd[j] = f32x4{qa[4 * j], qa[4 * j + 1], qa[4 * j + 2], qa[4 * j + 3]};
-                kd[j] = f32x4{ka[4 * j], ka[4 * j + 1], ka[4 * j + 2], ka[4 * j + 3]};
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f32x4 x;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int d = 4 * j + u;
-                    x[u] = d < D ? va[d < D ? d : 0] : (d == D ? 1.f : 0.f);
-                }
-                kd[8 + j] = x;
+                for (int j = 0; j < 8; ++j) d4[j] = f32x4{vv[4 * j], vv[4 * j + 1], vv[4 * j + 2], vv[4 * j + 3]};
             }
         }
     }
@@ -219,50 +209,53 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
 #pragma unroll
     for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
         if (t < Tl) {
-            float a = mn[t], b = mx[t];
+            float a = mn[t], b = mx[t], c = cm[t];
 #pragma unroll
             for (int off = 8; off <= 32; off <<= 1) {
                 a = fminf(a, __shfl_xor(a, off));
                 b = fmaxf(b, __shfl_xor(b, off));
+                c = fmaxf(c, __shfl_xor(c, off));
             }
             if (p == 0) {
-                red_s[((w * HEPT_MAX_TABLES + t) * H + h) * 2] = a;
-                red_s[((w * HEPT_MAX_TABLES + t) * H + h) * 2 + 1] = b;
+                float* r = red_s + ((w * HEPT_MAX_TABLES + t) * H + h) * 4;
+                r[0] = a; r[1] = b; r[2] = c;
             }
         }
     }
     __syncthreads();
     for (int i = tid; i < Tl * H; i += PREP_THREADS) {
         const int t = i / H, hh = i % H;
-        float a = INFINITY, b = -INFINITY;
+        float a = INFINITY, b = -INFINITY, c = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) {
-            a = fminf(a, red_s[((ww * HEPT_MAX_TABLES + t) * H + hh) * 2]);
-            b = fmaxf(b, red_s[((ww * HEPT_MAX_TABLES + t) * H + hh) * 2 + 1]);
+            const float* r = red_s + ((ww * HEPT_MAX_TABLES + t) * H + hh) * 4;
+            a = fminf(a, r[0]);
+            b = fmaxf(b, r[1]);
+            c = fmaxf(c, r[2]);
         }
-        float* dst = minmax + (((size_t)blockIdx.x * Tl + t) * H + hh) * 2;
-        dst[0] = a;
-        dst[1] = b;
+        // layout [Tl][H][grid][4]: the sort kernels reduce one (t,h) row with contiguous 16-B loads
+        *reinterpret_cast<f32x4*>(minmax + (((size_t)t * H + hh) * gridDim.x + blockIdx.x) * 4) = f32x4{a, b, c, 0.f};
     }
 }
 
 template <int D, int C>
 int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w,
-                const float* alpha, int N, int T, int t0, int Tl, int precision, void* qhat, void* kvhat,
+                const float* alpha, const int64_t* codes, int N, int T, int t0, int Tl, int precision, void* qhat,
+                void* kvhat,
                 float* qproj, float* kproj, float* minmax, hipStream_t st) {
     constexpr int H = 8, E = D + C;
     const size_t lds = sizeof(float) * (H * E * HEPT_MAX_TABLES + ((H * C + 3) & ~3) +
-                                        (PREP_THREADS / HEPT_WAVE) * (HEPT_MAX_TABLES * H * 2 + PREP_POINTS * H * D));
+                                        (PREP_THREADS / HEPT_WAVE) * (HEPT_MAX_TABLES * H * 4 + 64 * ((D / 4) | 1) * 4));
     const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
     // the sort kernel reduces exactly HEPT_PREP_GRID partials: idle workgroups still write theirs
     const int grid = HEPT_PREP_GRID;
     (void)ntiles;
     if (precision == HEPT_PREC_BF16)
         hipLaunchKernelGGL((prep_hash_kernel<D, C, true>), dim3(grid), dim3(PREP_THREADS), lds, st, q, k, v, coords,
-                           sqrt_w, alpha, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     else
         hipLaunchKernelGGL((prep_hash_kernel<D, C, false>), dim3(grid), dim3(PREP_THREADS), lds, st, q, k, v, coords,
-                           sqrt_w, alpha, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     return hept_launch_status();
 }
 
@@ -276,18 +269,18 @@ extern "C" int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, fl
 }
 
 extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
-                              const float* sqrt_w, const float* alpha, int N, int H, int D, int C, int T, int t0,
-                              int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj,
-                              float* minmax, void* stream) {
-    if (!q || !k || !v || !coords || !sqrt_w || !alpha || !qhat || !kvhat || !qproj || !kproj || !minmax)
+                              const float* sqrt_w, const float* alpha, const int64_t* codes, int N, int H, int D,
+                              int C, int T, int t0, int Tl, int precision, void* qhat, void* kvhat, float* qproj,
+                              float* kproj, float* minmax, void* stream) {
+    if (!q || !k || !v || !coords || !sqrt_w || !alpha || !codes || !qhat || !kvhat || !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
     if (H != 8 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
     if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16) return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
 #define HEPT_PREP_CASE(DD, CC)                                                                             \
     if (D == DD && C == CC)                                                                                \
-        return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, alpha, N, T, t0, Tl, precision, qhat, kvhat,   \
-                                   qproj, kproj, minmax, st);
+        return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, alpha, codes, N, T, t0, Tl, precision, qhat,   \
+                                   kvhat, qproj, kproj, minmax, st);
     HEPT_PREP_CASE(24, 6)
     HEPT_PREP_CASE(24, 4)
     HEPT_PREP_CASE(24, 2)

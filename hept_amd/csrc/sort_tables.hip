@@ -9,10 +9,11 @@
 // exactly torch.sort(stable=True): ascending key, ties in ascending point index (the
 // reference's own argsort is unstable and leaves tie order undefined, SURVEY.md §7 hard part 1).
 //
-// Integer/byte work, HBM/L2-bound, five launches:
-//   K1 keygen   key -> order-preserving u32, per-chunk min/max
-//   K2 hist     per-chunk histogram of a MONOTONE bucket id b(key) = trunc((key-kmin)*NB/(kmax-kmin))
-//   K2b scan    histogram -> exclusive offsets [segment][chunk][bucket] (in place) + bucket starts
+// Integer/byte work, HBM/L2-bound, four launches:
+//   K1 keygen   key -> order-preserving u32 + per-chunk histogram of a MONOTONE bucket id
+//               b(key) = trunc((key - kmin) * NB / (kmax - kmin)); [kmin,kmax] is the a-priori bound
+//               [hash min, hash max + largest code * span] from the prep kernel's partials
+//   K2 scan     histogram -> exclusive offsets [segment][chunk][bucket] (in place) + bucket starts
 //   K3 scatter  stable counting-sort pass on b (wave-level ballots, 64-wide; no data-path atomics),
 //               (key,index) travel as one 8-byte pair
 //   K4 rank     every element counts the smaller keys of its own bucket -> final position
@@ -49,104 +50,94 @@ __device__ __forceinline__ int bucket_of(unsigned int u, float kmin, float scale
     return b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
 }
 
-struct SegRange {
+// per-segment bucket map parameters, written once by K1 (chunk 0) and read by K3 / K4
+struct SegParams {
     float kmin, scale;
 };
-// reduce the per-chunk [min,max] of a segment (written by K1); every thread gets the same answer
-__device__ __forceinline__ SegRange segment_range(const unsigned int* __restrict__ chunk_mm, int seg, int n_chunks) {
-    unsigned int lo = 0xFFFFFFFFu, hi = 0u;
-    for (int c = 0; c < n_chunks; ++c) {
-        lo = min(lo, chunk_mm[((size_t)seg * n_chunks + c) * 2]);
-        hi = max(hi, chunk_mm[((size_t)seg * n_chunks + c) * 2 + 1]);
-    }
-    SegRange r;
-    r.kmin = from_ordered(lo);
-    const float width = from_ordered(hi) - r.kmin;
-    r.scale = width > 0.f ? (float)NB / width : 0.f;
-    if (!(r.scale < 3.0e38f)) r.scale = 0.f;  // inf/nan guard for denormal widths: one bucket, still exact
-    return r;
-}
 
-// K1: keys0[seg][n] = ordered bits of (proj + float(code) * span); chunk_mm[seg][chunk] = [min,max]
-__global__ __launch_bounds__(SORT_THREADS) void keygen_kernel(
+// K1: keys0[seg][n] = ordered bits of (proj + float(code) * span); hist[seg][chunk][NB]; seg_params[seg]
+__global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
     const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
-    const float* __restrict__ minmax, int n_partials, int N, int H, int t0, int Tl,
-    unsigned int* __restrict__ keys0, unsigned int* __restrict__ chunk_mm, int n_chunks) {
-    __shared__ float red_s[2][SORT_THREADS / HEPT_WAVE];
-    __shared__ unsigned int redu_s[2][SORT_THREADS / HEPT_WAVE];
+    const float* __restrict__ minmax, int N, int H, int t0, int Tl, unsigned int* __restrict__ keys0,
+    unsigned int* __restrict__ hist, SegParams* __restrict__ seg_params, int n_chunks) {
+    __shared__ unsigned int h_s[NB];
+    __shared__ float red_s[3][SORT_THREADS / HEPT_WAVE];
     const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
     const int th = seg % (Tl * H);  // local (table, head)
     const bool is_k = seg >= Tl * H;
     const int t = th / H, h = th % H;
+#pragma unroll
+    for (int i = 0; i < NB_PER_THREAD; ++i) h_s[i * SORT_THREADS + tid] = 0;
 
-    // hash range of this (table, head): reduce the prep kernel's per-workgroup partials
-    float lo = INFINITY, hi = -INFINITY;
-    for (int i = tid; i < n_partials; i += SORT_THREADS) {
-        const float* m = minmax + (((size_t)i * Tl + t) * H + h) * 2;
-        lo = fminf(lo, m[0]);
-        hi = fmaxf(hi, m[1]);
+    // hash range + largest code of this (table, head): reduce the prep kernel's per-workgroup partials
+    float lo = INFINITY, hi = -INFINITY, cmax = 0.f;
+    {
+        f32x4 m[HEPT_PREP_GRID / SORT_THREADS];
+#pragma unroll
+        for (int i = 0; i < HEPT_PREP_GRID / SORT_THREADS; ++i)
+            m[i] = *reinterpret_cast<const f32x4*>(minmax + (((size_t)t * H + h) * HEPT_PREP_GRID + i * SORT_THREADS + tid) * 4);
+#pragma unroll
+        for (int i = 0; i < HEPT_PREP_GRID / SORT_THREADS; ++i) {
+            lo = fminf(lo, m[i][0]);
+            hi = fmaxf(hi, m[i][1]);
+            cmax = fmaxf(cmax, m[i][2]);
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, off));
         hi = fmaxf(hi, __shfl_xor(hi, off));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, off));
     }
-    if ((tid & 63) == 0) { red_s[0][tid >> 6] = lo; red_s[1][tid >> 6] = hi; }
+    if ((tid & 63) == 0) { red_s[0][tid >> 6] = lo; red_s[1][tid >> 6] = hi; red_s[2][tid >> 6] = cmax; }
     __syncthreads();
     lo = fminf(fminf(red_s[0][0], red_s[0][1]), fminf(red_s[0][2], red_s[0][3]));
     hi = fmaxf(fmaxf(red_s[1][0], red_s[1][1]), fmaxf(red_s[1][2], red_s[1][3]));
+    cmax = fmaxf(fmaxf(red_s[2][0], red_s[2][1]), fmaxf(red_s[2][2], red_s[2][3]));
     const float span = hi - lo;
+    // keys lie in [lo, hi + cmax*span] (codes >= 0); any key outside is clamped by bucket_of (still monotone)
+    const float width = (hi + cmax * span) - lo;
+    float scale = width > 0.f ? (float)NB / width : 0.f;
+    if (!(scale < 3.0e38f)) scale = 0.f;  // inf/nan guard for denormal widths: one bucket, still exact
+    if (chunk == 0 && tid == 0) seg_params[seg] = SegParams{lo, scale};
 
     const float* proj = (is_k ? kproj : qproj) + (size_t)th * N;
     const int64_t* code = codes + ((size_t)(t0 + t) * H + h) * N;
     unsigned int* kout = keys0 + (size_t)seg * N;
     const int base = chunk * SORT_CHUNK;
-    unsigned int umin = 0xFFFFFFFFu, umax = 0u;
-#pragma unroll 4
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int n = base + i * SORT_THREADS + tid;
-        if (n < N) {
-            // two separately rounded ops, as the two eager ops of the reference; HIP's __fmul_rn /
-            // __fadd_rn are plain * and + and would be contracted to one fma without
-            // -ffp-contract=off (Makefile) -- the asm barrier makes it explicit here as well
-            float off = (float)code[n] * span;
-            asm volatile("" : "+v"(off));
-            const unsigned int u = ordered_bits(proj[n] + off);
-            kout[n] = u;
-            umin = min(umin, u);
-            umax = max(umax, u);
+    // two separately rounded ops per key, as the two eager ops of the reference; HIP's __fmul_rn /
+    // __fadd_rn are plain * and + and would be contracted to one fma without -ffp-contract=off
+    // (Makefile) -- the asm barrier makes it explicit here as well
+    auto make_key = [&](float pj, long long cd) {
+        float off = (float)cd * span;
+        asm volatile("" : "+v"(off));
+        return ordered_bits(pj + off);
+    };
+    const bool vec_ok = (N % 4) == 0;  // segment bases stay 16-B aligned
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS / 4; ++i) {
+        const int n = base + (i * SORT_THREADS + tid) * 4;
+        if (vec_ok && n + 3 < N) {
+            typedef __attribute__((ext_vector_type(2))) long long i64x2;
+            const f32x4 pj = *reinterpret_cast<const f32x4*>(proj + n);
+            const i64x2 c01 = *reinterpret_cast<const i64x2*>(code + n);
+            const i64x2 c23 = *reinterpret_cast<const i64x2*>(code + n + 2);
+            u32x4 u;
+            u[0] = make_key(pj[0], c01[0]);
+            u[1] = make_key(pj[1], c01[1]);
+            u[2] = make_key(pj[2], c23[0]);
+            u[3] = make_key(pj[3], c23[1]);
+            *reinterpret_cast<u32x4*>(kout + n) = u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&h_s[bucket_of(u[e], lo, scale)], 1u);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (n + e < N) {
+                    const unsigned int u = make_key(proj[n + e], code[n + e]);
+                    kout[n + e] = u;
+                    atomicAdd(&h_s[bucket_of(u, lo, scale)], 1u);
+                }
         }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        umin = min(umin, (unsigned int)__shfl_xor((int)umin, off));
-        umax = max(umax, (unsigned int)__shfl_xor((int)umax, off));
-    }
-    if ((tid & 63) == 0) { redu_s[0][tid >> 6] = umin; redu_s[1][tid >> 6] = umax; }
-    __syncthreads();
-    if (tid == 0) {
-        chunk_mm[((size_t)seg * n_chunks + chunk) * 2] = min(min(redu_s[0][0], redu_s[0][1]), min(redu_s[0][2], redu_s[0][3]));
-        chunk_mm[((size_t)seg * n_chunks + chunk) * 2 + 1] =
-            max(max(redu_s[1][0], redu_s[1][1]), max(redu_s[1][2], redu_s[1][3]));
-    }
-}
-
-// K2: hist[seg][chunk][NB] of the bucket id
-__global__ __launch_bounds__(SORT_THREADS) void bucket_hist_kernel(const unsigned int* __restrict__ keys0,
-                                                                   const unsigned int* __restrict__ chunk_mm, int N,
-                                                                   unsigned int* __restrict__ hist, int n_chunks) {
-    __shared__ unsigned int h_s[NB];
-    const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
-#pragma unroll
-    for (int i = 0; i < NB_PER_THREAD; ++i) h_s[i * SORT_THREADS + tid] = 0;
-    const SegRange rg = segment_range(chunk_mm, seg, n_chunks);
-    __syncthreads();
-    const unsigned int* src = keys0 + (size_t)seg * N;
-    const int base = chunk * SORT_CHUNK;
-#pragma unroll 4
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int n = base + i * SORT_THREADS + tid;
-        if (n < N) atomicAdd(&h_s[bucket_of(src[n], rg.kmin, rg.scale)], 1u);
     }
     __syncthreads();
     unsigned int* dst = hist + ((size_t)seg * n_chunks + chunk) * NB;
@@ -154,20 +145,24 @@ __global__ __launch_bounds__(SORT_THREADS) void bucket_hist_kernel(const unsigne
     for (int i = 0; i < NB_PER_THREAD; ++i) dst[i * SORT_THREADS + tid] = h_s[i * SORT_THREADS + tid];
 }
 
-// K2b: one workgroup per segment.  hist[seg][c][b] <- start[b] + sum_{c' < c} hist[seg][c'][b];
+// K2: one workgroup per segment.  hist[seg][c][b] <- start[b] + sum_{c' < c} hist[seg][c'][b];
 // bucket_start[seg][b] = start[b] = number of keys in smaller buckets; bucket_start[seg][NB] = N.
 __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(unsigned int* __restrict__ hist, int n_chunks,
                                                                    unsigned int* __restrict__ bucket_start) {
     constexpr int PER = NB / SCAN_THREADS;  // 4 consecutive buckets per thread
     constexpr int WAVES = SCAN_THREADS / HEPT_WAVE;
+    constexpr int BATCH = 8;                // chunk rows in flight per thread
     __shared__ unsigned int wsum_s[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, seg = blockIdx.x;
     unsigned int* hseg = hist + (size_t)seg * n_chunks * NB + tid * PER;
-    unsigned int total[PER] = {0, 0, 0, 0};
-    for (int c = 0; c < n_chunks; ++c) {
-        const u32x4 x = *reinterpret_cast<const u32x4*>(hseg + (size_t)c * NB);
+    u32x4 total = {0u, 0u, 0u, 0u};
+    for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
+        u32x4 x[BATCH];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) total[i] += x[i];
+        for (int i = 0; i < BATCH; ++i)
+            x[i] = (c0 + i < n_chunks) ? *reinterpret_cast<const u32x4*>(hseg + (size_t)(c0 + i) * NB) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) total += x[i];
     }
     const unsigned int mine = total[0] + total[1] + total[2] + total[3];
     unsigned int incl = mine;
@@ -188,28 +183,34 @@ __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(unsigned int*
     }
     *reinterpret_cast<u32x4*>(bucket_start + (size_t)seg * (NB + 1) + tid * PER) = acc;
     if (tid == SCAN_THREADS - 1) bucket_start[(size_t)seg * (NB + 1) + NB] = run;
-    for (int c = 0; c < n_chunks; ++c) {
-        u32x4* p = reinterpret_cast<u32x4*>(hseg + (size_t)c * NB);
-        const u32x4 x = *p;
-        *p = acc;
-        acc += x;
+    for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
+        u32x4 x[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i)
+            x[i] = (c0 + i < n_chunks) ? *reinterpret_cast<const u32x4*>(hseg + (size_t)(c0 + i) * NB) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            if (c0 + i < n_chunks) *reinterpret_cast<u32x4*>(hseg + (size_t)(c0 + i) * NB) = acc;
+            acc += x[i];
+        }
     }
 }
 
 // K3: stable scatter by bucket id -> (key,index) pairs in bucket order
 __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(
-    const unsigned int* __restrict__ keys0, const unsigned int* __restrict__ chunk_mm,
+    const unsigned int* __restrict__ keys0, const SegParams* __restrict__ seg_params,
     const unsigned int* __restrict__ offs, int N, int n_chunks, unsigned long long* __restrict__ pairs) {
     constexpr int WAVES = SORT_THREADS / HEPT_WAVE;
-    __shared__ unsigned short cnt_s[WAVES][NB];  // per-wave bucket counters (<= 1024 keys per wave)
+    __shared__ __attribute__((aligned(16))) unsigned short cnt_s[WAVES][NB];  // per-wave bucket counters (<= 1024 keys per wave)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int seg = blockIdx.y, chunk = blockIdx.x;
-    const SegRange rg = segment_range(chunk_mm, seg, n_chunks);
+    const SegParams rg = seg_params[seg];
+    // this wave's counters only: no workgroup barrier needed before ranking
     {
-        unsigned int* z = reinterpret_cast<unsigned int*>(&cnt_s[0][0]);
-        for (int i = tid; i < WAVES * NB / 2; i += SORT_THREADS) z[i] = 0;
+        u32x4* z = reinterpret_cast<u32x4*>(&cnt_s[w][0]);
+#pragma unroll
+        for (int i = 0; i < NB * 2 / 16 / HEPT_WAVE; ++i) z[i * HEPT_WAVE + lane] = u32x4{0u, 0u, 0u, 0u};
     }
-    __syncthreads();
 
     // rank the chunk: wave w owns 1024 consecutive keys, 16 rounds of 64 (stable: index order)
     unsigned int key[SORT_ITEMS];
@@ -220,8 +221,12 @@ __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int n = wbase + r * HEPT_WAVE + lane;
+        key[r] = n < N ? keys0[seg_off + n] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int n = wbase + r * HEPT_WAVE + lane;
         const bool valid = n < N;
-        key[r] = valid ? keys0[seg_off + n] : 0xFFFFFFFFu;
         const unsigned int dg = valid ? (unsigned int)bucket_of(key[r], rg.kmin, rg.scale) : (unsigned int)(NB - 1);
         dig[r] = (unsigned short)dg;
         unsigned long long peers = __ballot(valid);
@@ -236,55 +241,88 @@ __global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(
         if (valid && ahead == 0) cnt_s[w][dg] = (unsigned short)(prior + __popcll(peers));
         rank[r] = (unsigned short)(prior + ahead);
     }
-    __syncthreads();
-    // per-wave counters -> exclusive prefix over the waves of this workgroup
-#pragma unroll
-    for (int i = 0; i < NB_PER_THREAD; ++i) {
-        const int d = i * SORT_THREADS + tid;
-        unsigned int acc = 0;
-#pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww) {
-            const unsigned int c = cnt_s[ww][d];
-            cnt_s[ww][d] = (unsigned short)acc;
-            acc += c;
-        }
-    }
-    __syncthreads();
     const unsigned int* off_c = offs + ((size_t)seg * n_chunks + chunk) * NB;
+    unsigned int base_r[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) base_r[r] = off_c[dig[r]];
+    __syncthreads();
+    // keys of the same bucket held by earlier waves of this workgroup come first (only the touched
+    // counters are read: the chunk has as many keys as there are buckets)
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
+        unsigned int before_w = 0;
+#pragma unroll
+        for (int ww = 0; ww < WAVES - 1; ++ww)
+            if (ww < w) before_w += cnt_s[ww][dig[r]];
         const int n = wbase + r * HEPT_WAVE + lane;
         if (n < N) {
-            const size_t dst = seg_off + off_c[dig[r]] + cnt_s[w][dig[r]] + rank[r];
+            const size_t dst = seg_off + base_r[r] + before_w + rank[r];
             pairs[dst] = ((unsigned long long)key[r] << 32) | (unsigned int)n;
         }
     }
 }
 
-// K4: final position = bucket start + number of keys of the same bucket that sort before this one
+// K4: final position = bucket start + number of pairs of the same bucket that are smaller.  A pair is
+// (key << 32 | index); inside a bucket the scatter kept ascending index order, so u64 order of the pairs
+// is exactly (key, then original index): the stable tie rule.  The workgroup's 256 positions plus the
+// rest of their first/last buckets are staged in LDS (same-address reads broadcast within a wave).
+constexpr int RANK_PER_THREAD = 4;
+constexpr int RANK_SPAN = SORT_THREADS * RANK_PER_THREAD;  // positions per workgroup
+constexpr int RANK_CAP = 2048;
 __global__ __launch_bounds__(SORT_THREADS) void bucket_rank_kernel(const unsigned long long* __restrict__ pairs,
-                                                                   const unsigned int* __restrict__ chunk_mm,
+                                                                   const SegParams* __restrict__ seg_params,
                                                                    const unsigned int* __restrict__ bucket_start,
-                                                                   int N, int n_chunks, int* __restrict__ pos_out) {
-    const int seg = blockIdx.y;
-    const int i = blockIdx.x * SORT_THREADS + threadIdx.x;
-    const SegRange rg = segment_range(chunk_mm, seg, n_chunks);
-    if (i >= N) return;
-    const uint2* pr = reinterpret_cast<const uint2*>(pairs + (size_t)seg * N);  // .x = index, .y = key
-    const uint2 mine = pr[i];
-    const unsigned int me = mine.y;
-    const int b = bucket_of(me, rg.kmin, rg.scale);
+                                                                   int N, int* __restrict__ pos_out) {
+    __shared__ unsigned long long p_s[RANK_CAP];
+    __shared__ int range_s[2];
+    const int seg = blockIdx.y, tid = threadIdx.x;
+    const int i0 = blockIdx.x * RANK_SPAN;
+    const int last = min(i0 + RANK_SPAN, N) - 1;
+    const SegParams rg = seg_params[seg];
+    const unsigned long long* pr = pairs + (size_t)seg * N;
     const unsigned int* bs = bucket_start + (size_t)seg * (NB + 1);
-    const int s = (int)bs[b], e = (int)bs[b + 1];
-    // keys of one bucket are contiguous; lanes of a wave mostly share a bucket, so the loads broadcast.
-    // j < i in bucket order <=> smaller original index (the scatter pass is stable).
-    int smaller = 0;
-#pragma unroll 4
-    for (int j = s; j < e; ++j) {
-        const unsigned int kj = pr[j].y;
-        smaller += (kj < me) || (kj == me && j < i);
+    unsigned long long mine[RANK_PER_THREAD];
+    int s[RANK_PER_THREAD], e[RANK_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < RANK_PER_THREAD; ++u) {
+        const int i = i0 + u * SORT_THREADS + tid;
+        mine[u] = i < N ? pr[i] : 0ull;
     }
-    pos_out[(size_t)seg * N + s + smaller] = (int)mine.x;
+#pragma unroll
+    for (int u = 0; u < RANK_PER_THREAD; ++u) {
+        const int i = i0 + u * SORT_THREADS + tid;
+        s[u] = 0;
+        e[u] = 0;
+        if (i < N) {
+            const int b = bucket_of((unsigned int)(mine[u] >> 32), rg.kmin, rg.scale);
+            s[u] = (int)bs[b];
+            e[u] = (int)bs[b + 1];
+        }
+        if (i == i0) range_s[0] = s[u];
+        if (i == last) range_s[1] = e[u];
+    }
+    __syncthreads();
+    const int lo = range_s[0], hi = range_s[1];
+    int smaller[RANK_PER_THREAD] = {0, 0, 0, 0};
+    if (hi - lo <= RANK_CAP) {
+        for (int j = lo + tid; j < hi; j += SORT_THREADS) p_s[j - lo] = pr[j];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RANK_PER_THREAD; ++u) {
+#pragma unroll 4
+            for (int j = s[u]; j < e[u]; ++j) smaller[u] += p_s[j - lo] < mine[u];
+        }
+    } else {
+        // oversized bucket(s): same count straight from memory (slow path, adversarial inputs only)
+#pragma unroll
+        for (int u = 0; u < RANK_PER_THREAD; ++u)
+            for (int j = s[u]; j < e[u]; ++j) smaller[u] += pr[j] < mine[u];
+    }
+#pragma unroll
+    for (int u = 0; u < RANK_PER_THREAD; ++u) {
+        const int i = i0 + u * SORT_THREADS + tid;
+        if (i < N) pos_out[(size_t)seg * N + s[u] + smaller[u]] = (int)(unsigned int)mine[u];
+    }
 }
 
 }  // namespace
@@ -295,7 +333,7 @@ extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) {
     const size_t segs = (size_t)2 * Tl * H;
     const size_t n_chunks = ((size_t)N + SORT_CHUNK - 1) / SORT_CHUNK;
     return align256(segs * N * 4) + align256(segs * N * 8) + align256(segs * n_chunks * NB * 4) +
-           align256(segs * n_chunks * 2 * 4) + align256(segs * (NB + 1) * 4);
+           align256(segs * sizeof(SegParams)) + align256(segs * (NB + 1) * 4);
 }
 
 extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* codes, const float* minmax,
@@ -316,16 +354,15 @@ extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const in
     unsigned int* keys0 = reinterpret_cast<unsigned int*>(take((size_t)segs * N * 4));
     unsigned long long* pairs = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
     unsigned int* hist = reinterpret_cast<unsigned int*>(take((size_t)segs * n_chunks * NB * 4));
-    unsigned int* chunk_mm = reinterpret_cast<unsigned int*>(take((size_t)segs * n_chunks * 2 * 4));
+    SegParams* params = reinterpret_cast<SegParams*>(take((size_t)segs * sizeof(SegParams)));
     unsigned int* bstart = reinterpret_cast<unsigned int*>(take((size_t)segs * (NB + 1) * 4));
 
     const dim3 grid(n_chunks, segs), block(SORT_THREADS);
-    hipLaunchKernelGGL(keygen_kernel, grid, block, 0, st, qproj, kproj, codes, minmax, HEPT_PREP_GRID, N, H, t0, Tl,
-                       keys0, chunk_mm, n_chunks);
-    hipLaunchKernelGGL(bucket_hist_kernel, grid, block, 0, st, keys0, chunk_mm, N, hist, n_chunks);
+    hipLaunchKernelGGL(keygen_hist_kernel, grid, block, 0, st, qproj, kproj, codes, minmax, N, H, t0, Tl, keys0, hist,
+                       params, n_chunks);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(segs), dim3(SCAN_THREADS), 0, st, hist, n_chunks, bstart);
-    hipLaunchKernelGGL(bucket_scatter_kernel, grid, block, 0, st, keys0, chunk_mm, hist, N, n_chunks, pairs);
-    const dim3 grid4((N + SORT_THREADS - 1) / SORT_THREADS, segs);
-    hipLaunchKernelGGL(bucket_rank_kernel, grid4, block, 0, st, pairs, chunk_mm, bstart, N, n_chunks, qpos);
+    hipLaunchKernelGGL(bucket_scatter_kernel, grid, block, 0, st, keys0, params, hist, N, n_chunks, pairs);
+    const dim3 grid4((N + RANK_SPAN - 1) / RANK_SPAN, segs);
+    hipLaunchKernelGGL(bucket_rank_kernel, grid4, block, 0, st, pairs, params, bstart, N, qpos);
     return hept_launch_status();
 }

@@ -64,12 +64,15 @@ def rpe_scale(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dis
     return out
 
 
-def prep_hash(q, k, v, coords, sqrt_w, alpha, precision="fp32", t0: int = 0, tl: Optional[int] = None) -> Dict[str, torch.Tensor]:
+def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int = 0, tl: Optional[int] = None) -> Dict[str, torch.Tensor]:
     lib = _lib.load()
     q, k, v, coords, sqrt_w, alpha = (_f32c(x, nm) for x, nm in
                                       ((q, "query"), (k, "key"), (v, "value"), (coords, "coords"),
                                        (sqrt_w, "sqrt_w"), (alpha, "alpha")))
     n, h, d, c, t = _dims(q, coords, alpha)
+    if codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n):
+        raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}")
+    codes = codes.contiguous()
     tl = t - t0 if tl is None else tl
     prec = precision_code(precision)
     tile = torch.bfloat16 if prec == PREC_BF16 else torch.float32
@@ -78,9 +81,9 @@ def prep_hash(q, k, v, coords, sqrt_w, alpha, precision="fp32", t0: int = 0, tl:
     kvhat = torch.empty(h, n, 64, device=dev, dtype=tile)
     qproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
     kproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
-    minmax = torch.empty(_lib.PREP_GRID, tl, h, 2, device=dev, dtype=torch.float32)
+    minmax = torch.empty(tl, h, _lib.PREP_GRID, 4, device=dev, dtype=torch.float32)
     _lib.check(lib.hept_prep_hash(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), sqrt_w.data_ptr(),
-                                  alpha.data_ptr(), n, h, d, c, t, t0, tl, prec, qhat.data_ptr(), kvhat.data_ptr(),
+                                  alpha.data_ptr(), codes.data_ptr(), n, h, d, c, t, t0, tl, prec, qhat.data_ptr(), kvhat.data_ptr(),
                                   qproj.data_ptr(), kproj.data_ptr(), minmax.data_ptr(), _stream(q)),
                "hept_prep_hash")
     return dict(qhat=qhat, kvhat=kvhat, qproj=qproj, kproj=kproj, minmax=minmax)

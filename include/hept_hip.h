@@ -65,16 +65,17 @@ int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, float* sqrt_w
 
 /* replaces prep_qk (example/hept.py:25-27), the head-major rearranges (:57-59), E2LSH.forward
  * (example/hept_utils.py:45-47) and the min/max of lsh_mapping (:66-70).
- * minmax: (HEPT_PREP_GRID, Tl, H, 2) f32 per-workgroup partial [min,max]; reduced by hept_sort_tables. */
+ * minmax: (Tl, H, HEPT_PREP_GRID, 4) f32 per-workgroup partials [hash min, hash max, largest AND
+ * code, 0]; reduced by hept_sort_tables (the code maximum bounds the sort-key range). */
 int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
-                   const float* sqrt_w, const float* alpha, int N, int H, int D, int C,
-                   int T, int t0, int Tl, int precision,
+                   const float* sqrt_w, const float* alpha, const int64_t* codes,
+                   int N, int H, int D, int C, int T, int t0, int Tl, int precision,
                    void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
                    void* stream);
 #define HEPT_PREP_GRID 1024
 
 /* replaces hash_shift (example/hept_utils.py:70), the AND-shift add (example/hept.py:63-65)
- * and both argsorts (:67-68) with a stable LSD radix sort of the fp32 keys.
+ * and both argsorts (:67-68) with an exact stable sort of the fp32 keys (bucket pass + in-bucket ranking).
  * sort_ws: hept_sort_workspace_bytes(N, H, Tl) bytes. */
 size_t hept_sort_workspace_bytes(int N, int H, int Tl);
 int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* codes,

@@ -46,7 +46,7 @@ def _forward(g, inp, precision):
 def _staged(g, inp, precision, qpos=None, kpos=None):
     n, h, d, e, t = _dims(inp)
     sw = ops.rpe_scale(g["w_rpe_weight"], h, d, inp["w_per_dist"])
-    ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw, g["alpha"], precision)
+    ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw, g["alpha"], g["combined_shifts"], precision)
     if qpos is None:
         qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], g["combined_shifts"], ph["minmax"])
     part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, inp["block_size"])
@@ -77,7 +77,7 @@ def test_prep_hash_stage(name, gpu_device):
     assert bool((kv[..., 32 + d] == 1).all()) and bool((kv[..., 33 + d:] == 0).all()) and bool((qh[..., e:31] == 0).all())
     torch.testing.assert_close(qh[..., 31], -0.5 * (orc["q_hat"] ** 2).sum(-1), rtol=1e-5, atol=1e-6)
     mm = st["minmax"].cpu()
-    span = mm[..., 1].amax(0) - mm[..., 0].amin(0)
+    span = mm[..., 1].amax(-1) - mm[..., 0].amin(-1)
     torch.testing.assert_close(span, orc["hash_span"].squeeze(-1), rtol=1e-5, atol=0)
 
 
@@ -89,7 +89,7 @@ def test_sort_is_stable_sort_of_the_keys(name, gpu_device):
     n = inp["q"].shape[0]
     st = _staged(g, inp, "fp32")
     mm = st["minmax"]
-    span = mm[..., 1].amax(0) - mm[..., 0].amin(0)
+    span = mm[..., 1].amax(-1) - mm[..., 0].amin(-1)
     offs = g["combined_shifts"].float() * span[..., None]
     for pos, proj in ((st["qpos"], st["qproj"]), (st["kpos"], st["kproj"])):
         keys = proj + offs
@@ -177,7 +177,7 @@ def test_tracking_60k_full_size(precision, gpu_device):
     out = st["out"]
     # (1) sortedness / permutation / stability of all 2*T*H segments
     mm = st["minmax"]
-    span = mm[..., 1].amax(0) - mm[..., 0].amin(0)
+    span = mm[..., 1].amax(-1) - mm[..., 0].amin(-1)
     offs = g["combined_shifts"].float() * span[..., None]
     for pos, proj in ((st["qpos"], st["qproj"]), (st["kpos"], st["kproj"])):
         keys = proj + offs

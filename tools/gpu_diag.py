@@ -26,7 +26,7 @@ def run_case(name, precision):
     H, E, T = inp["alpha"].shape; D = inp["q"].shape[1] // H; N = inp["q"].shape[0]
     sw = ops.rpe_scale(g["w_rpe_weight"], H, D, K)
     stats("sqrt_w", sw, orc["sqrt_w"])
-    ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw, g["alpha"], precision)
+    ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw, g["alpha"], g["combined_shifts"], precision)
     stats("qproj", ph["qproj"], orc["q_hashed"]); stats("kproj", ph["kproj"], orc["k_hashed"])
     qh = ph["qhat"].float().cpu(); kv = ph["kvhat"].float().cpu()
     qref = orc["q_hat"]; kref = orc["k_hat"]
@@ -38,7 +38,7 @@ def run_case(name, precision):
     stats("v", kv[..., 32:32 + D], vref)
     print("   v ones col", kv[..., 32 + D].min().item(), kv[..., 32 + D].max().item(), "pad", kv[..., 32 + D + 1:].abs().max().item())
     mm = ph["minmax"].cpu()
-    span = (mm[..., 1].amax(0) - mm[..., 0].amin(0))
+    span = (mm[..., 1].amax(-1) - mm[..., 0].amin(-1))
     stats("hash_span", span, orc["hash_span"].squeeze(-1))
     qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], g["combined_shifts"], ph["minmax"])
     # check: permutation + sortedness on GPU's own keys
