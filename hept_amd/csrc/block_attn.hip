@@ -19,8 +19,9 @@
 // one kvhat row = K^ row | V row, contiguous); the wave's 32 Q^ rows go straight from HBM to
 // registers in B-operand layout.  No row max is needed: logits are clamped to <= 0
 // (example/hept.py:12) and the reference combines un-normalised numerators/denominators.
-// Output rows (32 floats = one 128-B line: numer[0..D-1], denom at D) are written straight to
-// part[t][qpos[row]][h][:], which fuses the un-sort.
+// Output rows are written straight to part[t][qpos[row]][h][:], which fuses the un-sort:
+//   fp32 path: 32 floats = one 128-B line  [numer 0..D-1 | denom at D | 0]
+//   bf16 path: 16 dwords = 64 B            [numer as D bf16 in dwords 0..11 | denom f32 in dword 12 | 0]
 //
 // bf16 path: v_mfma_f32_32x32x16_bf16, V fragments by ds_read_b64_tr_b16.
 // fp32 path: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), plain ds_read_b32 for V.
@@ -32,7 +33,7 @@ namespace {
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-template <int NKT, bool BF16>
+template <int NKT, bool BF16, bool P16>
 __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __restrict__ qhat,
                                                               const char* __restrict__ kvhat,
                                                               const int* __restrict__ qpos,
@@ -172,21 +173,42 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
         }
     }
 
-    // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
-    float* __restrict__ pt = part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
+    if constexpr (P16) {
+        // ---- scatter, 64-B rows: even lane 2i packs columns (2i, 2i+1) as bf16 -> dword i (i < 12);
+        //      lane 24 holds the denominator (f32, dword 12); lanes 26..30 write the zero padding
+        unsigned int* __restrict__ pt =
+            reinterpret_cast<unsigned int*>(part) + (size_t)t * N * H * 16 + (size_t)h * 16 + (li >> 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q2 = w * 32 + hept_acc_row(r, hh);
-        if (q2 < B) {
-            const int dst = qidx_s[q2];
-            float val = z[r];
-            if (li == D) val += 1e-20f;  // example/hept.py:14
-            pt[(size_t)dst * H * 32] = val;
+        for (int r = 0; r < 16; ++r) {
+            const float mine = z[r];
+            const float nbr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mine), 0xB1,
+                                                                                 0xF, 0xF, true));  // lane ^ 1
+            const int q2 = w * 32 + hept_acc_row(r, hh);
+            if (q2 < B && (li & 1) == 0) {
+                const int dst = qidx_s[q2];
+                unsigned int word = hept_pack_bf16(mine, nbr);
+                if (li == D) word = __float_as_uint(mine + 1e-20f);  // example/hept.py:14 (D is even)
+                if (li > D) word = 0u;
+                pt[(size_t)dst * H * 16] = word;
+            }
+        }
+    } else {
+        // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
+        float* __restrict__ pt = part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q2 = w * 32 + hept_acc_row(r, hh);
+            if (q2 < B) {
+                const int dst = qidx_s[q2];
+                float val = z[r];
+                if (li == D) val += 1e-20f;  // example/hept.py:14
+                pt[(size_t)dst * H * 32] = val;
+            }
         }
     }
 }
 
-template <bool BF16>
+template <bool BF16, bool P16>
 int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
                 const int* kpos, float* part, int N, int H, int D, int B, int nb) {
 #define HEPT_ATTN_CASE(K)                                                                                    \
@@ -195,13 +217,13 @@ int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char
         if (lds > 65536) {                                                                                   \
             static bool raised = false;                                                                      \
             if (!raised) {                                                                                   \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_kernel<K, BF16>),          \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16>),          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
                     return HEPT_ERR_LAUNCH;                                                                  \
                 raised = true;                                                                               \
             }                                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((block_attn_kernel<K, BF16>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
+        hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
                            kpos, part, N, H, D, B, nb);                                                      \
         break;                                                                                               \
     }
@@ -228,14 +250,19 @@ extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_
     if (!qhat || !kvhat || !qpos || !kpos || !part) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
         return HEPT_ERR_SHAPE;
+
     const int nb = N / B, nkt = (B + 31) / 32;
     const dim3 grid((unsigned)((size_t)Tl * nb * H));
     hipStream_t st = (hipStream_t)stream;
+    // bf16 tiles with D == 24 write packed 64-B partial rows (HEPT_PART_PACKED), everything else 128-B f32 rows
+    if (precision == HEPT_PREC_BF16 && D == 24)
+        return launch_attn<true, true>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H, D,
+                                       B, nb);
     if (precision == HEPT_PREC_BF16)
-        return launch_attn<true>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H, D, B,
-                                 nb);
+        return launch_attn<true, false>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H,
+                                        D, B, nb);
     if (precision == HEPT_PREC_F32)
-        return launch_attn<false>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H, D,
-                                  B, nb);
+        return launch_attn<false, false>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H,
+                                         D, B, nb);
     return HEPT_ERR_SHAPE;
 }

@@ -81,7 +81,11 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 2; }
+extern "C" int hept_abi_version(void) { return 3; }
+
+extern "C" int hept_part_precision(int precision, int D) {
+    return (precision == HEPT_PREC_BF16 && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
+}
 
 extern "C" int hept_check_shape(int N, int H, int D, int C, int Tl, int B) {
     if (N < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0) return HEPT_ERR_SHAPE;
@@ -109,7 +113,8 @@ extern "C" int hept_forward(const float* q, const float* k, const float* v, cons
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
     rc = run_tables(q, k, v, coords, codes, w_rpe, alpha, N, H, D, C, K, T, 0, T, B, precision, w, w.part, stream);
     if (rc) return rc;
-    rc = hept_combine_out(w.part, T, N, H, D, 0, N, out_weight, out_bias, out, stream);
+    rc = hept_combine_out(w.part, hept_part_precision(precision, D), T, N, H, D, 0, N, out_weight, out_bias, out,
+                          stream);
     prof_mark(4, (hipStream_t)stream);
     prof_call_done();
     return rc;
@@ -125,10 +130,12 @@ extern "C" int hept_forward_partial(const float* q, const float* k, const float*
     if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
     const Workspace w = carve(workspace, N, H, C, Tl, precision);
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
-    // one local table: block_attn scatters straight into acc, no reduction pass
-    float* part = Tl == 1 ? acc : w.part;
+    // one local table in the f32 row format: block_attn scatters straight into acc, no reduction pass
+    const int pprec = hept_part_precision(precision, D);
+    const bool direct = Tl == 1 && pprec == HEPT_PREC_F32;
+    float* part = direct ? acc : w.part;
     rc = run_tables(q, k, v, coords, codes, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B, precision, w, part, stream);
-    if (!rc && Tl > 1) rc = hept_reduce_tables(w.part, Tl, N, H, acc, stream);
+    if (!rc && !direct) rc = hept_reduce_tables(w.part, pprec, Tl, N, H, D, acc, stream);
     prof_mark(4, (hipStream_t)stream);
     prof_call_done();
     return rc;

@@ -4,8 +4,9 @@
 //   out = o.sum(0) / logits.sum(0)                         example/hept.py:79
 //   out_linear(rearrange(out, "h n d -> n (h d)"))         example/hept.py:80
 //
-// HBM-bound: reads Tl*H rows of 128 B per point (part layout (Tl, N, H, 32): the H rows of a
-// point are one contiguous 1-KiB run per table), writes D floats per point.  One wave owns 32
+// HBM-bound: reads Tl*H partial rows per point (part layout (Tl, N, H, row): the H rows of a point
+// are one contiguous run per table; row = 128 B of f32, or the packed 64-B form the bf16 path of
+// block_attn writes), writes D floats per point.  One wave owns 32
 // points: lane (point = lane & 31, half = lane >> 5) loads 64 contiguous bytes of each
 // (table, head) row with 16-B loads, sums the tables in the reference's order, divides by the
 // denominator column and feeds the 32 x (H*32) tile straight to v_mfma_f32_32x32x2_f32 against
@@ -17,21 +18,54 @@ namespace {
 constexpr int CMB_THREADS = 256;
 constexpr int CMB_WAVES = CMB_THREADS / HEPT_WAVE;
 
+// 16 consecutive columns [16*hh, 16*hh+16) of one (table, point, head) partial row, widened to fp32.
+// P16 rows: 16 dwords = [D bf16 numerators in dwords 0..11 | f32 denominator in dword 12 | 0].
+template <bool P16>
+__device__ __forceinline__ void load_half_row(const float* __restrict__ row, int hh, float (&x)[16]) {
+    if constexpr (P16) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(row) + 2 * hh;
+        const u32x4 a = src[0], b = src[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[2 * i] = hept_bf16_lo(a[i]);
+            x[2 * i + 1] = hept_bf16_hi(a[i]);
+            x[8 + 2 * i] = hept_bf16_lo(b[i]);
+            x[8 + 2 * i + 1] = hept_bf16_hi(b[i]);
+        }
+        if (hh == 1) {  // dword 12 (= b[0]) is the f32 denominator -> column 24; the rest is padding
+            x[8] = __uint_as_float(b[0]);
+#pragma unroll
+            for (int i = 9; i < 16; ++i) x[i] = 0.f;
+        }
+    } else {
+        const f32x4* src = reinterpret_cast<const f32x4*>(row + 16 * hh);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const f32x4 v = src[c4];
+            x[4 * c4] = v[0]; x[4 * c4 + 1] = v[1]; x[4 * c4 + 2] = v[2]; x[4 * c4 + 3] = v[3];
+        }
+    }
+}
+
+template <bool P16>
 __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
                                                                   int H, int D, int n0, int n_count,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out) {
+    constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
+    constexpr int DEN = P16 ? 24 : -1;    // P16 rows carry the denominator at column 24 of the widened row
     extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H][32 (d, zero padded)][32 (c, zero padded)]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int HD = H * D;
+    const int dcol = P16 ? DEN : D;
     for (int i = tid; i < H * 32 * 32; i += CMB_THREADS) {
         const int c = i & 31, d = (i >> 5) & 31, h = i >> 10;
         wt_s[i] = (c < D && d < D) ? W[(size_t)c * HD + h * D + d] : 0.f;  // W is (D, H*D) row-major
     }
     const float bia = (li < D && bias) ? bias[li] : 0.f;
     __syncthreads();
-    const size_t tstride = (size_t)N * H * 32;
+    const size_t tstride = (size_t)N * H * ROWF;
 
     const int n_tiles = (n_count + 31) / 32;
     for (int tile = blockIdx.x * CMB_WAVES + w; tile < n_tiles; tile += gridDim.x * CMB_WAVES) {
@@ -40,32 +74,26 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* row0 = part + (size_t)n * H * 32 + 16 * hh;
+        const float* row0 = part + (size_t)n * H * ROWF;
         for (int h = 0; h < H; ++h) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(row0 + h * 32);
-            f32x4 s[4];
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) s[c4] = src[c4];
+            float s[16];
+            load_half_row<P16>(row0 + h * ROWF, hh, s);
             for (int t = 1; t < Tl; ++t) {
-                const f32x4* st = reinterpret_cast<const f32x4*>(row0 + h * 32 + (size_t)t * tstride);
+                float x[16];
+                load_half_row<P16>(row0 + h * ROWF + (size_t)t * tstride, hh, x);
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) s[c4] += st[c4];
+                for (int u = 0; u < 16; ++u) s[u] += x[u];
             }
-            // denominator = column D of the row: held by the lane half that owns columns [16*hh, 16*hh+16)
+            // denominator column: held by the lane half that owns columns [16*hh, 16*hh+16)
             float den = 0.f;
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (16 * hh + 4 * c4 + u == D) den = s[c4][u];
-            const int owner = li + 32 * (D >> 4);
-            den = __shfl(den, owner);
+            for (int u = 0; u < 16; ++u)
+                if (16 * hh + u == dcol) den = s[u];
+            den = __shfl(den, li + 32 * (dcol >> 4));
             const float* wrow = wt_s + (size_t)h * 1024 + (16 * hh) * 32 + li;
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[c4][u] / den, wrow[(4 * c4 + u) * 32], acc, 0, 0, 0);
+            for (int u = 0; u < 16; ++u)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[u] / den, wrow[u * 32], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -75,29 +103,53 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_tables_kernel(const f32x4* __restrict__ part, int Tl, size_t n4,
-                                                            f32x4* __restrict__ acc) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        f32x4 s = part[i];
-        for (int t = 1; t < Tl; ++t) s += part[i + (size_t)t * n4];
-        acc[i] = s;
+// acc (N,H,32) f32 = sum over tables; P16 input rows are widened (denominator moves to column D)
+template <bool P16>
+__global__ __launch_bounds__(256) void reduce_tables_kernel(const float* __restrict__ part, int Tl, int D,
+                                                            size_t n_rows, float* __restrict__ acc) {
+    constexpr int ROWF = P16 ? 16 : 32;
+    const size_t total = n_rows * 2;  // one lane per half row
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i >> 1;
+        const int hh = (int)(i & 1);
+        float s[16];
+        load_half_row<P16>(part + row * ROWF, hh, s);
+        for (int t = 1; t < Tl; ++t) {
+            float x[16];
+            load_half_row<P16>(part + row * ROWF + (size_t)t * n_rows * ROWF, hh, x);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s[u] += x[u];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(acc + row * 32 + 16 * hh);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) dst[c4] = f32x4{s[4 * c4], s[4 * c4 + 1], s[4 * c4 + 2], s[4 * c4 + 3]};
     }
 }
 
 }  // namespace
 
-extern "C" int hept_reduce_tables(const float* part, int Tl, int N, int H, float* acc, void* stream) {
+extern "C" int hept_reduce_tables(const float* part, int part_precision, int Tl, int N, int H, int D, float* acc,
+                                  void* stream) {
     if (!part || !acc) return HEPT_ERR_ARG;
-    if (Tl < 1 || N < 1 || H < 1) return HEPT_ERR_SHAPE;
-    const size_t n4 = (size_t)N * H * 32 / 4;
-    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(reduce_tables_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const f32x4*>(part), Tl, n4, reinterpret_cast<f32x4*>(acc));
+    if (Tl < 1 || N < 1 || H < 1 || D < 1 || D > 28) return HEPT_ERR_SHAPE;
+    const size_t n_rows = (size_t)N * H;
+    const size_t blocks = (n_rows * 2 + 255) / 256;
+    const int grid = (int)(blocks < 4096 ? blocks : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (part_precision == HEPT_PREC_BF16) {
+        if (D != 24) return HEPT_ERR_SHAPE;  // packed rows exist for D == 24 only
+        hipLaunchKernelGGL(reduce_tables_kernel<true>, dim3(grid), dim3(256), 0, st, part, Tl, D, n_rows, acc);
+    } else if (part_precision == HEPT_PREC_F32) {
+        hipLaunchKernelGGL(reduce_tables_kernel<false>, dim3(grid), dim3(256), 0, st, part, Tl, D, n_rows, acc);
+    } else {
+        return HEPT_ERR_SHAPE;
+    }
     return hept_launch_status();
 }
 
-extern "C" int hept_combine_out(const float* part, int Tl, int N, int H, int D, int n0, int n_count,
-                                const float* out_weight, const float* out_bias, float* out, void* stream) {
+extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
+                                int n_count, const float* out_weight, const float* out_bias, float* out,
+                                void* stream) {
     if (!part || !out_weight || !out) return HEPT_ERR_ARG;
     if (Tl < 1 || N < 1 || H < 1 || H > 15 || D < 1 || D > 28 || n0 < 0 || n_count < 0 || n0 + n_count > N)
         return HEPT_ERR_SHAPE;
@@ -106,7 +158,16 @@ extern "C" int hept_combine_out(const float* part, int Tl, int N, int H, int D, 
     const int n_tiles = (n_count + 31) / 32;
     const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
     const int grid = wgs < 2048 ? wgs : 2048;
-    hipLaunchKernelGGL(combine_out_kernel, dim3(grid), dim3(CMB_THREADS), lds, (hipStream_t)stream, part, Tl, N, H, D,
-                       n0, n_count, out_weight, out_bias, out);
+    hipStream_t st = (hipStream_t)stream;
+    if (part_precision == HEPT_PREC_BF16) {
+        if (D != 24) return HEPT_ERR_SHAPE;  // packed rows keep the denominator at widened column 24
+        hipLaunchKernelGGL(combine_out_kernel<true>, dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D, n0,
+                           n_count, out_weight, out_bias, out);
+    } else if (part_precision == HEPT_PREC_F32) {
+        hipLaunchKernelGGL(combine_out_kernel<false>, dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D, n0,
+                           n_count, out_weight, out_bias, out);
+    } else {
+        return HEPT_ERR_SHAPE;
+    }
     return hept_launch_status();
 }

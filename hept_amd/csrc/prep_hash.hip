@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int PREP_THREADS = 256;
+// 16-B slots of the wave-private LDS buffer: 64 input rows at pitch 7 (D = 24) or 64 output rows of up to
+// 8 chunks + one pad slot per head
+constexpr int PREP_WAVE_SLOTS = 64 * 8 + 8;
 constexpr int PREP_POINTS = 8;   // points per wave iteration; lane = (point = lane >> 3, head = lane & 7)
 
 // sqrt_w[h][c] = sqrt(2 * sum_k exp(min(sum_d w[h*D+d][r*K+k], 50))), column 0 duplicated (eta, phi share dR).
@@ -46,49 +49,40 @@ __global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict
     }
 }
 
-// One wave = 8 consecutive points x 8 heads per iteration, no workgroup barriers in the loop:
-//   * the 8 points' q (then k, then v) rows are one contiguous 6-KiB run of the (N, H*D) input:
-//     six fully coalesced 16-B loads per lane,
-//   * a wave-private LDS buffer turns "lane = 16-B chunk" into "lane = (point, head) row of D floats"
-//     (LDS executes one wave's accesses in order, so no barrier is needed); rows are padded to an odd
-//     number of 16-B slots so that the row reads are bank-conflict free,
-//   * lane (p = lane >> 3, h = lane & 7) then augments, hashes and writes its own rows; q, k and v
-//     are finished one after the other to keep the register footprint (and so the occupancy) in check.
-template <int D, int C, bool BF16>
-__global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
-    const int64_t* __restrict__ codes, int N, int T, int t0, int Tl, void* __restrict__ qhat_,
-    void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
+// Streaming transform, one lane per (point, head) row, three wave ROLES selected by blockIdx.y:
+//   role 0 (q): q row + coords -> q^ row, q hashes, hash min/max, largest AND code
+//   role 1 (k): k row + coords -> k^ half of the kvhat row, k hashes, hash min/max
+//   role 2 (v): v row          -> v half of the kvhat row ([v | 1.0 at column D | 0])
+// A wave covers 8 consecutive points x 8 heads = one contiguous 6-KiB run of the (N, H*D) input and, per
+// head, one contiguous run of 8 output rows.  Both sides go through a wave-private LDS buffer so that
+// every global access is a full-width, fully coalesced 16 B per lane (LDS executes one wave's accesses
+// in order: no barrier): chunks -> padded rows (odd 16-B pitch: conflict-free) -> lane m = p*8 + h owns
+// row (p, h); finished rows -> [head][point] order (+1 slot per head: conflict-free) -> linear chunks.
+// Splitting the roles keeps every wave light (few registers, many waves per CU).
+template <int D, int C, bool BF16, int ROLE>
+__device__ __forceinline__ void prep_role(const float* __restrict__ x, const float* __restrict__ coords,
+                                          const float* __restrict__ sw_s, const float* __restrict__ alpha_s,
+                                          const int64_t* __restrict__ codes, int N, int t0, int Tl,
+                                          char* __restrict__ out_rows, float* __restrict__ proj,
+                                          float* __restrict__ red_s, f32x4* __restrict__ tile_s,
+                                          float* __restrict__ minmax, int slot) {
     constexpr int H = 8, E = D + C, HD = H * D, D4 = D / 4;
-    constexpr int CHUNKS = PREP_POINTS * HD / 4;        // 16-B chunks per 8-point tile (384)
-    constexpr int LOADS = CHUNKS / HEPT_WAVE;           // per lane (6)
     constexpr int WAVES = PREP_THREADS / HEPT_WAVE;
-    constexpr int ROW4 = D4 | 1;                        // LDS row pitch in 16-B slots (odd: 7 for D = 24)
-    static_assert(D % 4 == 0 && E <= 30 && D <= 28 && CHUNKS % HEPT_WAVE == 0, "row packing needs D%4==0, E<=30");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* alpha_s = smem;                                        // [H][E][HEPT_MAX_TABLES]
-    float* sw_s = alpha_s + H * E * HEPT_MAX_TABLES;              // [H][C] (+ pad to 16 B)
-    float* red_s = sw_s + ((H * C + 3) & ~3);                     // [WAVES][HEPT_MAX_TABLES][H][4]
-    float* tile_s = red_s + WAVES * HEPT_MAX_TABLES * H * 4;      // [WAVES][64 rows][ROW4 * 4]
-
+    constexpr int QROW = BF16 ? 64 : 128;
+    constexpr int ROWB = ROLE == 0 ? QROW : 2 * QROW;   // row pitch of the destination array
+    constexpr int ROWOFF = ROLE == 2 ? QROW : 0;        // v lives in the second half of a kvhat row
+    constexpr int CH = QROW / 16;                       // 16-B chunks per finished row
+    constexpr int LOADS = PREP_POINTS * HD / 4 / HEPT_WAVE;  // input chunks per lane (6)
+    constexpr int ROW4 = D4 | 1;                        // LDS pitch of an input row in 16-B slots (odd)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = lane & 7, p = lane >> 3;
-    for (int i = tid; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
-        const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
-        alpha_s[i] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
-    }
-    for (int i = tid; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
-    __syncthreads();
-    f32x4* buf = reinterpret_cast<f32x4*>(tile_s) + (size_t)w * 64 * ROW4;
-    // chunk c of the tile belongs to row c / D4 (= lane of the reader), slot c % D4
-    int wslot[LOADS];
+    f32x4* buf = tile_s + (size_t)w * PREP_WAVE_SLOTS;
+    int wslot[LOADS];  // chunk c of the tile belongs to row c / D4 (= the lane that reads it), slot c % D4
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
         const int c = j * 64 + lane;
         wslot[j] = (c / D4) * ROW4 + (c % D4);
     }
-    const f32x4* rowp = buf + lane * ROW4;
 
     float mn[HEPT_MAX_TABLES], mx[HEPT_MAX_TABLES], cm[HEPT_MAX_TABLES];
 #pragma unroll
@@ -100,162 +94,188 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
         const int rows = min(PREP_POINTS, N - n0);
         const int n = n0 + p;
         const bool live = p < rows;
-        const int valid_chunks = rows * (HD / 4);
-        const f32x4* q4 = reinterpret_cast<const f32x4*>(q + (size_t)n0 * HD);
-        const f32x4* k4 = reinterpret_cast<const f32x4*>(k + (size_t)n0 * HD);
-        const f32x4* v4 = reinterpret_cast<const f32x4*>(v + (size_t)n0 * HD);
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 xq[LOADS], xk[LOADS], xv[LOADS];
+        {
+            const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)n0 * HD);
+            const int valid_chunks = rows * (HD / 4);
+            f32x4 xin[LOADS];
 #pragma unroll
-        for (int j = 0; j < LOADS; ++j) xq[j] = (j * 64 + lane < valid_chunks) ? q4[j * 64 + lane] : zero4;
-#pragma unroll
-        for (int j = 0; j < LOADS; ++j) xk[j] = (j * 64 + lane < valid_chunks) ? k4[j * 64 + lane] : zero4;
-        float sc[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) sc[c] = live ? sw_s[h * C + c] * coords[(size_t)n * C + c] : 0.f;
-        // largest AND code of this (table, head): bounds the sort-key range for sort_tables
-#pragma unroll
-        for (int t = 0; t < HEPT_MAX_TABLES; ++t)
-            if (t < Tl && live) cm[t] = fmaxf(cm[t], __ll2float_ru(codes[((size_t)(t0 + t) * H + h) * N + n]));
-
-        // ---- one augmented row (q^ or k^): projections, rounding, norm, store
-        auto finish_row = [&](const f32x4* xin, float* __restrict__ proj, char* __restrict__ dst) {
-            float a[32];
+            for (int j = 0; j < LOADS; ++j)
+                xin[j] = (j * 64 + lane < valid_chunks) ? src[j * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < LOADS; ++j) buf[wslot[j]] = xin[j];
+        }
+        f32x4 xr[D4];
 #pragma unroll
-            for (int j = 0; j < D4; ++j) {
-                const f32x4 x = rowp[j];
-                a[4 * j] = x[0]; a[4 * j + 1] = x[1]; a[4 * j + 2] = x[2]; a[4 * j + 3] = x[3];
+        for (int j = 0; j < D4; ++j) xr[j] = buf[lane * ROW4 + j];
+        float a[32];
+        if (ROLE != 2) {
+            float cs[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) cs[c] = live ? coords[(size_t)n * C + c] : 0.f;
+            if (ROLE == 0) {
+                // largest AND code of this (table, head): bounds the sort-key range for sort_tables
+#pragma unroll
+                for (int t = 0; t < HEPT_MAX_TABLES; ++t)
+                    if (t < Tl && live) cm[t] = fmaxf(cm[t], __ll2float_ru(codes[((size_t)(t0 + t) * H + h) * N + n]));
             }
 #pragma unroll
-            for (int c = 0; c < C; ++c) a[D + c] = sc[c];
+            for (int c = 0; c < C; ++c) a[D + c] = sw_s[h * C + c] * cs[c];
 #pragma unroll
             for (int e = E; e < 32; ++e) a[e] = 0.f;
-            if (!live) return;
-            // E2LSH projections from the unrounded fp32 row; ascending-e fma chain
+        }
 #pragma unroll
-            for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
-                if (t < Tl) {
-                    float acc = 0.f;
+        for (int j = 0; j < D4; ++j) { a[4 * j] = xr[j][0]; a[4 * j + 1] = xr[j][1]; a[4 * j + 2] = xr[j][2]; a[4 * j + 3] = xr[j][3]; }
+        // finished row -> LDS slot of (head, point); the copy-out below turns slots into linear chunks
+        char* dst = reinterpret_cast<char*>(buf + (h * PREP_POINTS + p) * CH + h);
+
+        if (ROLE == 2) {
+            a[D] = 1.f;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) acc = fmaf(a[e], alpha_s[(h * E + e) * HEPT_MAX_TABLES + t], acc);
+            for (int d = D + 1; d < 32; ++d) a[d] = 0.f;
+            if (BF16) {
+                u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    d4[j] = u32x4{hept_pack_bf16(a[8 * j], a[8 * j + 1]), hept_pack_bf16(a[8 * j + 2], a[8 * j + 3]),
+                                  hept_pack_bf16(a[8 * j + 4], a[8 * j + 5]), hept_pack_bf16(a[8 * j + 6], a[8 * j + 7])};
+            } else {
+                f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d4[j] = f32x4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
+            }
+        } else {
+
+        // E2LSH projections from the unrounded fp32 row; ascending-e fma chain
+#pragma unroll
+        for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
+            if (t < Tl) {
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc = fmaf(a[e], alpha_s[(h * E + e) * HEPT_MAX_TABLES + t], acc);
+                if (live) {
                     proj[((size_t)t * H + h) * N + n] = acc;
                     mn[t] = fminf(mn[t], acc);
                     mx[t] = fmaxf(mx[t], acc);
                 }
             }
-            float ss = 0.f;
-            if (BF16) {
-                unsigned int wd[16];
-#pragma unroll
-                for (int i = 0; i < 15; ++i) {
-                    wd[i] = hept_pack_bf16(a[2 * i], a[2 * i + 1]);
-                    const float r0 = hept_bf16_lo(wd[i]), r1 = hept_bf16_hi(wd[i]);  // norm of the ROUNDED values
-                    ss = fmaf(r0, r0, ss);
-                    ss = fmaf(r1, r1, ss);
-                }
-                wd[15] = __float_as_uint(-0.5f * ss);
-                u32x4* d4 = reinterpret_cast<u32x4*>(dst);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d4[j] = u32x4{wd[4 * j], wd[4 * j + 1], wd[4 * j + 2], wd[4 * j + 3]};
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e) ss = fmaf(a[e], a[e], ss);
-                a[31] = -0.5f * ss;
-                f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d4[j] = f32x4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
-            }
-        };
-
-        const size_t row = (size_t)h * N + (live ? n : 0);
-        constexpr int QROW = BF16 ? 64 : 128;
-        char* qdst = reinterpret_cast<char*>(qhat_) + row * QROW;
-        char* kdst = reinterpret_cast<char*>(kvhat_) + row * 2 * QROW;
-        finish_row(xq, qproj, qdst);
-#pragma unroll
-        for (int j = 0; j < LOADS; ++j) xv[j] = (j * 64 + lane < valid_chunks) ? v4[j * 64 + lane] : zero4;
-        finish_row(xk, kproj, kdst);
-
-        // ---- value row: [v | 1.0 at column D | 0]
-#pragma unroll
-        for (int j = 0; j < LOADS; ++j) buf[wslot[j]] = xv[j];
-        float vv[32];
-#pragma unroll
-        for (int j = 0; j < D4; ++j) {
-            const f32x4 x = rowp[j];
-            vv[4 * j] = x[0]; vv[4 * j + 1] = x[1]; vv[4 * j + 2] = x[2]; vv[4 * j + 3] = x[3];
         }
-        vv[D] = 1.f;
+        float ss = 0.f;
+        if (BF16) {
+            unsigned int wd[16];
 #pragma unroll
-        for (int d = D + 1; d < 32; ++d) vv[d] = 0.f;
-        if (live) {
-            if (BF16) {
-                u32x4* d4 = reinterpret_cast<u32x4*>(kdst + QROW);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    d4[j] = u32x4{hept_pack_bf16(vv[8 * j], vv[8 * j + 1]), hept_pack_bf16(vv[8 * j + 2], vv[8 * j + 3]),
-                                  hept_pack_bf16(vv[8 * j + 4], vv[8 * j + 5]), hept_pack_bf16(vv[8 * j + 6], vv[8 * j + 7])};
-            } else {
-                f32x4* d4 = reinterpret_cast<f32x4*>(kdst + QROW);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d4[j] = f32x4{vv[4 * j], vv[4 * j + 1], vv[4 * j + 2], vv[4 * j + 3]};
+            for (int i = 0; i < 15; ++i) {
+                wd[i] = hept_pack_bf16(a[2 * i], a[2 * i + 1]);
+                const float r0 = hept_bf16_lo(wd[i]), r1 = hept_bf16_hi(wd[i]);  // norm of the ROUNDED values
+                ss = fmaf(r0, r0, ss);
+                ss = fmaf(r1, r1, ss);
             }
+            wd[15] = __float_as_uint(-0.5f * ss);
+            u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d4[j] = u32x4{wd[4 * j], wd[4 * j + 1], wd[4 * j + 2], wd[4 * j + 3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) ss = fmaf(a[e], a[e], ss);
+            a[31] = -0.5f * ss;
+            f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d4[j] = f32x4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
+        }
+        }  // ROLE != 2
+
+        // copy-out: chunk c of the [head][point][CH] image -> 8 consecutive destination rows per head
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c = j * 64 + lane;
+            const int hd = c / (PREP_POINTS * CH), rest = c % (PREP_POINTS * CH);
+            const int pt = rest / CH, u = rest % CH;
+            const f32x4 val = buf[c + hd];
+            if (pt < rows)
+                *reinterpret_cast<f32x4*>(out_rows + ((size_t)hd * N + n0 + pt) * ROWB + ROWOFF + u * 16) = val;
         }
     }
+    if (ROLE == 2) return;
 
     // per-workgroup partial hash range: lane keeps one head (h = lane & 7); fold the 8 point-lanes, then the waves
 #pragma unroll
     for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
         if (t < Tl) {
-            float a = mn[t], b = mx[t], c = cm[t];
+            float lo = mn[t], hi = mx[t], c = cm[t];
 #pragma unroll
             for (int off = 8; off <= 32; off <<= 1) {
-                a = fminf(a, __shfl_xor(a, off));
-                b = fmaxf(b, __shfl_xor(b, off));
+                lo = fminf(lo, __shfl_xor(lo, off));
+                hi = fmaxf(hi, __shfl_xor(hi, off));
                 c = fmaxf(c, __shfl_xor(c, off));
             }
             if (p == 0) {
                 float* r = red_s + ((w * HEPT_MAX_TABLES + t) * H + h) * 4;
-                r[0] = a; r[1] = b; r[2] = c;
+                r[0] = lo; r[1] = hi; r[2] = c;
             }
         }
     }
     __syncthreads();
     for (int i = tid; i < Tl * H; i += PREP_THREADS) {
         const int t = i / H, hh = i % H;
-        float a = INFINITY, b = -INFINITY, c = 0.f;
+        float lo = INFINITY, hi = -INFINITY, c = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) {
             const float* r = red_s + ((ww * HEPT_MAX_TABLES + t) * H + hh) * 4;
-            a = fminf(a, r[0]);
-            b = fmaxf(b, r[1]);
+            lo = fminf(lo, r[0]);
+            hi = fmaxf(hi, r[1]);
             c = fmaxf(c, r[2]);
         }
-        // layout [Tl][H][grid][4]: the sort kernels reduce one (t,h) row with contiguous 16-B loads
-        *reinterpret_cast<f32x4*>(minmax + (((size_t)t * H + hh) * gridDim.x + blockIdx.x) * 4) = f32x4{a, b, c, 0.f};
+        // layout [Tl][H][HEPT_PREP_GRID][4]: the sort kernels reduce one (t,h) row with contiguous 16-B loads
+        *reinterpret_cast<f32x4*>(minmax + (((size_t)t * H + hh) * HEPT_PREP_GRID + slot) * 4) = f32x4{lo, hi, c, 0.f};
     }
+}
+
+constexpr int PREP_WGS_PER_ROLE = HEPT_PREP_GRID / 2;  // q and k roles fill the HEPT_PREP_GRID partial slots
+
+template <int D, int C, bool BF16>
+__global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
+    const int64_t* __restrict__ codes, int N, int T, int t0, int Tl, void* __restrict__ qhat_,
+    void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
+    constexpr int H = 8, E = D + C;
+    static_assert(D % 4 == 0 && E <= 30 && D <= 28, "row packing needs D%4==0, E<=30");
+    __shared__ float alpha_s[H * E * HEPT_MAX_TABLES];
+    __shared__ float sw_s[H * C];
+    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * HEPT_MAX_TABLES * H * 4];
+    __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * PREP_WAVE_SLOTS];
+    static_assert(64 * ((D / 4) | 1) <= PREP_WAVE_SLOTS, "input tile does not fit the wave buffer");
+    const int role = blockIdx.y;
+    if (role != 2) {
+        for (int i = threadIdx.x; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
+            const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
+            alpha_s[i] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
+        }
+        for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
+        __syncthreads();
+    }
+    if (role == 0)
+        prep_role<D, C, BF16, 0>(q, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(qhat_), qproj,
+                                 red_s, tile_s, minmax, blockIdx.x);
+    else if (role == 1)
+        prep_role<D, C, BF16, 1>(k, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
+                                 red_s, tile_s, minmax, PREP_WGS_PER_ROLE + blockIdx.x);
+    else
+        prep_role<D, C, BF16, 2>(v, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
+                                 red_s, tile_s, minmax, 0);
 }
 
 template <int D, int C>
 int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w,
                 const float* alpha, const int64_t* codes, int N, int T, int t0, int Tl, int precision, void* qhat,
-                void* kvhat,
-                float* qproj, float* kproj, float* minmax, hipStream_t st) {
-    constexpr int H = 8, E = D + C;
-    const size_t lds = sizeof(float) * (H * E * HEPT_MAX_TABLES + ((H * C + 3) & ~3) +
-                                        (PREP_THREADS / HEPT_WAVE) * (HEPT_MAX_TABLES * H * 4 + 64 * ((D / 4) | 1) * 4));
-    const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
-    // the sort kernel reduces exactly HEPT_PREP_GRID partials: idle workgroups still write theirs
-    const int grid = HEPT_PREP_GRID;
-    (void)ntiles;
+                void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
+    // q- and k-role workgroups each write one of the HEPT_PREP_GRID partial slots the sort kernel reduces
+    const dim3 grid(PREP_WGS_PER_ROLE, 3);
     if (precision == HEPT_PREC_BF16)
-        hipLaunchKernelGGL((prep_hash_kernel<D, C, true>), dim3(grid), dim3(PREP_THREADS), lds, st, q, k, v, coords,
-                           sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+        hipLaunchKernelGGL((prep_hash_kernel<D, C, true>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
+                           alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     else
-        hipLaunchKernelGGL((prep_hash_kernel<D, C, false>), dim3(grid), dim3(PREP_THREADS), lds, st, q, k, v, coords,
-                           sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+        hipLaunchKernelGGL((prep_hash_kernel<D, C, false>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
+                           alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     return hept_launch_status();
 }
 

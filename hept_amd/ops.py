@@ -15,7 +15,7 @@ from ._lib import PREC_BF16, PREC_F32
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
-    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read",
+    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part",
 ]
 
 
@@ -105,31 +105,51 @@ def sort_tables(qproj, kproj, codes, minmax, t0: int = 0) -> Tuple[torch.Tensor,
     return pos[0], pos[1]
 
 
-def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Per-table partials (Tl, N, H, 32): numer in [..., :D], denom (+1e-20) at [..., D]."""
+def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int) -> torch.Tensor:
+    """Per-table partial rows (Tl, N, H, row).  fp32 tiles: row = 32 f32 (numer in [:D], denom (+1e-20) at [D]);
+    bf16 tiles with D == 24: packed row = 16 int32 dwords (24 bf16 numer | f32 denom | 0); see ``unpack_part``."""
     lib = _lib.load()
     h, n, _ = qhat.shape
     tl = qpos.shape[0]
     prec = PREC_BF16 if qhat.dtype == torch.bfloat16 else PREC_F32
+    packed = lib.hept_part_precision(prec, head_dim) == PREC_BF16
     qpos = qpos.to(torch.int32).contiguous()
     kpos = kpos.to(torch.int32).contiguous()
-    part = torch.empty(tl, n, h, 32, device=qhat.device, dtype=torch.float32) if out is None else out
+    part = torch.empty(tl, n, h, 16 if packed else 32, device=qhat.device, dtype=torch.int32 if packed else torch.float32)
     _lib.check(lib.hept_block_attn(qhat.data_ptr(), kvhat.data_ptr(), qpos.data_ptr(), kpos.data_ptr(), n, h,
                                    head_dim, tl, block_size, prec, part.data_ptr(), _stream(qhat)),
                "hept_block_attn")
     return part
 
 
-def reduce_tables(part: torch.Tensor) -> torch.Tensor:
+def _part_prec(part: torch.Tensor) -> int:
+    return PREC_BF16 if part.dtype == torch.int32 else PREC_F32
+
+
+def unpack_part(part: torch.Tensor) -> torch.Tensor:
+    """Widen packed partial rows (..., 16) int32 to the f32 row format (..., 32); f32 rows pass through."""
+    if part.dtype != torch.int32:
+        return part
+    lo = (part[..., :12] << 16).view(torch.float32)
+    hi = (part[..., :12] & -65536).view(torch.float32)
+    out = torch.zeros(*part.shape[:-1], 32, device=part.device, dtype=torch.float32)
+    out[..., 0:24:2] = lo
+    out[..., 1:24:2] = hi
+    out[..., 24] = part[..., 12].view(torch.float32)
+    return out
+
+
+def reduce_tables(part: torch.Tensor, head_dim: int = 24) -> torch.Tensor:
     lib = _lib.load()
     tl, n, h, _ = part.shape
     acc = torch.empty(n, h, 32, device=part.device, dtype=torch.float32)
-    _lib.check(lib.hept_reduce_tables(part.data_ptr(), tl, n, h, acc.data_ptr(), _stream(part)), "hept_reduce_tables")
+    _lib.check(lib.hept_reduce_tables(part.data_ptr(), _part_prec(part), tl, n, h, head_dim, acc.data_ptr(),
+                                      _stream(part)), "hept_reduce_tables")
     return acc
 
 
 def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int = 0, n_count: Optional[int] = None) -> torch.Tensor:
-    """(sum_t numer / sum_t denom) -> Linear(H*D -> D) for points [n0, n0+n_count); part is (Tl,N,H,32) or (N,H,32)."""
+    """(sum_t numer / sum_t denom) -> Linear(H*D -> D) for points [n0, n0+n_count); part is (Tl,N,H,row) or (N,H,32)."""
     lib = _lib.load()
     if part.dim() == 3:
         part = part.unsqueeze(0)
@@ -138,7 +158,7 @@ def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int
     w = _f32c(out_weight, "out_linear.weight")
     b = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
     out = torch.empty(n_count, head_dim, device=part.device, dtype=torch.float32)
-    _lib.check(lib.hept_combine_out(part.data_ptr(), tl, n, h, head_dim, n0, n_count, w.data_ptr(),
+    _lib.check(lib.hept_combine_out(part.data_ptr(), _part_prec(part), tl, n, h, head_dim, n0, n_count, w.data_ptr(),
                                     b.data_ptr() if b is not None else None, out.data_ptr(), _stream(part)),
                "hept_combine_out")
     return out

