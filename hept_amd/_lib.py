@@ -11,8 +11,8 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p
 
 from .build import LIB_PATH
 
-ABI_VERSION = 3
-PREC_F32, PREC_BF16 = 0, 1
+ABI_VERSION = 4
+PREC_F32, PREC_BF16, PREC_MIXED16 = 0, 1, 2
 ROW = 32
 MAX_TABLES = 8
 MAX_BLOCK = 256

@@ -23,7 +23,8 @@
 //   fp32 path: 32 floats = one 128-B line  [numer 0..D-1 | denom at D | 0]
 //   bf16 path: 16 dwords = 64 B            [numer as D bf16 in dwords 0..11 | denom f32 in dword 12 | 0]
 //
-// bf16 path: v_mfma_f32_32x32x16_bf16, V fragments by ds_read_b64_tr_b16.
+// bf16 path: v_mfma_f32_32x32x16_bf16, V fragments by ds_read_b64_tr_b16 (mixed16: the K^.Q^T product
+// takes fp16 rows through v_mfma_f32_32x32x16_f16; P.V stays bf16 for the exponent range of tiny weights).
 // fp32 path: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), plain ds_read_b32 for V.
 // blockIdx % H = head: with H = 8 every XCD (round-robin dispatch) gathers from one head's
 // qhat/kvhat slab only (speed only; nothing depends on placement).
@@ -33,7 +34,7 @@ namespace {
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-template <int NKT, bool BF16, bool P16>
+template <int NKT, bool BF16, bool P16, bool F16QK>
 __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __restrict__ qhat,
                                                               const char* __restrict__ kvhat,
                                                               const int* __restrict__ qpos,
@@ -120,8 +121,12 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
                 const int c = 2 * s + hh;
                 const u32x4 kraw =
                     *reinterpret_cast<const u32x4*>(k_s + key * QROW + ((c ^ ((key >> 2) & 3)) * 16));
-                x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kraw),
-                                                            __builtin_bit_cast(bf16x8, qraw[s]), x, 0, 0, 0);
+                if constexpr (F16QK)
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kraw),
+                                                               __builtin_bit_cast(f16x8, qraw[s]), x, 0, 0, 0);
+                else
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kraw),
+                                                                __builtin_bit_cast(bf16x8, qraw[s]), x, 0, 0, 0);
             }
         } else {
             float kf[16];
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
     }
 }
 
-template <bool BF16, bool P16>
+template <bool BF16, bool P16, bool F16QK>
 int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
                 const int* kpos, float* part, int N, int H, int D, int B, int nb) {
 #define HEPT_ATTN_CASE(K)                                                                                    \
@@ -217,13 +222,13 @@ int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char
         if (lds > 65536) {                                                                                   \
             static bool raised = false;                                                                      \
             if (!raised) {                                                                                   \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16>),          \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16, F16QK>),          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
                     return HEPT_ERR_LAUNCH;                                                                  \
                 raised = true;                                                                               \
             }                                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
+        hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16, F16QK>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
                            kpos, part, N, H, D, B, nb);                                                      \
         break;                                                                                               \
     }
@@ -255,14 +260,17 @@ extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_
     const dim3 grid((unsigned)((size_t)Tl * nb * H));
     hipStream_t st = (hipStream_t)stream;
     // bf16 tiles with D == 24 write packed 64-B partial rows (HEPT_PART_PACKED), everything else 128-B f32 rows
+    const char* qh = (const char*)qhat;
+    const char* kv = (const char*)kvhat;
     if (precision == HEPT_PREC_BF16 && D == 24)
-        return launch_attn<true, true>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H, D,
-                                       B, nb);
+        return launch_attn<true, true, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
     if (precision == HEPT_PREC_BF16)
-        return launch_attn<true, false>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H,
-                                        D, B, nb);
+        return launch_attn<true, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
+    if (precision == HEPT_PREC_MIXED16 && D == 24)
+        return launch_attn<true, true, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
+    if (precision == HEPT_PREC_MIXED16)
+        return launch_attn<true, false, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
     if (precision == HEPT_PREC_F32)
-        return launch_attn<false, false>(nkt, grid, st, (const char*)qhat, (const char*)kvhat, qpos, kpos, part, N, H,
-                                         D, B, nb);
+        return launch_attn<false, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
     return HEPT_ERR_SHAPE;
 }

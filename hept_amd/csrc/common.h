@@ -29,6 +29,16 @@ __device__ __forceinline__ float hept_bf16_round(float x) { return (float)(__bf1
 __device__ __forceinline__ float hept_bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hept_bf16_hi(unsigned int w) { return __uint_as_float(w & 0xFFFF0000u); }
 
+// float pair -> packed fp16 (round to nearest even, v_cvt_pk_f16_f32), saturating at the largest finite fp16
+typedef __attribute__((ext_vector_type(2))) _Float16 hept_f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ unsigned int hept_pack_f16(float lo, float hi) {
+    const hept_f32x2 v = {fminf(fmaxf(lo, -65504.f), 65504.f), fminf(fmaxf(hi, -65504.f), 65504.f)};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hept_f16x2));
+}
+__device__ __forceinline__ float hept_f16_lo(unsigned int w) { return (float)__builtin_bit_cast(hept_f16x2, w)[0]; }
+__device__ __forceinline__ float hept_f16_hi(unsigned int w) { return (float)__builtin_bit_cast(hept_f16x2, w)[1]; }
+
 // Row of the 32x32 MFMA accumulator held in register r by lane-half hh
 // (C/D layout of v_mfma_f32_32x32x*: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
 __device__ __forceinline__ int hept_acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict
 // in order: no barrier): chunks -> padded rows (odd 16-B pitch: conflict-free) -> lane m = p*8 + h owns
 // row (p, h); finished rows -> [head][point] order (+1 slot per head: conflict-free) -> linear chunks.
 // Splitting the roles keeps every wave light (few registers, many waves per CU).
-template <int D, int C, bool BF16, int ROLE>
+template <int D, int C, int TILE, int ROLE>
 __device__ __forceinline__ void prep_role(const float* __restrict__ x, const float* __restrict__ coords,
                                           const float* __restrict__ sw_s, const float* __restrict__ alpha_s,
                                           const int64_t* __restrict__ codes, int N, int t0, int Tl,
@@ -68,6 +68,8 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
                                           float* __restrict__ minmax, int slot) {
     constexpr int H = 8, E = D + C, HD = H * D, D4 = D / 4;
     constexpr int WAVES = PREP_THREADS / HEPT_WAVE;
+    constexpr bool BF16 = TILE != HEPT_PREC_F32;      // 16-bit tiles
+    constexpr bool F16QK = TILE == HEPT_PREC_MIXED16;  // q^/k^ rows in fp16 instead of bf16
     constexpr int QROW = BF16 ? 64 : 128;
     constexpr int ROWB = ROLE == 0 ? QROW : 2 * QROW;   // row pitch of the destination array
     constexpr int ROWOFF = ROLE == 2 ? QROW : 0;        // v lives in the second half of a kvhat row
@@ -164,8 +166,10 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
             unsigned int wd[16];
 #pragma unroll
             for (int i = 0; i < 15; ++i) {
-                wd[i] = hept_pack_bf16(a[2 * i], a[2 * i + 1]);
-                const float r0 = hept_bf16_lo(wd[i]), r1 = hept_bf16_hi(wd[i]);  // norm of the ROUNDED values
+                wd[i] = F16QK ? hept_pack_f16(a[2 * i], a[2 * i + 1]) : hept_pack_bf16(a[2 * i], a[2 * i + 1]);
+                // norm of the ROUNDED values
+                const float r0 = F16QK ? hept_f16_lo(wd[i]) : hept_bf16_lo(wd[i]);
+                const float r1 = F16QK ? hept_f16_hi(wd[i]) : hept_bf16_hi(wd[i]);
                 ss = fmaf(r0, r0, ss);
                 ss = fmaf(r1, r1, ss);
             }
@@ -231,7 +235,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
 
 constexpr int PREP_WGS_PER_ROLE = HEPT_PREP_GRID / 2;  // q and k roles fill the HEPT_PREP_GRID partial slots
 
-template <int D, int C, bool BF16>
+template <int D, int C, int TILE>
 __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
@@ -254,13 +258,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
         __syncthreads();
     }
     if (role == 0)
-        prep_role<D, C, BF16, 0>(q, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(qhat_), qproj,
+        prep_role<D, C, TILE, 0>(q, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(qhat_), qproj,
                                  red_s, tile_s, minmax, blockIdx.x);
     else if (role == 1)
-        prep_role<D, C, BF16, 1>(k, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
+        prep_role<D, C, TILE, 1>(k, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
                                  red_s, tile_s, minmax, PREP_WGS_PER_ROLE + blockIdx.x);
     else
-        prep_role<D, C, BF16, 2>(v, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
+        prep_role<D, C, TILE, 2>(v, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
                                  red_s, tile_s, minmax, 0);
 }
 
@@ -271,11 +275,14 @@ int launch_prep(const float* q, const float* k, const float* v, const float* coo
     // q- and k-role workgroups each write one of the HEPT_PREP_GRID partial slots the sort kernel reduces
     const dim3 grid(PREP_WGS_PER_ROLE, 3);
     if (precision == HEPT_PREC_BF16)
-        hipLaunchKernelGGL((prep_hash_kernel<D, C, true>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
-                           alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+        hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_BF16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords,
+                           sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+    else if (precision == HEPT_PREC_MIXED16)
+        hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_MIXED16>), grid, dim3(PREP_THREADS), 0, st, q, k, v,
+                           coords, sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     else
-        hipLaunchKernelGGL((prep_hash_kernel<D, C, false>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
-                           alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+        hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_F32>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords,
+                           sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     return hept_launch_status();
 }
 
@@ -295,7 +302,8 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
     if (!q || !k || !v || !coords || !sqrt_w || !alpha || !codes || !qhat || !kvhat || !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
     if (H != 8 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
-    if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16) return HEPT_ERR_SHAPE;
+    if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16 && precision != HEPT_PREC_MIXED16)
+        return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
 #define HEPT_PREP_CASE(DD, CC)                                                                             \
     if (D == DD && C == CC)                                                                                \

@@ -10,7 +10,7 @@ int64, optional ignored ``pe``; same attribute and state-dict names
 checkpoint loads with ``strict=True``.
 
 Two keyword-only extensions: ``precision`` ("fp32" reference numerics /
-"bf16" MFMA tiles) and ``process_group`` (shard the ``n_hashes`` tables over
+"bf16" MFMA tiles / "mixed16" = fp16 q̂,k̂ tiles with bf16 weights and values) and ``process_group`` (shard the ``n_hashes`` tables over
 the ranks of a ``torch.distributed`` group).
 
 Forward only (inference metric); the module runs under ``torch.no_grad()``

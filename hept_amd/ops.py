@@ -11,7 +11,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_F32
+from ._lib import PREC_BF16, PREC_F32, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
@@ -20,13 +20,15 @@ __all__ = [
 
 
 def precision_code(precision) -> int:
-    if isinstance(precision, int) and not isinstance(precision, bool) and precision in (PREC_F32, PREC_BF16):
+    if isinstance(precision, int) and not isinstance(precision, bool) and precision in (PREC_F32, PREC_BF16, PREC_MIXED16):
         return precision
+    if precision == "mixed16":
+        return PREC_MIXED16
     if precision in ("fp32", "f32") or precision is torch.float32:
         return PREC_F32
     if precision == "bf16" or precision is torch.bfloat16:
         return PREC_BF16
-    raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+    raise ValueError(f"precision must be 'fp32', 'bf16' or 'mixed16', got {precision!r}")
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -75,7 +77,8 @@ def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int =
     codes = codes.contiguous()
     tl = t - t0 if tl is None else tl
     prec = precision_code(precision)
-    tile = torch.bfloat16 if prec == PREC_BF16 else torch.float32
+    # dtype tag of the row buffers: bf16 / f16 (mixed16: q^,k^ halves are fp16, the v half of kvhat is bf16) / f32
+    tile = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16}[prec]
     dev = q.device
     qhat = torch.empty(h, n, 32, device=dev, dtype=tile)
     kvhat = torch.empty(h, n, 64, device=dev, dtype=tile)
@@ -111,7 +114,7 @@ def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int) -> torch
     lib = _lib.load()
     h, n, _ = qhat.shape
     tl = qpos.shape[0]
-    prec = PREC_BF16 if qhat.dtype == torch.bfloat16 else PREC_F32
+    prec = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16, torch.float16: PREC_MIXED16}[qhat.dtype]
     packed = lib.hept_part_precision(prec, head_dim) == PREC_BF16
     qpos = qpos.to(torch.int32).contiguous()
     kpos = kpos.to(torch.int32).contiguous()

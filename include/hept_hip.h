@@ -30,7 +30,7 @@
  *                                      written by hept_block_attn iff precision is bf16 and D == 24
  *   acc          (N, H, 32) f32      sum over tables of part, always in the f32 row format
  *   out          (N, D)     f32
- * "tile" element type is f32 (precision 0) or bf16 (precision 1).
+ * "tile" element type is f32 (precision 0) or 16-bit (precision 1: bf16; precision 2: fp16 for q^/k^ rows, bf16 for v rows).
  */
 #ifndef HEPT_HIP_H
 #define HEPT_HIP_H
@@ -47,8 +47,10 @@ extern "C" {
 #define HEPT_ERR_LAUNCH 2  /* HIP reported a launch error */
 #define HEPT_ERR_ARG 3     /* null pointer / workspace too small */
 
-#define HEPT_PREC_F32 0
-#define HEPT_PREC_BF16 1
+#define HEPT_PREC_F32 0      /* f32 tiles, f32 MFMA: the reference's numerics */
+#define HEPT_PREC_BF16 1     /* bf16 tiles (q^, k^, v, weights P), bf16 MFMA, packed bf16 partial numerators */
+#define HEPT_PREC_MIXED16 2  /* as BF16 but q^/k^ tiles in fp16 (11-bit significand protects the logit
+                                q.k - |q|^2/2 - |k|^2/2; values are clamped to +-65504); P, v stay bf16 */
 
 #define HEPT_ROW 32          /* padded row width (elements) of qhat / k / v / part rows */
 #define HEPT_MAX_TABLES 8    /* tables per call */

@@ -241,6 +241,7 @@ def forward_partials(
     q_positions: Optional[torch.Tensor] = None,
     k_positions: Optional[torch.Tensor] = None,
     tile_dtype: torch.dtype = torch.float32,
+    qk_dtype: Optional[torch.dtype] = None,
     keep: bool = True,
 ) -> Dict[str, torch.Tensor]:
     """Everything up to the per-table partials in original point order.
@@ -266,8 +267,9 @@ def forward_partials(
     q_pos = sort_keys(q_keys, stable_sort) if q_positions is None else q_positions
     k_pos = sort_keys(k_keys, stable_sort) if k_positions is None else k_positions
 
-    sq = gather_blocks(_round_tile(q_hat, tile_dtype), q_pos, block_size)
-    sk = gather_blocks(_round_tile(k_hat, tile_dtype), k_pos, block_size)
+    qk_dt = tile_dtype if qk_dtype is None else qk_dtype  # "mixed16": fp16 q̂/k̂ tiles, everything else bf16
+    sq = gather_blocks(_round_tile(q_hat, qk_dt), q_pos, block_size)
+    sk = gather_blocks(_round_tile(k_hat, qk_dt), k_pos, block_size)
     sv = gather_blocks(_round_tile(v_h, tile_dtype), k_pos, block_size)
     denom_s, numer_s = block_rbf_attention(sq, sk, sv, tile_dtype)
     del sq, sk, sv
@@ -307,13 +309,14 @@ def forward(
     q_positions: Optional[torch.Tensor] = None,
     k_positions: Optional[torch.Tensor] = None,
     tile_dtype: torch.dtype = torch.float32,
+    qk_dtype: Optional[torch.dtype] = None,
     keep: bool = True,
 ) -> Dict[str, torch.Tensor]:
     """Full operator, ``example/hept.py:43-81``; returns a dict with ``out`` (N,D) and intermediates."""
     res = forward_partials(
         q, k, v, coords, codes, w_rpe_weight, alpha,
         block_size=block_size, w_per_dist=w_per_dist, stable_sort=stable_sort,
-        q_positions=q_positions, k_positions=k_positions, tile_dtype=tile_dtype, keep=keep,
+        q_positions=q_positions, k_positions=k_positions, tile_dtype=tile_dtype, qk_dtype=qk_dtype, keep=keep,
     )
     per_head = combine_tables(res["numer"], res["denom"])
     res["per_head"] = per_head

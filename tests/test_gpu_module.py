@@ -52,7 +52,8 @@ def test_module_bf16_and_errors(gpu_device):
         again = m(g["q"], g["k"], g["v"], **kw)
     assert torch.equal(out, again)  # deterministic run to run (no atomics on the data path)
     ref = torch.from_numpy(fx["out"])
-    assert (((out.cpu() - ref).abs() <= 2e-2 + 2e-2 * ref.abs()).all(-1)).float().mean() >= 0.97
+    err = (out.cpu() - ref).abs().amax(-1)
+    assert (err <= 2.5e-2 * (ref.abs().amax(-1) + 1e-3)).float().mean() >= 0.97
     with pytest.raises(RuntimeError, match="forward .inference. path only"):
         m(g["q"].requires_grad_(True), g["k"], g["v"], **kw)
     with torch.no_grad(), pytest.raises(ValueError, match="multiple of block_size"):

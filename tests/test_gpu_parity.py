@@ -16,10 +16,8 @@ pytestmark = pytest.mark.gpu
 SMALL = ["g1_rand512", "g2_example4k", "g4_pileup", "g6_block100"]
 ALL = SMALL + ["g3_ckpt6k"]
 ATOL = {"g3_ckpt6k": 1e-3}
-# bf16 tiles round q^/k^ to 8 bits: the logit error grows with |q^|.  G3 (trained weights,
-# |q^|^2 ~ 1e3) is therefore held to the oracle's bf16 model only; its agreement with the fp32 reference is
-# recorded with a looser floor.
-BF16_REF_ROWS = {"g3_ckpt6k": 0.80}
+# agreement of the 16-bit kernels with the oracle's MODEL of them (same rounded tiles, fp32 accumulate): a
+# last-bit fp32 difference can flip the rounding of a stored bf16 numerator, so G3 (|out| ~ 2..8) sits lower
 BF16_MODEL_ROWS = {"g3_ckpt6k": 0.96}
 
 
@@ -53,6 +51,27 @@ def _staged(g, inp, precision, qpos=None, kpos=None):
     part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, inp["block_size"])
     out = ops.combine_out(part, d, g["out_weight"], g["out_bias"])
     return dict(sqrt_w=sw, part=part, out=out, qpos=qpos, kpos=kpos, **ph)
+
+
+def _model_kw(precision):
+    """Oracle switches that model a HIP precision mode."""
+    if precision == "bf16":
+        return dict(tile_dtype=torch.bfloat16)
+    if precision == "mixed16":
+        return dict(tile_dtype=torch.bfloat16, qk_dtype=torch.float16)
+    return {}
+
+
+def _rows_scaled_ok(out, ref, rel):
+    """Fraction of rows whose worst element error is <= rel * (largest |reference| of that row).  The 16-bit
+    modes round weights, values and stored numerators to bf16: their error scales with the row, not the element."""
+    err = (out - ref).abs().amax(-1)
+    return (err <= rel * (ref.abs().amax(-1) + 1e-3)).float().mean().item()
+
+
+# stated tolerances of the 16-bit modes against the fp32 REFERENCE (measured 99th percentiles: bf16 <= 1.9e-2,
+# mixed16 <= 0.85e-2 of the row scale on every golden case, tools/tol_probe.py)
+REL16 = {"bf16": 2.5e-2, "mixed16": 1.0e-2}
 
 
 def _rows_ok(out, ref, atol, rtol=1e-4):
@@ -99,7 +118,7 @@ def test_sort_is_stable_sort_of_the_keys(name, gpu_device):
         assert torch.equal(torch.sort(pos.long(), -1).values, torch.arange(n, device=pos.device).expand_as(pos))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "mixed16"])
 @pytest.mark.parametrize("name", ALL)
 def test_block_attention_with_reference_permutations(name, precision, gpu_device):
     """The reference's own q/k permutations injected: output must equal the REFERENCE's golden output."""
@@ -117,15 +136,19 @@ def test_block_attention_with_reference_permutations(name, precision, gpu_device
         assert _rows_ok(out, ref, atol, 1e-4) >= 0.999
         torch.testing.assert_close(out, ref, rtol=3e-2, atol=3 * atol)
     else:
-        assert _rows_ok(out, ref, atol=2e-2, rtol=2e-2) >= BF16_REF_ROWS.get(name, 0.99)
-        # tight against the oracle's model of the bf16 path (rounded tiles and weights, fp32 accumulate)
-        orc = _oracle(inp, q_positions=qp.long().cpu(), k_positions=kp.long().cpu(), tile_dtype=torch.bfloat16, keep=False)
+        # bf16 rounds q^/k^ to 8 bits (logit error grows with |q^|); mixed16 keeps 11 bits there, what is left
+        # is the bf16 rounding of the weights, v and the stored numerators (2^-9 relative each, unbiased)
+        assert _rows_scaled_ok(out, ref, REL16[precision]) >= 0.99
+        if precision == "mixed16":
+            assert _rows_scaled_ok(out, ref, 2.5e-2) == 1.0
+        # tight against the oracle's model of the 16-bit path (rounded tiles and weights, fp32 accumulate)
+        orc = _oracle(inp, q_positions=qp.long().cpu(), k_positions=kp.long().cpu(), keep=False, **_model_kw(precision))
         # (rtol = 2 bf16 ulps: a last-bit fp32 difference can flip the rounding of a stored bf16 numerator)
         assert _rows_ok(out, orc["out"], atol=5e-3, rtol=8e-3) >= BF16_MODEL_ROWS.get(name, 0.995)
     d = inp["q"].shape[1] // inp["alpha"].shape[0]
     wide = ops.unpack_part(st["part"])
     assert float(wide[..., d + 1:].abs().max()) == 0.0
-    if precision == "bf16":
+    if precision != "fp32":
         assert st["part"].shape[-1] == 16 and float(st["part"][..., 13:].abs().max()) == 0.0
     if precision == "fp32" and "denom_rows" in fx:
         rows = torch.from_numpy(fx["rows"].astype(np.int64))
@@ -133,21 +156,23 @@ def test_block_attention_with_reference_permutations(name, precision, gpu_device
         torch.testing.assert_close(den, torch.from_numpy(fx["denom_rows"]), rtol=2e-4, atol=ATOL.get(name, 1e-5) * 10)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "mixed16"])
 @pytest.mark.parametrize("name", ALL)
 def test_forward_end_to_end_vs_oracle(name, precision, gpu_device):
     """Whole operator (one C call, own radix sort) against the oracle (stable sort): tie-aware row criterion."""
     inp, fx = cases.load_case(name)
     g = _gpu(inp, gpu_device)
     out = _forward(g, inp, precision).cpu()
-    orc = _oracle(inp, keep=False, tile_dtype=torch.bfloat16 if precision == "bf16" else torch.float32)
+    orc = _oracle(inp, keep=False, **_model_kw(precision))
     atol = ATOL.get(name, 1e-5) if precision == "fp32" else 5e-3
     rtol = 1e-4 if precision == "fp32" else 8e-3
     assert _rows_ok(out, orc["out"], atol, rtol) >= (0.995 if precision == "fp32" else BF16_MODEL_ROWS.get(name, 0.995))
     # and against the reference itself (unstable argsort there): only tie-induced rows may differ
     ref = torch.from_numpy(fx["out"])
-    lim = 0.98 if precision == "fp32" else BF16_REF_ROWS.get(name, 0.97)
-    assert _rows_ok(out, ref, atol if precision == "fp32" else 2e-2, rtol if precision == "fp32" else 2e-2) >= lim
+    if precision == "fp32":
+        assert _rows_ok(out, ref, atol, rtol) >= 0.98
+    else:
+        assert _rows_scaled_ok(out, ref, REL16[precision]) >= 0.97
     staged = _staged(g, inp, precision)["out"].cpu()
     assert torch.equal(staged, out)  # hept_forward == the stage entry points chained
 
@@ -179,7 +204,7 @@ def test_reduce_tables_and_partial_forward(gpu_device):
     assert torch.equal(torch.cat([lo, hi]), out)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "mixed16"])
 def test_tracking_60k_full_size(precision, gpu_device):
     """BASELINE config 3 at full size: golden sampled rows + size-independent properties."""
     inp, fx = cases.load_case("g5_track60k")
@@ -204,14 +229,16 @@ def test_tracking_60k_full_size(precision, gpu_device):
     torch.testing.assert_close(st["qproj"].cpu()[..., rows], qh_ref, rtol=0, atol=4e-6 * float(qh_ref.abs().max()))
     # (3) sampled output rows against the reference (unstable sort there -> tie-aware)
     ref = torch.from_numpy(fx["out_rows"])
-    tol = (1e-5, 1e-4) if precision == "fp32" else (2e-2, 2e-2)
-    assert _rows_ok(out.cpu()[rows], ref, *tol) >= 0.97
+    if precision == "fp32":
+        assert _rows_ok(out.cpu()[rows], ref, 1e-5, 1e-4) >= 0.97
+    else:
+        assert _rows_scaled_ok(out.cpu()[rows], ref, REL16[precision]) >= 0.96
     # (4) every output row is a convex combination of values pushed through out_linear: linear in v
     g2 = dict(g)
     g2["v"] = g["v"] * 2.0
     out2 = _forward(g2, inp, precision)
     bias = g["out_bias"]
-    torch.testing.assert_close(out2 - bias, 2.0 * (out - bias), rtol=2e-3 if precision == "bf16" else 1e-4, atol=1e-5)
+    torch.testing.assert_close(out2 - bias, 2.0 * (out - bias), rtol=1e-4 if precision == "fp32" else 2e-3, atol=1e-5)
     # (5) checksum of checksums vs the full oracle would take minutes on CPU: compare against the
     #     oracle on the sampled rows' blocks instead -> done in (3); denominators must be positive
     assert bool((ops.unpack_part(st["part"])[..., d] > 0).all())

@@ -19,9 +19,10 @@ def run_case(name, precision):
     inp, fx = cases.load_case(name)
     B, K = inp["block_size"], inp["w_per_dist"]
     print(f"== {name} N={inp['q'].shape[0]} B={B} T={inp['alpha'].shape[2]} precision={precision}", flush=True)
-    tile = torch.bfloat16 if precision == "bf16" else torch.float32
+    tile = torch.float32 if precision == "fp32" else torch.bfloat16
+    qk = torch.float16 if precision == "mixed16" else None
     orc = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"], inp["alpha"],
-                     inp["out_weight"], inp["out_bias"], block_size=B, w_per_dist=K, tile_dtype=tile)  # bf16: tiles and P rounded
+                     inp["out_weight"], inp["out_bias"], block_size=B, w_per_dist=K, tile_dtype=tile, qk_dtype=qk)
     g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
     H, E, T = inp["alpha"].shape; D = inp["q"].shape[1] // H; N = inp["q"].shape[0]
     sw = ops.rpe_scale(g["w_rpe_weight"], H, D, K)
@@ -29,14 +30,16 @@ def run_case(name, precision):
     ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw, g["alpha"], g["combined_shifts"], precision)
     stats("qproj", ph["qproj"], orc["q_hashed"]); stats("kproj", ph["kproj"], orc["k_hashed"])
     qh = ph["qhat"].float().cpu(); kv = ph["kvhat"].float().cpu()
+    vraw = ph["kvhat"][..., 32:].view(torch.bfloat16).float().cpu() if precision == "mixed16" else kv[..., 32:]
     qref = orc["q_hat"]; kref = orc["k_hat"]
-    if precision == "bf16":
-        qref = qref.to(torch.bfloat16).float(); kref = kref.to(torch.bfloat16).float()
+    if precision != "fp32":
+        qd = torch.float16 if precision == "mixed16" else torch.bfloat16
+        qref = qref.to(qd).float(); kref = kref.to(qd).float()
     stats("qhat[:E]", qh[..., :E], qref); stats("khat[:E]", kv[..., :E], kref)
     vref = inp["v"].reshape(N, H, D).permute(1, 0, 2)
-    if precision == "bf16": vref = vref.to(torch.bfloat16).float()
-    stats("v", kv[..., 32:32 + D], vref)
-    print("   v ones col", kv[..., 32 + D].min().item(), kv[..., 32 + D].max().item(), "pad", kv[..., 32 + D + 1:].abs().max().item())
+    if precision != "fp32": vref = vref.to(torch.bfloat16).float()
+    stats("v", vraw[..., :D], vref)
+    print("   v ones col", vraw[..., D].min().item(), vraw[..., D].max().item(), "pad", vraw[..., D + 1:].abs().max().item())
     mm = ph["minmax"].cpu()
     span = (mm[..., 1].amax(-1) - mm[..., 0].amin(-1))
     stats("hash_span", span, orc["hash_span"].squeeze(-1))
@@ -80,7 +83,7 @@ if __name__ == "__main__":
     names = sys.argv[1:] or ["g1_rand512", "g6_block100", "g4_pileup", "g3_ckpt6k"]
     print(torch.cuda.get_device_name(0))
     for nm in names:
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", "bf16", "mixed16"):
             try:
                 run_case(nm, prec)
             except Exception as e:
