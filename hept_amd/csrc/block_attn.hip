@@ -34,7 +34,7 @@ namespace {
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-template <int NKT, bool BF16, bool P16, bool F16QK>
+template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL>
 __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __restrict__ qhat,
                                                               const char* __restrict__ kvhat,
                                                               const int* __restrict__ qpos,
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
 
     // ---- this wave's 32 query rows: HBM -> registers (B-operand layout), norm from the row tail
     const int qi = w * 32 + li;
-    const bool qvalid = qi < B;
+    const bool qvalid = FULL || qi < B;
     const int qsrc = qp[qvalid ? qi : 0];
     if (hh == 0) qidx_s[qi] = qvalid ? qsrc : -1;
     const char* qrow = qbase + (size_t)qsrc * QROW;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
         const int ci = it * NT + tid;
         const int key = ci / CPR, c = ci % CPR;
         u32x4 val = {0u, 0u, 0u, 0u};
-        if (key < B) {
+        if (FULL || key < B) {  // FULL: B == 32 * NKT, no ragged tile -> no masking code at all
             const int src = kp[key];
             val = *reinterpret_cast<const u32x4*>(kvbase + (size_t)src * KVROW + c * 16);
         }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
 
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        if (kt * 32 >= B) break;  // uniform
+        if (!FULL && kt * 32 >= B) break;  // uniform
         const int key = kt * 32 + li;
         f32x16 x;
 #pragma unroll
@@ -141,10 +141,12 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
                 x = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], __uint_as_float(qraw[s >> 2][s & 3]), x, 0, 0, 0);
         }
 
+        // exp(min(x, 0)) written as min(exp(x), 1): identical value for every x (exp is monotone, exp(0) = 1),
+        // and v_min on the v_exp result needs no NaN-canonicalising v_max in front of it
         float pr[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = __expf(fminf(x[r], 0.f));
-        if ((kt + 1) * 32 > B) {  // ragged last tile (B not a multiple of 32): padded keys carry no weight
+        for (int r = 0; r < 16; ++r) pr[r] = fminf(__expf(x[r]), 1.f);
+        if (!FULL && (kt + 1) * 32 > B) {  // ragged last tile (B not a multiple of 32): padded keys carry no weight
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (kt * 32 + hept_acc_row(r, hh) >= B) pr[r] = 0.f;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
             const float nbr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mine), 0xB1,
                                                                                  0xF, 0xF, true));  // lane ^ 1
             const int q2 = w * 32 + hept_acc_row(r, hh);
-            if (q2 < B && (li & 1) == 0) {
+            if ((FULL || q2 < B) && (li & 1) == 0) {
                 const int dst = qidx_s[q2];
                 unsigned int word = hept_pack_bf16(mine, nbr);
                 if (li == D) word = __float_as_uint(mine + 1e-20f);  // example/hept.py:14 (D is even)
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q2 = w * 32 + hept_acc_row(r, hh);
-            if (q2 < B) {
+            if (FULL || q2 < B) {
                 const int dst = qidx_s[q2];
                 float val = z[r];
                 if (li == D) val += 1e-20f;  // example/hept.py:14
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __rest
     }
 }
 
-template <bool BF16, bool P16, bool F16QK>
-int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
+template <bool BF16, bool P16, bool F16QK, bool FULL>
+int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
                 const int* kpos, float* part, int N, int H, int D, int B, int nb) {
 #define HEPT_ATTN_CASE(K)                                                                                    \
     case K: {                                                                                                \
@@ -222,13 +224,13 @@ int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char
         if (lds > 65536) {                                                                                   \
             static bool raised = false;                                                                      \
             if (!raised) {                                                                                   \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16, F16QK>),          \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16, F16QK, FULL>),          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
                     return HEPT_ERR_LAUNCH;                                                                  \
                 raised = true;                                                                               \
             }                                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16, F16QK>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
+        hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16, F16QK, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
                            kpos, part, N, H, D, B, nb);                                                      \
         break;                                                                                               \
     }
@@ -246,6 +248,14 @@ int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char
     }
 #undef HEPT_ATTN_CASE
     return hept_launch_status();
+}
+
+template <bool BF16, bool P16, bool F16QK>
+int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
+                const int* kpos, float* part, int N, int H, int D, int B, int nb) {
+    if (B == 32 * nkt)
+        return launch_attn_full<BF16, P16, F16QK, true>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb);
+    return launch_attn_full<BF16, P16, F16QK, false>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb);
 }
 
 }  // namespace
