@@ -11,7 +11,7 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p
 
 from .build import LIB_PATH
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PREC_F32, PREC_BF16, PREC_MIXED16 = 0, 1, 2
 ROW = 32
 MAX_TABLES = 8
@@ -42,6 +42,7 @@ SIGNATURES = {
     "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
     "hept_profile_enable": (c_int, [c_int, c_int]),
     "hept_profile_read": (c_int, [_P, _P]),
+    "hept_profile_stride": (c_int, [c_int]),
 }
 
 _lib = None

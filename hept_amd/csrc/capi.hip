@@ -45,16 +45,21 @@ Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
 // ---- optional stage timing (hept_profile_*): a pool of HIP events recorded on the caller's stream
 struct Profiler {
     int mode = 0, max_calls = 0, n_calls = 0;
+    int stride = 1, seen = 0;  // only every `stride`-th forward call is bracketed
     hipEvent_t* ev = nullptr;  // [max_calls][5]
 } g_prof;
 
+inline bool prof_active() {
+    return g_prof.mode != 0 && g_prof.n_calls < g_prof.max_calls && g_prof.seen % g_prof.stride == 0;
+}
 inline void prof_mark(int slot, hipStream_t st) {
-    if (g_prof.mode == 0 || g_prof.n_calls >= g_prof.max_calls) return;
+    if (!prof_active()) return;
     if (g_prof.mode == 1 && slot != 2 && slot != 3) return;
     hipEventRecord(g_prof.ev[(size_t)g_prof.n_calls * 5 + slot], st);
 }
 inline void prof_call_done() {
-    if (g_prof.mode != 0 && g_prof.n_calls < g_prof.max_calls) ++g_prof.n_calls;
+    if (prof_active()) ++g_prof.n_calls;
+    if (g_prof.mode != 0) ++g_prof.seen;
 }
 
 // stages shared by hept_forward / hept_forward_partial; leaves per-table partials in w.part
@@ -81,7 +86,7 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 4; }
+extern "C" int hept_abi_version(void) { return 5; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -150,12 +155,20 @@ extern "C" int hept_profile_enable(int mode, int max_calls) {
     }
     g_prof.mode = mode;
     g_prof.n_calls = 0;
+    g_prof.seen = 0;
     g_prof.max_calls = mode ? max_calls : 0;
     if (g_prof.max_calls) {
         g_prof.ev = new hipEvent_t[(size_t)g_prof.max_calls * 5];
         for (size_t i = 0; i < (size_t)g_prof.max_calls * 5; ++i)
             if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return HEPT_ERR_LAUNCH;
     }
+    return HEPT_OK;
+}
+
+extern "C" int hept_profile_stride(int stride) {
+    if (stride < 1) return HEPT_ERR_ARG;
+    g_prof.stride = stride;
+    g_prof.seen = 0;
     return HEPT_OK;
 }
 

@@ -1,4 +1,4 @@
-// sort_tables: AND-shifted sort keys + stable segmented sort (bucket pass + in-bucket ranking).
+// sort_tables: AND-shifted sort keys + stable segmented sort (two 8-bit passes on a 16-bit bucket id + in-bucket ranking).
 //
 // Replaces, for tables [t0, t0+Tl) (reference file:line):
 //   hash_shift = max - min            example/hept_utils.py:70
@@ -9,32 +9,32 @@
 // exactly torch.sort(stable=True): ascending key, ties in ascending point index (the
 // reference's own argsort is unstable and leaves tie order undefined, SURVEY.md §7 hard part 1).
 //
-// Integer/byte work, HBM/L2-bound, four launches:
-//   K1 keygen   key -> order-preserving u32 + per-chunk histogram of a MONOTONE bucket id
-//               b(key) = trunc((key - kmin) * NB / (kmax - kmin)); [kmin,kmax] is the a-priori bound
-//               [hash min, hash max + largest code * span] from the prep kernel's partials
-//   K2 scan     histogram -> exclusive offsets [segment][chunk][bucket] (in place) + bucket starts
-//   K3 scatter  stable counting-sort pass on b (wave-level ballots, 64-wide; no data-path atomics),
-//               (key,index) travel as one 8-byte pair
-//   K4 rank     every element counts the smaller keys of its own bucket -> final position
-// b() is a monotone non-decreasing function of the key itself (fp32 sub, mul and truncation are all
-// monotone), so bucket order never contradicts key order and ties never straddle buckets: the
-// two-level result is the exact stable sort for ANY input.  Cost is O(N + sum bucket^2): with the
-// quantile AND codes of HEPT the keys are near-uniform over [kmin,kmax] (~N/4096 per bucket);
-// adversarial inputs (all keys within 1/4096 of the range) degrade to O(N^2) compares per
-// segment — slow, never wrong.
+// Integer/byte work, HBM/L2-bound.  Every key gets a MONOTONE 16-bit bucket id
+//     id(key) = trunc((key - kmin) * 65536 / (kmax - kmin)),
+// where [kmin,kmax] = [hash min, hash max + largest code * span] is known before any key exists (from the
+// prep kernel's partials).  id() is a monotone non-decreasing function of the key itself (fp32 subtract,
+// multiply and truncate are monotone), so id order never contradicts key order and equal keys share an id.
+//   K1 keygen      key -> order-preserving u32, per-chunk histogram of the LOW id byte
+//   K2 scan        histogram -> exclusive offsets [segment][chunk][256]
+//   K3 scatter     stable counting-sort pass on the low byte (wave-level ballots, 64-wide; no data-path
+//                  atomics); the chunk is bucket-sorted in LDS first so that the global writes are runs of
+//                  ~16 consecutive (key,index) pairs instead of single 8-byte scatters
+//   K4 hist        per-chunk histogram of the HIGH id byte of the pass-1 order;  K5 = K2;  K6 = K3 (high byte)
+//   K7 rank        keys are now grouped by id (~N/65536 * clumping, a handful per id): every element counts the
+//                  same-id neighbours that sort before it (u64 compare of (key << 32 | index): inside an id the
+//                  stable passes kept ascending index order) -> final position
+// The result is the exact stable sort for ANY input; cost O(N + sum group^2).  Adversarial inputs (all keys
+// inside 1/65536 of the range) degrade to O(N^2) neighbour scans per segment — slow, never wrong.
 #include "common.h"
 
 namespace {
 
 constexpr int SORT_THREADS = 256;
-// (8192 buckets / 8192-key chunks were measured: rank -16 us, but scatter +24 us at 256 VGPRs: net loss)
+constexpr int SORT_WAVES = SORT_THREADS / HEPT_WAVE;
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;  // 4096 keys per workgroup
-constexpr int NB = 4096;                               // buckets per segment (12-bit digit)
-constexpr int NB_BITS = 12;
-constexpr int NB_PER_THREAD = NB / SORT_THREADS;       // 16
-constexpr int SCAN_THREADS = 1024;
+constexpr int RADIX = 256;
+constexpr int ID_BUCKETS = 65536;
 
 __device__ __forceinline__ unsigned int ordered_bits(float key) {
     if (key == 0.f) key = 0.f;  // -0.0 and +0.0 compare equal in the reference sort
@@ -44,31 +44,30 @@ __device__ __forceinline__ unsigned int ordered_bits(float key) {
 __device__ __forceinline__ float from_ordered(unsigned int u) {
     return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
-// monotone bucket id; scale = NB / (kmax - kmin), 0 when all keys are equal
-__device__ __forceinline__ int bucket_of(unsigned int u, float kmin, float scale) {
+// monotone 16-bit bucket id; scale = 65536 / (kmax - kmin), 0 when all keys are equal
+__device__ __forceinline__ unsigned int id16_of(unsigned int u, float kmin, float scale) {
     const float x = (from_ordered(u) - kmin) * scale;
     const int b = (int)x;
-    return b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+    return (unsigned int)(b < 0 ? 0 : (b > ID_BUCKETS - 1 ? ID_BUCKETS - 1 : b));
 }
 
-// per-segment bucket map parameters, written once by K1 (chunk 0) and read by K3 / K4
+// per-segment id map parameters, written once by K1 (chunk 0) and read by the later kernels
 struct SegParams {
     float kmin, scale;
 };
 
-// K1: keys0[seg][n] = ordered bits of (proj + float(code) * span); hist[seg][chunk][NB]; seg_params[seg]
+// K1: keys0[seg][n] = ordered bits of (proj + float(code) * span); hist[seg][chunk][256] of the low id byte
 __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
     const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
     const float* __restrict__ minmax, int N, int H, int t0, int Tl, unsigned int* __restrict__ keys0,
     unsigned int* __restrict__ hist, SegParams* __restrict__ seg_params, int n_chunks) {
-    __shared__ unsigned int h_s[NB];
-    __shared__ float red_s[3][SORT_THREADS / HEPT_WAVE];
+    __shared__ unsigned int h_s[RADIX];
+    __shared__ float red_s[3][SORT_WAVES];
     const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
     const int th = seg % (Tl * H);  // local (table, head)
     const bool is_k = seg >= Tl * H;
     const int t = th / H, h = th % H;
-#pragma unroll
-    for (int i = 0; i < NB_PER_THREAD; ++i) h_s[i * SORT_THREADS + tid] = 0;
+    h_s[tid] = 0;
 
     // hash range + largest code of this (table, head): reduce the prep kernel's per-workgroup partials
     float lo = INFINITY, hi = -INFINITY, cmax = 0.f;
@@ -96,9 +95,9 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
     hi = fmaxf(fmaxf(red_s[1][0], red_s[1][1]), fmaxf(red_s[1][2], red_s[1][3]));
     cmax = fmaxf(fmaxf(red_s[2][0], red_s[2][1]), fmaxf(red_s[2][2], red_s[2][3]));
     const float span = hi - lo;
-    // keys lie in [lo, hi + cmax*span] (codes >= 0); any key outside is clamped by bucket_of (still monotone)
+    // keys lie in [lo, hi + cmax*span] (codes >= 0); any key outside is clamped by id16_of (still monotone)
     const float width = (hi + cmax * span) - lo;
-    float scale = width > 0.f ? (float)NB / width : 0.f;
+    float scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
     if (!(scale < 3.0e38f)) scale = 0.f;  // inf/nan guard for denormal widths: one bucket, still exact
     if (chunk == 0 && tid == 0) seg_params[seg] = SegParams{lo, scale};
 
@@ -130,54 +129,56 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
             u[3] = make_key(pj[3], c23[1]);
             *reinterpret_cast<u32x4*>(kout + n) = u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&h_s[bucket_of(u[e], lo, scale)], 1u);
+            for (int e = 0; e < 4; ++e) atomicAdd(&h_s[id16_of(u[e], lo, scale) & 0xFF], 1u);
         } else {
             for (int e = 0; e < 4; ++e)
                 if (n + e < N) {
                     const unsigned int u = make_key(proj[n + e], code[n + e]);
                     kout[n + e] = u;
-                    atomicAdd(&h_s[bucket_of(u, lo, scale)], 1u);
+                    atomicAdd(&h_s[id16_of(u, lo, scale) & 0xFF], 1u);
                 }
         }
     }
     __syncthreads();
-    unsigned int* dst = hist + ((size_t)seg * n_chunks + chunk) * NB;
-#pragma unroll
-    for (int i = 0; i < NB_PER_THREAD; ++i) dst[i * SORT_THREADS + tid] = h_s[i * SORT_THREADS + tid];
+    hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
 }
 
-// K2: one workgroup per segment.  hist[seg][c][b] <- start[b] + sum_{c' < c} hist[seg][c'][b];
-// bucket_start[seg][b] = start[b] = number of keys in smaller buckets; bucket_start[seg][NB] = N.
-__global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(unsigned int* __restrict__ hist, int n_chunks,
-                                                                   unsigned int* __restrict__ bucket_start) {
-    constexpr int PER = NB / SCAN_THREADS;  // consecutive buckets per thread
-    constexpr int V = PER / 4;
-    constexpr int WAVES = SCAN_THREADS / HEPT_WAVE;
-    constexpr int BATCH = 8;                // chunk rows in flight per thread
-    static_assert(PER % 4 == 0, "bucket count must be a multiple of 4 * SCAN_THREADS");
-    __shared__ unsigned int wsum_s[WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, seg = blockIdx.x;
-    unsigned int* hseg = hist + (size_t)seg * n_chunks * NB + tid * PER;
-    u32x4 total[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) total[j] = u32x4{0u, 0u, 0u, 0u};
-    for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
-        u32x4 x[BATCH][V];
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i)
-#pragma unroll
-            for (int j = 0; j < V; ++j)
-                x[i][j] = (c0 + i < n_chunks) ? *reinterpret_cast<const u32x4*>(hseg + (size_t)(c0 + i) * NB + 4 * j)
-                                              : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i)
-#pragma unroll
-            for (int j = 0; j < V; ++j) total[j] += x[i][j];
+// K4: histogram of the high id byte over the pass-1 order
+__global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const unsigned long long* __restrict__ pairs,
+                                                               const SegParams* __restrict__ seg_params, int N,
+                                                               unsigned int* __restrict__ hist, int n_chunks) {
+    __shared__ unsigned int h_s[RADIX];
+    const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
+    const SegParams rg = seg_params[seg];
+    h_s[tid] = 0;
+    __syncthreads();
+    const uint2* src = reinterpret_cast<const uint2*>(pairs + (size_t)seg * N);
+    const int base = chunk * SORT_CHUNK;
+#pragma unroll 8
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int n = base + i * SORT_THREADS + tid;
+        if (n < N) atomicAdd(&h_s[id16_of(src[n].y, rg.kmin, rg.scale) >> 8], 1u);
     }
-    unsigned int mine = 0;
+    __syncthreads();
+    hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
+}
+
+// K2/K5: one workgroup per segment, one thread per digit.
+// hist[seg][c][d] <- (keys of this segment with a smaller digit) + (same digit in earlier chunks)
+__global__ __launch_bounds__(RADIX) void scan_kernel(unsigned int* __restrict__ hist, int n_chunks) {
+    constexpr int BATCH = 16;
+    __shared__ unsigned int wsum_s[RADIX / HEPT_WAVE];
+    const int d = threadIdx.x, lane = d & 63, w = d >> 6, seg = blockIdx.x;
+    unsigned int* hseg = hist + (size_t)seg * n_chunks * RADIX + d;
+    unsigned int total = 0;
+    for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
+        unsigned int x[BATCH];
 #pragma unroll
-    for (int j = 0; j < V; ++j) mine += total[j][0] + total[j][1] + total[j][2] + total[j][3];
-    unsigned int incl = mine;
+        for (int i = 0; i < BATCH; ++i) x[i] = (c0 + i < n_chunks) ? hseg[(size_t)(c0 + i) * RADIX] : 0u;
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) total += x[i];
+    }
+    unsigned int incl = total;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned int y = __shfl_up(incl, off);
@@ -185,167 +186,208 @@ __global__ __launch_bounds__(SCAN_THREADS) void bucket_scan_kernel(unsigned int*
     }
     if (lane == 63) wsum_s[w] = incl;
     __syncthreads();
-    unsigned int run = incl - mine;
+    unsigned int run = incl - total;
     for (int ww = 0; ww < w; ++ww) run += wsum_s[ww];
-    u32x4 acc[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[j][i] = run;
-            run += total[j][i];
-        }
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-        unsigned int* bs = bucket_start + (size_t)seg * (NB + 1) + tid * PER + 4 * j;
-        bs[0] = acc[j][0]; bs[1] = acc[j][1]; bs[2] = acc[j][2]; bs[3] = acc[j][3];  // (NB+1)-pitch rows: 4-B aligned only
-    }
-    if (tid == SCAN_THREADS - 1) bucket_start[(size_t)seg * (NB + 1) + NB] = run;
     for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
-        u32x4 x[BATCH][V];
+        unsigned int x[BATCH];
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i)
+        for (int i = 0; i < BATCH; ++i) x[i] = (c0 + i < n_chunks) ? hseg[(size_t)(c0 + i) * RADIX] : 0u;
 #pragma unroll
-            for (int j = 0; j < V; ++j)
-                x[i][j] = (c0 + i < n_chunks) ? *reinterpret_cast<const u32x4*>(hseg + (size_t)(c0 + i) * NB + 4 * j)
-                                              : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i)
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                if (c0 + i < n_chunks) *reinterpret_cast<u32x4*>(hseg + (size_t)(c0 + i) * NB + 4 * j) = acc[j];
-                acc[j] += x[i][j];
-            }
+        for (int i = 0; i < BATCH; ++i) {
+            if (c0 + i < n_chunks) hseg[(size_t)(c0 + i) * RADIX] = run;
+            run += x[i];
+        }
     }
 }
 
-// K3: stable scatter by bucket id -> (key,index) pairs in bucket order
-__global__ __launch_bounds__(SORT_THREADS) void bucket_scatter_kernel(
-    const unsigned int* __restrict__ keys0, const SegParams* __restrict__ seg_params,
-    const unsigned int* __restrict__ offs, int N, int n_chunks, unsigned long long* __restrict__ pairs) {
-    constexpr int WAVES = SORT_THREADS / HEPT_WAVE;
-    __shared__ __attribute__((aligned(16))) unsigned short cnt_s[WAVES][NB];  // per-wave bucket counters (<= 1024 keys per wave)
+// K3/K6: one stable counting-sort pass on one id byte.  HI = false: source is keys0 (index implicit), digit =
+// low byte; HI = true: source is the pass-1 pairs, digit = high byte.
+template <bool HI>
+__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned int* __restrict__ keys0,
+                                                               const unsigned long long* __restrict__ src_pairs,
+                                                               const SegParams* __restrict__ seg_params,
+                                                               const unsigned int* __restrict__ offs, int N,
+                                                               int n_chunks,
+                                                               unsigned long long* __restrict__ dst_pairs) {
+    __shared__ unsigned long long stage_s[SORT_CHUNK];   // the chunk, digit-sorted (32 KiB)
+    __shared__ unsigned int cnt_s[SORT_WAVES][RADIX];    // per-wave digit counters -> exclusive wave prefix
+    __shared__ unsigned int start_s[RADIX];              // first local position of a digit
+    __shared__ unsigned int goff_s[RADIX];               // global offset of the digit's first key of this chunk
+    __shared__ unsigned int wsum_s[SORT_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int seg = blockIdx.y, chunk = blockIdx.x;
     const SegParams rg = seg_params[seg];
-    // this wave's counters only: no workgroup barrier needed before ranking
-    {
-        u32x4* z = reinterpret_cast<u32x4*>(&cnt_s[w][0]);
-#pragma unroll
-        for (int i = 0; i < NB * 2 / 16 / HEPT_WAVE; ++i) z[i * HEPT_WAVE + lane] = u32x4{0u, 0u, 0u, 0u};
-    }
-
-    // rank the chunk: wave w owns 1024 consecutive keys, 16 rounds of 64 (stable: index order)
-    unsigned int key[SORT_ITEMS];
-    unsigned short rank[SORT_ITEMS], dig[SORT_ITEMS];
-    const int wbase = chunk * SORT_CHUNK + w * (SORT_ITEMS * HEPT_WAVE);
     const size_t seg_off = (size_t)seg * N;
+#pragma unroll
+    for (int ww = 0; ww < SORT_WAVES; ++ww) cnt_s[ww][tid] = 0;
+    goff_s[tid] = offs[((size_t)seg * n_chunks + chunk) * RADIX + tid];
+
+    // wave w owns 1024 consecutive keys, 16 rounds of 64 (stable: index order)
+    unsigned long long pr[SORT_ITEMS];
+    const int wbase = chunk * SORT_CHUNK + w * (SORT_ITEMS * HEPT_WAVE);
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int n = wbase + r * HEPT_WAVE + lane;
+        if (HI)
+            pr[r] = n < N ? src_pairs[seg_off + n] : ~0ull;
+        else
+            pr[r] = n < N ? (((unsigned long long)keys0[seg_off + n] << 32) | (unsigned int)n) : ~0ull;
+    }
+    __syncthreads();
+    unsigned short rank[SORT_ITEMS];
+    unsigned char dig[SORT_ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int n = wbase + r * HEPT_WAVE + lane;
-        key[r] = n < N ? keys0[seg_off + n] : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int n = wbase + r * HEPT_WAVE + lane;
         const bool valid = n < N;
-        const unsigned int dg = valid ? (unsigned int)bucket_of(key[r], rg.kmin, rg.scale) : (unsigned int)(NB - 1);
-        dig[r] = (unsigned short)dg;
+        const unsigned int id = id16_of((unsigned int)(pr[r] >> 32), rg.kmin, rg.scale);
+        const unsigned int dg = valid ? (HI ? id >> 8 : id & 0xFF) : 0xFFu;
+        dig[r] = (unsigned char)dg;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < NB_BITS; ++b) {
+        for (int b = 0; b < 8; ++b) {
             const bool bit = (dg >> b) & 1u;
             const unsigned long long m = __ballot(bit);
             peers &= bit ? m : ~m;
         }
         const unsigned int prior = cnt_s[w][dg];
         const unsigned int ahead = __popcll(peers & lt_mask);
-        if (valid && ahead == 0) cnt_s[w][dg] = (unsigned short)(prior + __popcll(peers));
+        if (valid && ahead == 0) cnt_s[w][dg] = prior + __popcll(peers);
         rank[r] = (unsigned short)(prior + ahead);
     }
-    const unsigned int* off_c = offs + ((size_t)seg * n_chunks + chunk) * NB;
-    unsigned int base_r[SORT_ITEMS];
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) base_r[r] = off_c[dig[r]];
     __syncthreads();
-    // keys of the same bucket held by earlier waves of this workgroup come first (only the touched
-    // counters are read: the chunk has as many keys as there are buckets)
+    // digit `tid`: exclusive prefix over the waves, then over the digits -> first local position of the digit
+    unsigned int total = 0;
+#pragma unroll
+    for (int ww = 0; ww < SORT_WAVES; ++ww) {
+        const unsigned int c = cnt_s[ww][tid];
+        cnt_s[ww][tid] = total;
+        total += c;
+    }
+    unsigned int incl = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) wsum_s[w] = incl;
+    __syncthreads();
+    unsigned int first = incl - total;
+#pragma unroll
+    for (int ww = 0; ww < SORT_WAVES; ++ww)
+        if (ww < w) first += wsum_s[ww];
+    start_s[tid] = first;
+    __syncthreads();
+    // bucket-sort the chunk inside LDS
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
-        unsigned int before_w = 0;
-#pragma unroll
-        for (int ww = 0; ww < WAVES - 1; ++ww)
-            if (ww < w) before_w += cnt_s[ww][dig[r]];
         const int n = wbase + r * HEPT_WAVE + lane;
-        if (n < N) {
-            const size_t dst = seg_off + base_r[r] + before_w + rank[r];
-            pairs[dst] = ((unsigned long long)key[r] << 32) | (unsigned int)n;
+        if (n < N) stage_s[start_s[dig[r]] + cnt_s[w][dig[r]] + rank[r]] = pr[r];
+    }
+    __syncthreads();
+    // write out: consecutive local positions of one digit are consecutive global positions
+    const int n_valid = min(SORT_CHUNK, N - chunk * SORT_CHUNK);
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int lp = r * SORT_THREADS + tid;
+        if (lp < n_valid) {
+            const unsigned long long p = stage_s[lp];
+            const unsigned int id = id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale);
+            const unsigned int dg = HI ? id >> 8 : id & 0xFF;
+            dst_pairs[seg_off + goff_s[dg] + (lp - start_s[dg])] = p;
         }
     }
 }
 
-// K4: final position = bucket start + number of pairs of the same bucket that are smaller.  A pair is
-// (key << 32 | index); inside a bucket the scatter kept ascending index order, so u64 order of the pairs
-// is exactly (key, then original index): the stable tie rule.  The workgroup's 256 positions plus the
-// rest of their first/last buckets are staged in LDS (same-address reads broadcast within a wave).
+// K7: final position of every element.  After the two passes the pairs are ordered by id, and id is monotone
+// in the key, so everything left of an element's id group is smaller and everything right of it is larger as
+// u64 (key << 32 | index); inside the group the stable passes kept ascending index.  Hence, for ANY window
+// [i-K, i+K] that contains the whole group:
+//        final position(i) = (i - K) + #{ j in window : pair_j < pair_i }
+// -- a branch-free count with no id logic (slots left of the segment hold 0, slots right of it ~0, which
+// makes the formula exact at the segment ends as well).  A thread owns 4 consecutive positions and streams
+// the staged pairs of their joint window once.  Only when a group reaches a window edge (groups are ~5
+// keys at tracking-60k; adversarial inputs can make them arbitrarily long) the element is recounted with
+// plain loops over its whole group.
 constexpr int RANK_PER_THREAD = 4;
 constexpr int RANK_SPAN = SORT_THREADS * RANK_PER_THREAD;  // positions per workgroup
-constexpr int RANK_CAP = 2048;
-__global__ __launch_bounds__(SORT_THREADS) void bucket_rank_kernel(const unsigned long long* __restrict__ pairs,
-                                                                   const SegParams* __restrict__ seg_params,
-                                                                   const unsigned int* __restrict__ bucket_start,
-                                                                   int N, int* __restrict__ pos_out) {
-    __shared__ unsigned long long p_s[RANK_CAP];
-    __shared__ int range_s[2];
+constexpr int RANK_K = 24;
+__global__ __launch_bounds__(SORT_THREADS) void neighbour_rank_kernel(const unsigned long long* __restrict__ pairs,
+                                                                      const SegParams* __restrict__ seg_params,
+                                                                      int N, int* __restrict__ pos_out) {
+    constexpr int W = RANK_SPAN + 2 * RANK_K;
+    // slot(g) = g + g/4: a thread's window starts at a multiple of 4, so lane t reads slot 5t + const ->
+    // 10-dword lane stride, bank-conflict free for ds_read_b64 (a plain layout is 4-way conflicted)
+    __shared__ unsigned long long p_s[W + W / 4 + 1];
     const int seg = blockIdx.y, tid = threadIdx.x;
     const int i0 = blockIdx.x * RANK_SPAN;
-    const int last = min(i0 + RANK_SPAN, N) - 1;
     const SegParams rg = seg_params[seg];
     const unsigned long long* pr = pairs + (size_t)seg * N;
-    const unsigned int* bs = bucket_start + (size_t)seg * (NB + 1);
-    unsigned long long mine[RANK_PER_THREAD];
-    int s[RANK_PER_THREAD], e[RANK_PER_THREAD];
-#pragma unroll
-    for (int u = 0; u < RANK_PER_THREAD; ++u) {
-        const int i = i0 + u * SORT_THREADS + tid;
-        mine[u] = i < N ? pr[i] : 0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < RANK_PER_THREAD; ++u) {
-        const int i = i0 + u * SORT_THREADS + tid;
-        s[u] = 0;
-        e[u] = 0;
-        if (i < N) {
-            const int b = bucket_of((unsigned int)(mine[u] >> 32), rg.kmin, rg.scale);
-            s[u] = (int)bs[b];
-            e[u] = (int)bs[b + 1];
-        }
-        if (i == i0) range_s[0] = s[u];
-        if (i == last) range_s[1] = e[u];
+    auto id_of = [&](unsigned long long p) { return id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale); };
+    for (int j = tid; j < W; j += SORT_THREADS) {
+        const int g = i0 - RANK_K + j;
+        p_s[j + (j >> 2)] = g < 0 ? 0ull : (g < N ? pr[g] : ~0ull);
     }
     __syncthreads();
-    const int lo = range_s[0], hi = range_s[1];
-    int smaller[RANK_PER_THREAD] = {0, 0, 0, 0};
-    if (hi - lo <= RANK_CAP) {
-        for (int j = lo + tid; j < hi; j += SORT_THREADS) p_s[j - lo] = pr[j];
-        __syncthreads();
+    const int b = i0 + RANK_PER_THREAD * tid;  // first of this thread's 4 positions
+    if (b >= N) return;
+    const unsigned long long* win0 = p_s + 5 * tid;  // window slot j of this thread lives at win0[j + j/4]
+#define WIN(j) win0[(j) + ((j) >> 2)]
+    unsigned long long mine[RANK_PER_THREAD];
+    int cnt[RANK_PER_THREAD];
 #pragma unroll
-        for (int u = 0; u < RANK_PER_THREAD; ++u) {
-#pragma unroll 4
-            for (int j = s[u]; j < e[u]; ++j) smaller[u] += p_s[j - lo] < mine[u];
+    for (int e = 0; e < RANK_PER_THREAD; ++e) {
+        mine[e] = WIN(RANK_K + e);
+        cnt[e] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * RANK_K + RANK_PER_THREAD; ++j) {
+        const unsigned long long p = WIN(j);
+#pragma unroll
+        for (int e = 0; e < RANK_PER_THREAD; ++e)
+            if (j >= e && j <= e + 2 * RANK_K) cnt[e] += p < mine[e];  // window of element e: [e, e + 2K]
+    }
+#pragma unroll
+    for (int e = 0; e < RANK_PER_THREAD; ++e) {
+        const int i = b + e;
+        if (i >= N) break;
+        int pos = i - RANK_K + cnt[e];
+        // does the id group reach a window edge?  (edge slots outside the segment never belong to it)
+        const unsigned int id = id_of(mine[e]);
+        const bool left_open = i - RANK_K >= 0 && id_of(WIN(e)) == id;
+        const bool right_open = i + RANK_K < N && id_of(WIN(e + 2 * RANK_K)) == id;
+        if (left_open || right_open) {
+            // walk the whole group from memory, 8 independent loads per round trip
+            int smaller = 0, first = i;
+            bool go = true;
+            for (int j = i - 1; go && j >= 0; j -= 8) {
+                unsigned long long p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = j - u >= 0 ? pr[j - u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    go = go && j - u >= 0 && id_of(p[u]) == id;
+                    smaller += go && p[u] < mine[e];
+                    first = go ? j - u : first;
+                }
+            }
+            go = true;
+            for (int j = i + 1; go && j < N; j += 8) {
+                unsigned long long p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = j + u < N ? pr[j + u] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    go = go && j + u < N && id_of(p[u]) == id;
+                    smaller += go && p[u] < mine[e];
+                }
+            }
+            pos = first + smaller;
         }
-    } else {
-        // oversized bucket(s): same count straight from memory (slow path, adversarial inputs only)
-#pragma unroll
-        for (int u = 0; u < RANK_PER_THREAD; ++u)
-            for (int j = s[u]; j < e[u]; ++j) smaller[u] += pr[j] < mine[u];
+        pos_out[(size_t)seg * N + pos] = (int)(unsigned int)mine[e];
     }
-#pragma unroll
-    for (int u = 0; u < RANK_PER_THREAD; ++u) {
-        const int i = i0 + u * SORT_THREADS + tid;
-        if (i < N) pos_out[(size_t)seg * N + s[u] + smaller[u]] = (int)(unsigned int)mine[u];
-    }
+#undef WIN
 }
 
 }  // namespace
@@ -355,8 +397,8 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) {
     const size_t segs = (size_t)2 * Tl * H;
     const size_t n_chunks = ((size_t)N + SORT_CHUNK - 1) / SORT_CHUNK;
-    return align256(segs * N * 4) + align256(segs * N * 8) + align256(segs * n_chunks * NB * 4) +
-           align256(segs * sizeof(SegParams)) + align256(segs * (NB + 1) * 4);
+    return align256(segs * N * 4) + 2 * align256(segs * N * 8) + align256(segs * n_chunks * RADIX * 4) +
+           align256(segs * sizeof(SegParams));
 }
 
 extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* codes, const float* minmax,
@@ -375,17 +417,20 @@ extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const in
         return r;
     };
     unsigned int* keys0 = reinterpret_cast<unsigned int*>(take((size_t)segs * N * 4));
-    unsigned long long* pairs = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
-    unsigned int* hist = reinterpret_cast<unsigned int*>(take((size_t)segs * n_chunks * NB * 4));
+    unsigned long long* pa = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
+    unsigned long long* pb = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
+    unsigned int* hist = reinterpret_cast<unsigned int*>(take((size_t)segs * n_chunks * RADIX * 4));
     SegParams* params = reinterpret_cast<SegParams*>(take((size_t)segs * sizeof(SegParams)));
-    unsigned int* bstart = reinterpret_cast<unsigned int*>(take((size_t)segs * (NB + 1) * 4));
 
     const dim3 grid(n_chunks, segs), block(SORT_THREADS);
     hipLaunchKernelGGL(keygen_hist_kernel, grid, block, 0, st, qproj, kproj, codes, minmax, N, H, t0, Tl, keys0, hist,
                        params, n_chunks);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(segs), dim3(SCAN_THREADS), 0, st, hist, n_chunks, bstart);
-    hipLaunchKernelGGL(bucket_scatter_kernel, grid, block, 0, st, keys0, params, hist, N, n_chunks, pairs);
-    const dim3 grid4((N + RANK_SPAN - 1) / RANK_SPAN, segs);
-    hipLaunchKernelGGL(bucket_rank_kernel, grid4, block, 0, st, pairs, params, bstart, N, qpos);
+    hipLaunchKernelGGL(scan_kernel, dim3(segs), dim3(RADIX), 0, st, hist, n_chunks);
+    hipLaunchKernelGGL(scatter_kernel<false>, grid, block, 0, st, keys0, nullptr, params, hist, N, n_chunks, pa);
+    hipLaunchKernelGGL(hist_hi_kernel, grid, block, 0, st, pa, params, N, hist, n_chunks);
+    hipLaunchKernelGGL(scan_kernel, dim3(segs), dim3(RADIX), 0, st, hist, n_chunks);
+    hipLaunchKernelGGL(scatter_kernel<true>, grid, block, 0, st, nullptr, pa, params, hist, N, n_chunks, pb);
+    const dim3 grid7((N + RANK_SPAN - 1) / RANK_SPAN, segs);
+    hipLaunchKernelGGL(neighbour_rank_kernel, grid7, block, 0, st, pb, params, N, qpos);
     return hept_launch_status();
 }

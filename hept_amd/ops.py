@@ -223,9 +223,12 @@ def forward_partial(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: 
     return acc
 
 
-def profile_enable(mode: int, max_calls: int = 0) -> None:
-    """Stage timing with HIP events recorded inside hept_forward (mode 1: block_attn only, 2: all stages, 0: off)."""
-    _lib.check(_lib.load().hept_profile_enable(mode, max_calls), "hept_profile_enable")
+def profile_enable(mode: int, max_calls: int = 0, stride: int = 1) -> None:
+    """Stage timing with HIP events recorded inside hept_forward (mode 1: block_attn only, 2: all stages, 0: off);
+    only every ``stride``-th call is bracketed."""
+    lib = _lib.load()
+    _lib.check(lib.hept_profile_enable(mode, max_calls), "hept_profile_enable")
+    _lib.check(lib.hept_profile_stride(stride), "hept_profile_stride")
 
 
 def profile_read() -> Tuple[Dict[str, float], int]:

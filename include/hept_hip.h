@@ -130,6 +130,9 @@ int hept_forward_partial(const float* q, const float* k, const float* v, const f
  * calls into ms[4], stores the number of calls in *n_calls and resets the pool. */
 int hept_profile_enable(int mode, int max_calls);
 int hept_profile_read(float* ms, int* n_calls);
+/* Bracket only every `stride`-th forward call (default 1): an event pair costs a few microseconds of
+ * stream time, so a timed loop samples the kernel instead of instrumenting every step. */
+int hept_profile_stride(int stride);
 
 #ifdef __cplusplus
 }
