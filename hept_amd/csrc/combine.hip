@@ -18,8 +18,117 @@ namespace {
 constexpr int CMB_THREADS = 256;
 constexpr int CMB_WAVES = CMB_THREADS / HEPT_WAVE;
 
-// 16 consecutive columns [16*hh, 16*hh+16) of one (table, point, head) partial row, widened to fp32.
-// P16 rows: 16 dwords = [D bf16 numerators in dwords 0..11 | f32 denominator in dword 12 | 0].
+// Raw 16-B pieces of one (table, point, head) partial row kept in registers until they are needed
+// (P16: 4 pieces = 64 B; f32: 7 pieces = the 28 leading floats, which hold numer 0..D-1 and the denominator).
+template <bool P16>
+struct RawRow {
+    static constexpr int PIECES = P16 ? 4 : 7;
+    u32x4 q[PIECES];
+    __device__ __forceinline__ void load(const float* __restrict__ row) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(row);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) q[i] = src[i];
+    }
+    // x[0..27] += widened row; returns the denominator
+    __device__ __forceinline__ float add_to(float (&x)[28], int D) const {
+        if constexpr (P16) {  // [24 bf16 numerators in dwords 0..11 | f32 denominator in dword 12 | 0]
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x[8 * p + 2 * i] += hept_bf16_lo(q[p][i]);
+                    x[8 * p + 2 * i + 1] += hept_bf16_hi(q[p][i]);
+                }
+            return __uint_as_float(q[3][0]);
+        } else {              // [numer 0..D-1 | denom at D | 0]
+            float den = 0.f;
+#pragma unroll
+            for (int p = 0; p < 7; ++p)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = __uint_as_float(q[p][u]);
+                    x[4 * p + u] += v;
+                    if (4 * p + u == D) den = v;
+                }
+            return den;
+        }
+    }
+};
+
+// One wave = 32 points.  Lane (point = lane & 31, hh = lane >> 5) owns the rows of heads 2j + hh: it loads a
+// whole row (64 B packed / 112 B f32, contiguous) per table, so the denominator sits in the same lane as its
+// numerators (no cross-lane traffic), and the two lane halves feed the two k-slots of v_mfma_f32_32x32x2_f32
+// with different heads: D steps per head pair, no padded columns in the MFMA stream.  The rows of the next
+// head pair are requested before the current pair is reduced (the kernel runs at ~2 waves per SIMD, so the
+// overlap has to come from inside the wave).  Tables are summed in the reference's order (t = 0, 1, ...);
+// the division is one correctly rounded reciprocal per row followed by multiplies (<= 1 ulp from a/b).
+template <bool P16>
+__global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
+                                                                  int H, int D, int n0, int n_count,
+                                                                  const float* __restrict__ W,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ out) {
+    constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
+    constexpr int TMAX = HEPT_MAX_TABLES;
+    extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H (even-padded)][28 (d)][32 (c, zero padded)]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
+    const int HD = H * D, HP = (H + 1) & ~1;
+    for (int i = tid; i < HP * 28 * 32; i += CMB_THREADS) {
+        const int c = i & 31, d = (i >> 5) % 28, h = i / (28 * 32);
+        wt_s[i] = (c < D && d < D && h < H) ? W[(size_t)c * HD + h * D + d] : 0.f;  // W is (D, H*D) row-major
+    }
+    const float bia = (li < D && bias) ? bias[li] : 0.f;
+    __syncthreads();
+    const size_t tstride = (size_t)N * H * ROWF;
+    const int n_tiles = (n_count + 31) / 32;
+    for (int tile = blockIdx.x * CMB_WAVES + w; tile < n_tiles; tile += gridDim.x * CMB_WAVES) {
+        const int i = tile * 32 + li;
+        const int n = n0 + (i < n_count ? i : n_count - 1);
+        const float* prow = part + (size_t)n * H * ROWF;
+        auto row_of = [&](int hp) { const int head = hp + hh; return prow + (size_t)(head < H ? head : 0) * ROWF; };
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        RawRow<P16> cur[3], nxt[3];  // up to 3 tables in flight; more tables are loaded in place below
+        const int tpre = Tl < 3 ? Tl : 3;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < tpre) cur[t].load(row_of(0) + (size_t)t * tstride);
+        for (int hp = 0; hp < HP; hp += 2) {
+            const bool more = hp + 2 < HP;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (more && t < tpre) nxt[t].load(row_of(hp + 2) + (size_t)t * tstride);
+            float s[28];
+#pragma unroll
+            for (int u = 0; u < 28; ++u) s[u] = 0.f;
+            float den = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (t < tpre) den += cur[t].add_to(s, D);
+            for (int t = 3; t < Tl && t < TMAX; ++t) {  // beyond three tables: plain loads
+                RawRow<P16> extra;
+                extra.load(row_of(hp) + (size_t)t * tstride);
+                den += extra.add_to(s, D);
+            }
+            const float inv = 1.0f / den;
+            const int head = hp + hh;
+            const float* wrow = wt_s + (size_t)head * 28 * 32 + li;
+#pragma unroll
+            for (int u = 0; u < 28; ++u)
+                if (u < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[u] * inv, wrow[u * 32], acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) cur[t] = nxt[t];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i2 = tile * 32 + hept_acc_row(r, hh);
+            if (i2 < n_count && li < D) out[(size_t)i2 * D + li] = acc[r] + bia;
+        }
+    }
+}
+
+// 16 consecutive columns [16*hh, 16*hh+16) of one partial row, widened to fp32 (reduce_tables)
 template <bool P16>
 __device__ __forceinline__ void load_half_row(const float* __restrict__ row, int hh, float (&x)[16]) {
     if constexpr (P16) {
@@ -43,62 +152,6 @@ __device__ __forceinline__ void load_half_row(const float* __restrict__ row, int
         for (int c4 = 0; c4 < 4; ++c4) {
             const f32x4 v = src[c4];
             x[4 * c4] = v[0]; x[4 * c4 + 1] = v[1]; x[4 * c4 + 2] = v[2]; x[4 * c4 + 3] = v[3];
-        }
-    }
-}
-
-template <bool P16>
-__global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
-                                                                  int H, int D, int n0, int n_count,
-                                                                  const float* __restrict__ W,
-                                                                  const float* __restrict__ bias,
-                                                                  float* __restrict__ out) {
-    constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
-    constexpr int DEN = P16 ? 24 : -1;    // P16 rows carry the denominator at column 24 of the widened row
-    extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H][32 (d, zero padded)][32 (c, zero padded)]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
-    const int HD = H * D;
-    const int dcol = P16 ? DEN : D;
-    for (int i = tid; i < H * 32 * 32; i += CMB_THREADS) {
-        const int c = i & 31, d = (i >> 5) & 31, h = i >> 10;
-        wt_s[i] = (c < D && d < D) ? W[(size_t)c * HD + h * D + d] : 0.f;  // W is (D, H*D) row-major
-    }
-    const float bia = (li < D && bias) ? bias[li] : 0.f;
-    __syncthreads();
-    const size_t tstride = (size_t)N * H * ROWF;
-
-    const int n_tiles = (n_count + 31) / 32;
-    for (int tile = blockIdx.x * CMB_WAVES + w; tile < n_tiles; tile += gridDim.x * CMB_WAVES) {
-        const int i = tile * 32 + li;
-        const int n = n0 + (i < n_count ? i : n_count - 1);
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* row0 = part + (size_t)n * H * ROWF;
-        for (int h = 0; h < H; ++h) {
-            float s[16];
-            load_half_row<P16>(row0 + h * ROWF, hh, s);
-            for (int t = 1; t < Tl; ++t) {
-                float x[16];
-                load_half_row<P16>(row0 + h * ROWF + (size_t)t * tstride, hh, x);
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s[u] += x[u];
-            }
-            // denominator column: held by the lane half that owns columns [16*hh, 16*hh+16)
-            float den = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (16 * hh + u == dcol) den = s[u];
-            den = __shfl(den, li + 32 * (dcol >> 4));
-            const float* wrow = wt_s + (size_t)h * 1024 + (16 * hh) * 32 + li;
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[u] / den, wrow[u * 32], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i2 = tile * 32 + hept_acc_row(r, hh);
-            if (i2 < n_count && li < D) out[(size_t)i2 * D + li] = acc[r] + bia;
         }
     }
 }
@@ -154,7 +207,7 @@ extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, i
     if (Tl < 1 || N < 1 || H < 1 || H > 15 || D < 1 || D > 28 || n0 < 0 || n_count < 0 || n0 + n_count > N)
         return HEPT_ERR_SHAPE;
     if (n_count == 0) return HEPT_OK;
-    const size_t lds = sizeof(float) * (size_t)H * 32 * 32;
+    const size_t lds = sizeof(float) * (size_t)((H + 1) & ~1) * 28 * 32;
     const int n_tiles = (n_count + 31) / 32;
     const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
     const int grid = wgs < 2048 ? wgs : 2048;
