@@ -6,8 +6,8 @@ The compute path is the HIP library ``csrc/libhept_hip.so`` (C ABI in
 ``include/hept_hip.h``); there is no CPU or eager-PyTorch fallback.
 """
 from .hept import E2LSH, HEPTAttention
-from .prep import bit_shift, get_regions, pad_and_unpad, prepare_input, quantile_partition
+from .prep import bit_shift, get_regions, pad_and_unpad, prepare_input, prepare_input_hip, quantile_partition
 
 __all__ = [
-    "HEPTAttention", "E2LSH", "prepare_input", "get_regions", "quantile_partition", "bit_shift", "pad_and_unpad",
+    "HEPTAttention", "E2LSH", "prepare_input", "prepare_input_hip", "get_regions", "quantile_partition", "bit_shift", "pad_and_unpad",
 ]

@@ -34,12 +34,16 @@ SIGNATURES = {
     "hept_prep_hash": (c_int, [_P] * 7 + [c_int] * 8 + [_P] * 6),
     "hept_sort_workspace_bytes": (c_size_t, [c_int] * 3),
     "hept_sort_tables": (c_int, [_P] * 4 + [c_int] * 5 + [_P] * 4),
+    "hept_argsort_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "hept_segmented_argsort": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "hept_block_attn": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P]),
     "hept_part_precision": (c_int, [c_int, c_int]),
     "hept_reduce_tables": (c_int, [_P] + [c_int] * 5 + [_P, _P]),
     "hept_combine_out": (c_int, [_P] + [c_int] * 7 + [_P] * 4),
     "hept_forward": (c_int, [_P] * 9 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
+    "hept_prepare_workspace_bytes": (c_size_t, [c_int] * 5),
+    "hept_prepare_input": (c_int, [_P, c_int, _P, _P] + [c_int] * 4 + [_P] + [c_int] * 3 + [_P, c_size_t] + [_P] * 5),
     "hept_profile_enable": (c_int, [c_int, c_int]),
     "hept_profile_read": (c_int, [_P, _P]),
     "hept_profile_stride": (c_int, [c_int]),

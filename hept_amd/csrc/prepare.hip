@@ -1,0 +1,210 @@
+// prepare_input on the GPU: quantile regions -> packed AND code -> pad to block multiples.
+//
+// Replaces, for one batch of clouds (reference file:line):
+//   argsort(eta), argsort(phi) per cloud + quantile_partition   example/transformer.py:44-51, example/hept_utils.py:6-14
+//   bit_shift x2                                                example/transformer.py:10-13,55-56
+//   pad_and_unpad + the three gathers by pad_seq                example/transformer.py:16-32,59-62
+//
+// Integer/byte work on a few 1e5 elements: launch-latency bound, not bandwidth bound.  All sorts go through
+// hept_segmented_argsort (stable, exact); region ids use integer division (rank and width are exact
+// integers in fp32, so `rank // width` of the reference is the integer quotient); the bit counts
+// ceil(log2(max + 1)) are bit lengths.  The reference ranks with an unstable argsort: ties between equal
+// coordinates / equal codes are broken by index here (as in the torch mirror hept_amd/prep.py).
+#include "common.h"
+
+namespace {
+
+constexpr int PT = 256;
+
+__device__ __forceinline__ int bit_length(int m) { return m <= 0 ? 0 : 32 - __clz(m); }
+
+// keys[(c*2 + a)][j] = coordinate a of the j-th point of cloud c, +inf beyond the cloud
+__global__ __launch_bounds__(PT) void coord_keys_kernel(const float* __restrict__ coords, int C,
+                                                        const int* __restrict__ cloud_start, int L,
+                                                        float* __restrict__ keys) {
+    const int seg = blockIdx.y, c = seg >> 1, a = seg & 1;
+    const int j = blockIdx.x * PT + threadIdx.x;
+    if (j >= L) return;
+    const int s = cloud_start[c], n_c = cloud_start[c + 1] - s;
+    keys[(size_t)seg * L + j] = j < n_c ? coords[(size_t)(s + j) * C + a] : INFINITY;
+}
+
+// rank[a][point] = position of the point in its cloud's ascending order of coordinate a
+__global__ __launch_bounds__(PT) void rank_scatter_kernel(const int* __restrict__ pos,
+                                                          const int* __restrict__ cloud_start, int L, int n_raw,
+                                                          int* __restrict__ rank) {
+    const int seg = blockIdx.y, c = seg >> 1, a = seg & 1;
+    const int r = blockIdx.x * PT + threadIdx.x;
+    const int s = cloud_start[c], n_c = cloud_start[c + 1] - s;
+    if (r < n_c) rank[(size_t)a * n_raw + s + pos[(size_t)seg * L + r]] = r;
+}
+
+// region id of a rank: rank // ceil(n_c / regions) + 1, with the reference's fp32 evaluation of the width
+// (`n / regions` with a Python-int numerator is reciprocal-times-n in torch, hept_amd/prep.py)
+__device__ __forceinline__ int region_of(int rank, int n_c, float regions) {
+    const float width = ceilf((1.0f / regions) * (float)n_c);
+    return rank / (int)width + 1;
+}
+
+// cloud of a raw point: binary search in cloud_start (points of a cloud are contiguous)
+__device__ __forceinline__ int cloud_of(const int* __restrict__ cloud_start, int n_clouds, int n) {
+    int lo = 0, hi = n_clouds;  // invariant: cloud_start[lo] <= n < cloud_start[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cloud_start[mid] <= n) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// phase 0: max eta region per row; phase 1: max of (phi << bits_eta | eta) per row; phase 2: final codes
+template <int PHASE>
+__global__ __launch_bounds__(PT) void codes_kernel(const int* __restrict__ rank, const int* __restrict__ cloud_start,
+                                                   int n_clouds, int n_raw, const float* __restrict__ regions, int T,
+                                                   int H, int* __restrict__ row_max /* [2][T*H] */,
+                                                   int64_t* __restrict__ codes_raw) {
+    const int row = blockIdx.y, t = row / H, h = row % H;
+    const int n = blockIdx.x * PT + threadIdx.x;
+    int val = 0;
+    if (n < n_raw) {
+        const int c = cloud_of(cloud_start, n_clouds, n);
+        const int n_c = cloud_start[c + 1] - cloud_start[c];
+        const int eta = region_of(rank[n], n_c, regions[((size_t)t * 2 + 0) * H + h]);
+        if (PHASE == 0) {
+            val = eta;
+        } else {
+            const int phi = region_of(rank[(size_t)n_raw + n], n_c, regions[((size_t)t * 2 + 1) * H + h]);
+            const int p1 = (phi << bit_length(row_max[row])) | eta;
+            if (PHASE == 1) {
+                val = p1;
+            } else {
+                codes_raw[(size_t)row * n_raw + n] =
+                    ((int64_t)c << bit_length(row_max[(size_t)T * H + row])) | (int64_t)p1;
+                return;
+            }
+        }
+    }
+    if (PHASE == 2) return;
+    // workgroup max -> one atomic per workgroup
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) val = max(val, __shfl_xor(val, off));
+    __shared__ int red_s[PT / HEPT_WAVE];
+    if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = val;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int m = red_s[0];
+        for (int i = 1; i < PT / HEPT_WAVE; ++i) m = max(m, red_s[i]);
+        atomicMax(&row_max[(size_t)PHASE * T * H + row], m);
+    }
+}
+
+__global__ __launch_bounds__(PT) void code_keys_kernel(const int64_t* __restrict__ codes_row0, int n_raw,
+                                                       float* __restrict__ keys) {
+    const int n = blockIdx.x * PT + threadIdx.x;
+    if (n < n_raw) keys[n] = (float)codes_row0[n];  // codes < 2^24 (checked by the caller): exact
+}
+
+// one thread per padded slot: gather index, un-pad mask, padded coords; blockIdx.y > 0: padded codes of one row
+__global__ __launch_bounds__(PT) void pad_gather_kernel(const int* __restrict__ cloud_start,
+                                                        const int* __restrict__ pad_start, int n_clouds, int n_raw,
+                                                        int n_pad, int B, const int* __restrict__ by_code,
+                                                        const float* __restrict__ coords, int C,
+                                                        const int64_t* __restrict__ codes_raw, int rows,
+                                                        int64_t* __restrict__ pad_seq, unsigned char* __restrict__ unpad,
+                                                        float* __restrict__ coords_pad, int64_t* __restrict__ codes_pad) {
+    const int s = blockIdx.x * PT + threadIdx.x;
+    if (s >= n_pad) return;
+    const int c = cloud_of(pad_start, n_clouds, s);
+    const int j = s - pad_start[c];
+    const int n_c = cloud_start[c + 1] - cloud_start[c];
+    const bool real = j < n_c;
+    int src;
+    if (real) {
+        src = cloud_start[c] + j;
+    } else {
+        // pad slot j - n_c copies the point at sorted position raw_end - B + (j - n_c) of the table-0/head-0
+        // code order; a cloud smaller than B reaches into the previous cloud, a negative index wraps
+        // (torch indexing), exactly as the reference does
+        int sp = cloud_start[c + 1] - B + (j - n_c);
+        if (sp < 0) sp += n_raw;
+        src = by_code[sp];
+    }
+    const int part = blockIdx.y;
+    if (part == 0) {
+        pad_seq[s] = src;
+        unpad[s] = real ? 1 : 0;
+        for (int a = 0; a < C; ++a) coords_pad[(size_t)s * C + a] = coords[(size_t)src * C + a];
+    } else {
+        const int row = part - 1;
+        codes_pad[(size_t)row * n_pad + s] = codes_raw[(size_t)row * n_raw + src];
+    }
+}
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t hept_prepare_workspace_bytes(int n_raw, int n_clouds, int max_cloud, int T, int H) {
+    const size_t S = (size_t)2 * n_clouds;
+    const size_t sortL = (size_t)max_cloud > (size_t)n_raw / 1 ? (size_t)max_cloud : (size_t)max_cloud;
+    size_t b = 0;
+    b += al256(S * sortL * 4);                                         // coordinate key matrix
+    b += al256(S * sortL * 4);                                         // its argsort
+    b += al256((size_t)2 * n_raw * 4);                                 // ranks
+    b += al256((size_t)2 * T * H * 4);                                 // row maxima
+    b += al256((size_t)T * H * n_raw * 8);                             // raw codes
+    b += al256((size_t)n_raw * 4) * 2;                                 // code keys + their argsort
+    const size_t a1 = hept_argsort_workspace_bytes((int)S, (int)sortL);
+    const size_t a2 = hept_argsort_workspace_bytes(1, n_raw);
+    b += al256(a1 > a2 ? a1 : a2);
+    return b;
+}
+
+// cloud_start / pad_start: device int32 arrays of n_clouds + 1 exclusive prefix sums of the raw / padded sizes.
+// Outputs: pad_seq (n_pad) i64, unpad (n_pad) u8, coords_pad (n_pad, C) f32, codes_pad (T, H, n_pad) i64.
+extern "C" int hept_prepare_input(const float* coords, int C, const int32_t* cloud_start, const int32_t* pad_start,
+                                  int n_clouds, int n_raw, int max_cloud, int n_pad, const float* regions, int T,
+                                  int H, int B, void* workspace, size_t workspace_bytes, int64_t* pad_seq,
+                                  unsigned char* unpad, float* coords_pad, int64_t* codes_pad, void* stream) {
+    if (!coords || !cloud_start || !pad_start || !regions || !workspace || !pad_seq || !unpad || !coords_pad ||
+        !codes_pad)
+        return HEPT_ERR_ARG;
+    if (C < 2 || n_clouds < 1 || n_raw < 1 || max_cloud < 1 || n_pad < n_raw || T < 1 || H < 1 || B < 1)
+        return HEPT_ERR_SHAPE;
+    if (workspace_bytes < hept_prepare_workspace_bytes(n_raw, n_clouds, max_cloud, T, H)) return HEPT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = 2 * n_clouds, L = max_cloud, rows = T * H;
+    char* ws = reinterpret_cast<char*>(workspace);
+    auto take = [&](size_t bytes) {
+        char* r = ws;
+        ws += al256(bytes);
+        return r;
+    };
+    float* keys = reinterpret_cast<float*>(take((size_t)S * L * 4));
+    int* pos = reinterpret_cast<int*>(take((size_t)S * L * 4));
+    int* rank = reinterpret_cast<int*>(take((size_t)2 * n_raw * 4));
+    int* row_max = reinterpret_cast<int*>(take((size_t)2 * rows * 4));
+    int64_t* codes_raw = reinterpret_cast<int64_t*>(take((size_t)rows * n_raw * 8));
+    float* ckeys = reinterpret_cast<float*>(take((size_t)n_raw * 4));
+    int* by_code = reinterpret_cast<int*>(take((size_t)n_raw * 4));
+    void* sort_ws = ws;
+
+    const dim3 gridL((L + PT - 1) / PT, S), gridN((n_raw + PT - 1) / PT, rows);
+    hipLaunchKernelGGL(coord_keys_kernel, gridL, dim3(PT), 0, st, coords, C, cloud_start, L, keys);
+    int rc = hept_segmented_argsort(keys, S, L, sort_ws, pos, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rank_scatter_kernel, gridL, dim3(PT), 0, st, pos, cloud_start, L, n_raw, rank);
+    if (hipMemsetAsync(row_max, 0, (size_t)2 * rows * 4, st) != hipSuccess) return HEPT_ERR_LAUNCH;
+    hipLaunchKernelGGL(codes_kernel<0>, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
+                       codes_raw);
+    hipLaunchKernelGGL(codes_kernel<1>, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
+                       codes_raw);
+    hipLaunchKernelGGL(codes_kernel<2>, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
+                       codes_raw);
+    hipLaunchKernelGGL(code_keys_kernel, dim3((n_raw + PT - 1) / PT), dim3(PT), 0, st, codes_raw, n_raw, ckeys);
+    rc = hept_segmented_argsort(ckeys, 1, n_raw, sort_ws, by_code, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pad_gather_kernel, dim3((n_pad + PT - 1) / PT, rows + 1), dim3(PT), 0, st, cloud_start, pad_start,
+                       n_clouds, n_raw, n_pad, B, by_code, coords, C, codes_raw, rows, pad_seq, unpad, coords_pad,
+                       codes_pad);
+    return hept_launch_status();
+}

@@ -390,16 +390,108 @@ __global__ __launch_bounds__(SORT_THREADS) void neighbour_rank_kernel(const unsi
 #undef WIN
 }
 
+// ---- generic front end (hept_segmented_argsort): S segments of L raw fp32 keys, +inf allowed as padding ----
+// finite min/max of one segment -> id map parameters
+__global__ __launch_bounds__(SORT_THREADS) void raw_range_kernel(const float* __restrict__ keys, int L,
+                                                                 SegParams* __restrict__ seg_params) {
+    __shared__ float red_s[2][SORT_WAVES];
+    const int tid = threadIdx.x, seg = blockIdx.x;
+    const float* k = keys + (size_t)seg * L;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = tid; i < L; i += SORT_THREADS) {
+        const float x = k[i];
+        if (x < INFINITY && x > -INFINITY) {
+            lo = fminf(lo, x);
+            hi = fmaxf(hi, x);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if ((tid & 63) == 0) { red_s[0][tid >> 6] = lo; red_s[1][tid >> 6] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        lo = fminf(fminf(red_s[0][0], red_s[0][1]), fminf(red_s[0][2], red_s[0][3]));
+        hi = fmaxf(fmaxf(red_s[1][0], red_s[1][1]), fmaxf(red_s[1][2], red_s[1][3]));
+        const float width = hi - lo;
+        float scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
+        if (!(scale < 3.0e38f)) scale = 0.f;
+        seg_params[seg] = SegParams{lo > hi ? 0.f : lo, scale};
+    }
+}
+
+// keys0 = ordered bits of the raw keys + per-chunk histogram of the low id byte
+__global__ __launch_bounds__(SORT_THREADS) void raw_keygen_hist_kernel(const float* __restrict__ keys, int L,
+                                                                       const SegParams* __restrict__ seg_params,
+                                                                       unsigned int* __restrict__ keys0,
+                                                                       unsigned int* __restrict__ hist, int n_chunks) {
+    __shared__ unsigned int h_s[RADIX];
+    const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
+    const SegParams rg = seg_params[seg];
+    h_s[tid] = 0;
+    __syncthreads();
+    const int base = chunk * SORT_CHUNK;
+#pragma unroll 4
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int n = base + i * SORT_THREADS + tid;
+        if (n < L) {
+            const unsigned int u = ordered_bits(keys[(size_t)seg * L + n]);
+            keys0[(size_t)seg * L + n] = u;
+            atomicAdd(&h_s[id16_of(u, rg.kmin, rg.scale) & 0xFF], 1u);
+        }
+    }
+    __syncthreads();
+    hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
+}
+
+// the passes shared by hept_sort_tables and hept_segmented_argsort: keys0 + hist(low byte) + params -> pos
+struct SortBuffers {
+    unsigned int* keys0;
+    unsigned long long *pa, *pb;
+    unsigned int* hist;
+    SegParams* params;
+};
+SortBuffers carve_sort(void* sort_ws, int segs, int N) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
+    char* ws = reinterpret_cast<char*>(sort_ws);
+    SortBuffers b;
+    b.keys0 = reinterpret_cast<unsigned int*>(ws);
+    ws += al((size_t)segs * N * 4);
+    b.pa = reinterpret_cast<unsigned long long*>(ws);
+    ws += al((size_t)segs * N * 8);
+    b.pb = reinterpret_cast<unsigned long long*>(ws);
+    ws += al((size_t)segs * N * 8);
+    b.hist = reinterpret_cast<unsigned int*>(ws);
+    ws += al((size_t)segs * n_chunks * RADIX * 4);
+    b.params = reinterpret_cast<SegParams*>(ws);
+    return b;
+}
+void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st) {
+    const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
+    const dim3 grid(n_chunks, segs), block(SORT_THREADS);
+    hipLaunchKernelGGL(scan_kernel, dim3(segs), dim3(RADIX), 0, st, b.hist, n_chunks);
+    hipLaunchKernelGGL(scatter_kernel<false>, grid, block, 0, st, b.keys0, nullptr, b.params, b.hist, N, n_chunks, b.pa);
+    hipLaunchKernelGGL(hist_hi_kernel, grid, block, 0, st, b.pa, b.params, N, b.hist, n_chunks);
+    hipLaunchKernelGGL(scan_kernel, dim3(segs), dim3(RADIX), 0, st, b.hist, n_chunks);
+    hipLaunchKernelGGL(scatter_kernel<true>, grid, block, 0, st, nullptr, b.pa, b.params, b.hist, N, n_chunks, b.pb);
+    const dim3 grid7((N + RANK_SPAN - 1) / RANK_SPAN, segs);
+    hipLaunchKernelGGL(neighbour_rank_kernel, grid7, block, 0, st, b.pb, b.params, N, pos);
+}
+
 }  // namespace
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) {
-    const size_t segs = (size_t)2 * Tl * H;
-    const size_t n_chunks = ((size_t)N + SORT_CHUNK - 1) / SORT_CHUNK;
+static size_t sort_bytes(size_t segs, size_t N) {
+    const size_t n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     return align256(segs * N * 4) + 2 * align256(segs * N * 8) + align256(segs * n_chunks * RADIX * 4) +
            align256(segs * sizeof(SegParams));
 }
+
+extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) { return sort_bytes((size_t)2 * Tl * H, N); }
 
 extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* codes, const float* minmax,
                                 int N, int H, int T, int t0, int Tl, void* sort_ws, int32_t* qpos, int32_t* kpos,
@@ -410,27 +502,24 @@ extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const in
     hipStream_t st = (hipStream_t)stream;
     const int segs = 2 * Tl * H;
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
-    char* ws = reinterpret_cast<char*>(sort_ws);
-    auto take = [&](size_t bytes) {
-        char* r = ws;
-        ws += align256(bytes);
-        return r;
-    };
-    unsigned int* keys0 = reinterpret_cast<unsigned int*>(take((size_t)segs * N * 4));
-    unsigned long long* pa = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
-    unsigned long long* pb = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
-    unsigned int* hist = reinterpret_cast<unsigned int*>(take((size_t)segs * n_chunks * RADIX * 4));
-    SegParams* params = reinterpret_cast<SegParams*>(take((size_t)segs * sizeof(SegParams)));
+    const SortBuffers b = carve_sort(sort_ws, segs, N);
+    hipLaunchKernelGGL(keygen_hist_kernel, dim3(n_chunks, segs), dim3(SORT_THREADS), 0, st, qproj, kproj, codes, minmax,
+                       N, H, t0, Tl, b.keys0, b.hist, b.params, n_chunks);
+    run_passes(b, segs, N, qpos, st);
+    return hept_launch_status();
+}
 
-    const dim3 grid(n_chunks, segs), block(SORT_THREADS);
-    hipLaunchKernelGGL(keygen_hist_kernel, grid, block, 0, st, qproj, kproj, codes, minmax, N, H, t0, Tl, keys0, hist,
-                       params, n_chunks);
-    hipLaunchKernelGGL(scan_kernel, dim3(segs), dim3(RADIX), 0, st, hist, n_chunks);
-    hipLaunchKernelGGL(scatter_kernel<false>, grid, block, 0, st, keys0, nullptr, params, hist, N, n_chunks, pa);
-    hipLaunchKernelGGL(hist_hi_kernel, grid, block, 0, st, pa, params, N, hist, n_chunks);
-    hipLaunchKernelGGL(scan_kernel, dim3(segs), dim3(RADIX), 0, st, hist, n_chunks);
-    hipLaunchKernelGGL(scatter_kernel<true>, grid, block, 0, st, nullptr, pa, params, hist, N, n_chunks, pb);
-    const dim3 grid7((N + RANK_SPAN - 1) / RANK_SPAN, segs);
-    hipLaunchKernelGGL(neighbour_rank_kernel, grid7, block, 0, st, pb, params, N, qpos);
+extern "C" size_t hept_argsort_workspace_bytes(int S, int L) { return sort_bytes((size_t)S, (size_t)L); }
+
+extern "C" int hept_segmented_argsort(const float* keys, int S, int L, void* ws, int32_t* pos, void* stream) {
+    if (!keys || !ws || !pos) return HEPT_ERR_ARG;
+    if (S < 1 || L < 1) return HEPT_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_chunks = (L + SORT_CHUNK - 1) / SORT_CHUNK;
+    const SortBuffers b = carve_sort(ws, S, L);
+    hipLaunchKernelGGL(raw_range_kernel, dim3(S), dim3(SORT_THREADS), 0, st, keys, L, b.params);
+    hipLaunchKernelGGL(raw_keygen_hist_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, b.params, b.keys0,
+                       b.hist, n_chunks);
+    run_passes(b, S, L, pos, st);
     return hept_launch_status();
 }

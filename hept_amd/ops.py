@@ -15,7 +15,7 @@ from ._lib import PREC_BF16, PREC_F32, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
-    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part",
+    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort",
 ]
 
 
@@ -106,6 +106,18 @@ def sort_tables(qproj, kproj, codes, minmax, t0: int = 0) -> Tuple[torch.Tensor,
                                     t0, tl, ws.data_ptr(), pos[0].data_ptr(), pos[1].data_ptr(), _stream(qproj)),
                "hept_sort_tables")
     return pos[0], pos[1]
+
+
+def segmented_argsort(keys: torch.Tensor) -> torch.Tensor:
+    """Stable ascending argsort of every row of a float32 (S, L) GPU tensor (+inf pads sort last); int32 (S, L)."""
+    lib = _lib.load()
+    keys = _f32c(keys, "keys")
+    s_, l_ = keys.shape
+    ws = torch.empty(int(lib.hept_argsort_workspace_bytes(s_, l_)), device=keys.device, dtype=torch.uint8)
+    pos = torch.empty(s_, l_, device=keys.device, dtype=torch.int32)
+    _lib.check(lib.hept_segmented_argsort(keys.data_ptr(), s_, l_, ws.data_ptr(), pos.data_ptr(), _stream(keys)),
+               "hept_segmented_argsort")
+    return pos
 
 
 def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int) -> torch.Tensor:

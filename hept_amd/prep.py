@@ -26,7 +26,7 @@ from typing import Dict, Tuple
 
 import torch
 
-__all__ = ["get_regions", "quantile_partition", "bit_shift", "pad_and_unpad", "prepare_input"]
+__all__ = ["get_regions", "quantile_partition", "bit_shift", "pad_and_unpad", "prepare_input", "prepare_input_hip"]
 
 
 def get_regions(num_regions, num_or_hashes, num_heads, num_and_hashes=2, generator=None) -> torch.Tensor:
@@ -104,12 +104,62 @@ def _rank_within_cloud(values: torch.Tensor, batch: torch.Tensor, raw_start: tor
     return rank - raw_start[batch]
 
 
+def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+    """``prepare_input`` on the GPU through the C ABI (``hept_prepare_input``, ``csrc/prepare.hip``).
+
+    Same contract as :func:`prepare_input`.  The only host round trip is the per-cloud size vector
+    (needed to size the outputs; the reference synchronises on it as well).
+    """
+    from . import _lib
+
+    lib = _lib.load()
+    regions = helper_params["regions"].to(device=coords.device, dtype=torch.float32).contiguous()
+    block_size, num_heads = int(helper_params["block_size"]), int(helper_params["num_heads"])
+    n_tables = regions.shape[0]
+    if regions.shape[2] != num_heads:
+        raise ValueError("regions must have shape (n_hashes, 2, num_heads)")
+    coords_c = coords.contiguous().float()
+    n_raw, c_dim = coords_c.shape
+    sizes = torch.bincount(batch).cpu()
+    n_clouds = sizes.numel()
+    if int(sizes.min()) < 1:
+        raise ValueError("every cloud id in [0, batch.max()] must own at least one point")
+    padded = ((sizes + block_size - 1) // block_size) * block_size
+    max_cloud, n_pad = int(sizes.max()), int(padded.sum())
+    # packed codes must stay below 2^24 (they are sorted as exact fp32 keys)
+    reg_hi = regions.amax(dim=(0, 2)).cpu()
+    bits = sum(int(torch.ceil(reg_hi[a]).item() + 1).bit_length() for a in (0, 1))
+    if (n_clouds << bits) >= (1 << 24):
+        raise ValueError("AND codes would exceed 2^24: too many clouds x regions for the fp32-keyed pad sort")
+    zero = torch.zeros(1, dtype=torch.int64)
+    cloud_start = torch.cat([zero, sizes.cumsum(0)]).to(torch.int32).to(coords.device)
+    pad_start = torch.cat([zero, padded.cumsum(0)]).to(torch.int32).to(coords.device)
+    dev = coords.device
+    ws = torch.empty(int(lib.hept_prepare_workspace_bytes(n_raw, n_clouds, max_cloud, n_tables, num_heads)),
+                     device=dev, dtype=torch.uint8)
+    pad_seq = torch.empty(n_pad, device=dev, dtype=torch.int64)
+    unpad = torch.empty(n_pad, device=dev, dtype=torch.uint8)
+    coords_pad = torch.empty(n_pad, c_dim, device=dev, dtype=torch.float32)
+    codes_pad = torch.empty(n_tables, num_heads, n_pad, device=dev, dtype=torch.int64)
+    _lib.check(lib.hept_prepare_input(coords_c.data_ptr(), c_dim, cloud_start.data_ptr(), pad_start.data_ptr(),
+                                      n_clouds, n_raw, max_cloud, n_pad, regions.data_ptr(), n_tables, num_heads,
+                                      block_size, ws.data_ptr(), ws.numel(), pad_seq.data_ptr(), unpad.data_ptr(),
+                                      coords_pad.data_ptr(), codes_pad.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream), "hept_prepare_input")
+    kwargs = {"combined_shifts": codes_pad, "coords": coords_pad.to(coords.dtype)}
+    return x[pad_seq], kwargs, unpad.bool()
+
+
 def prepare_input(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """Padded features, ``{"combined_shifts", "coords"}`` and the un-pad mask.
 
     Reference: ``example/transformer.py:35-63``.  ``helper_params`` carries
-    ``block_size``, ``num_heads`` and ``regions`` of shape (T, 2, H).
+    ``block_size``, ``num_heads`` and ``regions`` of shape (T, 2, H).  GPU tensors go through the HIP
+    kernels (:func:`prepare_input_hip`); CPU tensors through the torch implementation below, which is
+    also the host-side specification the HIP path is tested against.
     """
+    if coords.is_cuda:
+        return prepare_input_hip(x, coords, batch, helper_params)
     regions = helper_params["regions"]
     block_size, num_heads = helper_params["block_size"], helper_params["num_heads"]
     n_tables = regions.shape[0]

@@ -87,6 +87,12 @@ int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* code
                      const float* minmax, int N, int H, int T, int t0, int Tl,
                      void* sort_ws, int32_t* qpos, int32_t* kpos, void* stream);
 
+/* Generic form of the same sort: stable ascending argsort of S segments of L fp32 keys each
+ * (row-major (S, L); +inf is a legal padding key and sorts last).  pos (S, L) i32.  Used by
+ * hept_prepare_input; equals torch.sort(stable=True).indices. */
+size_t hept_argsort_workspace_bytes(int S, int L);
+int hept_segmented_argsort(const float* keys, int S, int L, void* ws, int32_t* pos, void* stream);
+
 /* replaces sort_to_buckets x3 (example/hept.py:70-72), qkv_res (:7-18), invert_permutation and
  * unsort_from_buckets x2 (:76-78): gather -> block-local RBF attention on MFMA -> scatter. */
 int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos,
@@ -120,6 +126,20 @@ int hept_forward_partial(const float* q, const float* k, const float* v, const f
                          int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
                          int precision, void* workspace, size_t workspace_bytes, float* acc,
                          void* stream);
+
+/* SURVEY.md §8 f-1 — replaces prepare_input (example/transformer.py:35-63: per-cloud argsorts of eta / phi,
+ * quantile_partition example/hept_utils.py:6-14, bit_shift x2 :10-13, pad_and_unpad :16-32 and the gathers by
+ * pad_seq :59-62) for one batch of clouds whose points are contiguous.
+ *   coords (n_raw, C) f32; cloud_start, pad_start: device i32 (n_clouds + 1) exclusive prefix sums of the raw /
+ *   block-padded cloud sizes; regions (T, 2, H) f32; max_cloud = largest raw cloud; n_pad = pad_start[n_clouds].
+ * Outputs: pad_seq (n_pad) i64, unpad (n_pad) u8 mask, coords_pad (n_pad, C) f32, codes_pad (T, H, n_pad) i64.
+ * Ties (equal coordinates / equal codes) are broken by ascending index; the reference's argsort leaves them
+ * undefined.  Requires every packed code < 2^24. */
+size_t hept_prepare_workspace_bytes(int n_raw, int n_clouds, int max_cloud, int T, int H);
+int hept_prepare_input(const float* coords, int C, const int32_t* cloud_start, const int32_t* pad_start,
+                       int n_clouds, int n_raw, int max_cloud, int n_pad, const float* regions, int T, int H,
+                       int B, void* workspace, size_t workspace_bytes, int64_t* pad_seq, unsigned char* unpad,
+                       float* coords_pad, int64_t* codes_pad, void* stream);
 
 /* Optional stage timing with HIP events recorded on the caller's stream inside hept_forward /
  * hept_forward_partial (nothing like it exists in the reference; used by bench.py for the roofline).

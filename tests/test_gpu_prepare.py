@@ -1,0 +1,77 @@
+"""prepare_input on the GPU (-m gpu): HIP kernels vs the host mirror (which make_golden.py
+pinned on the reference's own prepare_input) and vs the reference's stored padding."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from hept_amd import ops
+from hept_amd.prep import prepare_input, prepare_input_hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu_prepare(inp, block_size):
+    helper = {"block_size": block_size, "num_heads": cases.NUM_HEADS, "regions": inp["regions"]}
+    n_raw = inp["n_raw"]
+    return prepare_input(torch.arange(n_raw), inp["coords_raw"], inp["batch"], helper)
+
+
+@pytest.mark.parametrize("name", ["g2_example4k", "g3_ckpt6k", "g4_pileup", "g5_track60k", "g6_block100"])
+def test_hip_prepare_equals_host_mirror(name, gpu_device):
+    """Both use stable sorts, so everything is bit-exact: pad_seq, mask, AND codes, padded coords."""
+    inp, fx = cases.load_case(name)
+    b = cases.CASES[name]["block_size"]
+    pad_cpu, kw_cpu, mask_cpu = _cpu_prepare(inp, b)
+    helper = {"block_size": b, "num_heads": cases.NUM_HEADS, "regions": inp["regions"].to(gpu_device)}
+    x = torch.arange(inp["n_raw"], device=gpu_device)
+    pad_gpu, kw_gpu, mask_gpu = prepare_input_hip(x, inp["coords_raw"].to(gpu_device), inp["batch"].to(gpu_device), helper)
+    assert torch.equal(pad_gpu.cpu(), pad_cpu)
+    assert torch.equal(mask_gpu.cpu(), mask_cpu)
+    assert torch.equal(kw_gpu["combined_shifts"].cpu(), kw_cpu["combined_shifts"])
+    assert torch.equal(kw_gpu["coords"].cpu(), kw_cpu["coords"])
+    # against the reference: identical on real points up to the stored tie patches, same pad code multiset
+    assert torch.equal(pad_gpu.cpu()[mask_cpu], torch.arange(inp["n_raw"]))
+    ref_pad = torch.from_numpy(fx["pad_seq"].astype(np.int64))
+    raw_codes = kw_gpu["combined_shifts"].cpu()[0, 0][mask_cpu]
+    assert torch.equal(torch.sort(raw_codes[pad_gpu.cpu()[~mask_cpu]]).values,
+                       torch.sort(raw_codes[ref_pad[~mask_cpu]]).values)
+
+
+def test_segmented_argsort_is_stable_and_handles_padding(gpu_device):
+    g = torch.Generator().manual_seed(5)
+    keys = torch.randn(7, 5000, generator=g)
+    keys[:, ::3] = keys[:, 1::3][:, : keys[:, ::3].shape[1]]  # many exact ties
+    keys[2, 4000:] = float("inf")                               # padding sorts last, in index order
+    keys[5] = 1.25                                              # all equal: identity permutation
+    keys[6, :100] = -0.0
+    keys[6, 100:200] = 0.0                                      # -0.0 == +0.0
+    pos = ops.segmented_argsort(keys.to(gpu_device)).long().cpu()
+    want = torch.sort(keys, dim=-1, stable=True).indices
+    assert torch.equal(pos, want)
+    one = torch.randn(1, 77, generator=g)
+    assert torch.equal(ops.segmented_argsort(one.to(gpu_device)).long().cpu(), torch.sort(one, dim=-1, stable=True).indices)
+
+
+def test_prepare_then_attention_pipeline(gpu_device):
+    """prepare_input (HIP) -> HEPTAttention (HIP) end to end on GPU tensors only, against the CPU pipeline."""
+    import hept_oracle as ho
+    inp, _ = cases.load_case("g4_pileup")
+    b = 256
+    dev = gpu_device
+    helper = {"block_size": b, "num_heads": 8, "regions": inp["regions"].to(dev)}
+    g = torch.Generator().manual_seed(1)
+    n_raw = inp["n_raw"]
+    feats = torch.randn(n_raw, 192 * 3, generator=g)
+    x_pad, kw, mask = prepare_input(feats.to(dev), inp["coords_raw"].to(dev), inp["batch"].to(dev), helper)
+    q, k, v = x_pad[:, :192].contiguous(), x_pad[:, 192:384].contiguous(), x_pad[:, 384:].contiguous()
+    out = ops.forward(q, k, v, kw["coords"], kw["combined_shifts"], inp["w_rpe_weight"].to(dev), inp["alpha"].to(dev),
+                      inp["out_weight"].to(dev), inp["out_bias"].to(dev), block_size=b, w_per_dist=10)
+    pad_cpu, kw_cpu, _ = _cpu_prepare(inp, b)
+    fc = feats[pad_cpu]
+    ref = ho.forward(fc[:, :192], fc[:, 192:384], fc[:, 384:], kw_cpu["coords"], kw_cpu["combined_shifts"],
+                     inp["w_rpe_weight"], inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=b, w_per_dist=10,
+                     keep=False)["out"]
+    err = (out.cpu() - ref).abs()
+    assert ((err <= 1e-5 + 1e-4 * ref.abs()).all(-1)).float().mean() >= 0.995
+    assert out[mask].shape[0] == n_raw
