@@ -42,6 +42,8 @@ SIGNATURES = {
     "hept_combine_out": (c_int, [_P] + [c_int] * 7 + [_P] * 4),
     "hept_forward": (c_int, [_P] * 9 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
+    "hept_block_attn_bwd": (c_int, [_P] * 5 + [c_int] * 5 + [_P] * 3),
+    "hept_bwd_reduce": (c_int, [_P, _P] + [c_int] * 5 + [_P] * 5),
     "hept_prepare_workspace_bytes": (c_size_t, [c_int] * 5),
     "hept_prepare_input": (c_int, [_P, c_int, _P, _P] + [c_int] * 4 + [_P] + [c_int] * 3 + [_P, c_size_t] + [_P] * 5),
     "hept_profile_enable": (c_int, [c_int, c_int]),

@@ -1,0 +1,52 @@
+"""Training path: autograd around the HIP kernels.
+
+The reference trains through ``HEPTAttention.forward`` with plain autograd (``example/trainer.py:11-22``):
+gradients reach ``query, key, value``, ``w_rpe.weight`` and ``out_linear``; hashing and sorting carry none
+(``lsh_mapping`` is ``@torch.no_grad``, ``argsort`` yields integers; ``e2lsh.alpha`` is frozen).  Here the
+non-trivial part — everything from the augmented rows to the table-summed partial rows — is one
+``torch.autograd.Function`` whose forward and backward are HIP kernels (f32 tiles); the tiny
+differentiable parameter math around it (``sqrt_w`` from ``w_rpe.weight``, the final divide and
+``out_linear``) stays in torch so that its gradients come from autograd itself.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+__all__ = ["HeptPartialSums", "rpe_scale_torch"]
+
+
+def rpe_scale_torch(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dist: int) -> torch.Tensor:
+    """Differentiable ``sqrt(2 * sum_k exp(min(sum_d w, 50)))`` with column 0 duplicated; (H, C).
+    Reference ``example/hept.py:48-54`` (view) and ``:22-23,25``."""
+    w4 = w_rpe_weight.reshape(n_heads, head_dim, -1, w_per_dist)
+    qw = w4.sum(dim=1).clamp(max=50).exp().sum(dim=-1)
+    return torch.sqrt(2 * torch.cat([qw[:, :1], qw], dim=-1))
+
+
+class HeptPartialSums(torch.autograd.Function):
+    """(q, k, v, coords, sqrt_w) -> acc (N, H, 32) = sum over tables of [numer | denom | 0]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, coords, sqrt_w, alpha, codes, block_size):
+        n, hd = q.shape
+        h = alpha.shape[0]
+        d = hd // h
+        ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, "fp32")
+        qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"])
+        part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, block_size)
+        acc = ops.reduce_tables(part, d)
+        ctx.save_for_backward(ph["qhat"], ph["kvhat"], qpos, kpos, coords, sqrt_w)
+        ctx.dims = (d, coords.shape[1], block_size)
+        return acc
+
+    @staticmethod
+    def backward(ctx, gacc):
+        qhat, kvhat, qpos, kpos, coords, sqrt_w = ctx.saved_tensors
+        d, c, block_size = ctx.dims
+        dq, dk, dv, dcs = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size)
+        # scaled coordinates s[n,h,c] = sqrt_w[h,c] * coords[n,c]
+        dsw = torch.einsum("nhc,nc->hc", dcs, coords) if ctx.needs_input_grad[4] else None
+        dcoords = torch.einsum("nhc,hc->nc", dcs, sqrt_w) if ctx.needs_input_grad[3] else None
+        return dq, dk, dv, dcoords, dsw, None, None, None

@@ -1,0 +1,281 @@
+// block_attn_bwd: backward of the block-local RBF attention, fp32 tiles, fp32 MFMA.
+//
+// The reference has no custom backward: it trains through example/hept.py:55-80 with plain autograd
+// (example/trainer.py:11-22).  Hashing and sorting carry no gradient (lsh_mapping is @torch.no_grad,
+// example/hept_utils.py:64; argsort yields integers), so given the forward's permutations the
+// differentiable part is, per (table, head, block):
+//     S_ij = q^_i.k^_j - |q^_i|^2/2 - |k^_j|^2/2,   P = exp(min(S, 0)),   numer = P.V,   den = P.1
+// With G_i = [d numer_i | d den_i] (the upstream gradient row of query i; the same for every table,
+// since the tables are summed before the division) and V carrying its 1.0 column:
+//     dP = G.V^T                       (the 1.0 column of V adds d den_i to every dP_ij)
+//     dS = dP o P o [S <= 0]           (clamp(max=0) passes the gradient where S <= 0, like torch)
+//     dV_j  = sum_i P_ij dnumer_i
+//     dq^_i = sum_j dS_ij (k^_j - q^_i),     dk^_j = sum_i dS_ij (q^_i - k^_j)
+// The scores are recomputed (never stored).  Same MFMA scheme as the forward: the accumulator of
+// (rows . cols^T) already has the A-operand layout of the next product, so nothing bounces through LDS.
+//   phase Q: wave owns 32 queries, walks the key tiles:   X = K^.Q^T, Y = V.G^T, dS = Y o P o M,  Z += dS^T K^
+//   phase K: wave owns 32 keys,    walks the query tiles: X = Q^.K^T, Y = G.V^T, dS likewise,     ZK += dS^T Q^, ZV += P^T G
+// The row sums (sum_j dS_ij, sum_i dS_ij) ride in the products through a 1.0 placed in the unused column 30
+// of the staged K^ / Q^ tiles.  Outputs are per-table partial rows scattered back to point order:
+//   dq_part (T, N, H, 32): d q^ (E columns)          dkv_part (T, N, H, 64): d k^ (E columns) | d v (D columns)
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int sw_byte(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ float lds_elem(const char* tile, int row, int col) {
+    return *reinterpret_cast<const float*>(tile + sw_byte(row, col >> 2) + ((col & 3) << 2));
+}
+// 16 consecutive columns [16*hh, 16*hh+16) of a staged row
+__device__ __forceinline__ void lds_half_row(const char* tile, int row, int hh, float (&x)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + sw_byte(row, 4 * hh + c));
+        x[4 * c] = v[0]; x[4 * c + 1] = v[1]; x[4 * c + 2] = v[2]; x[4 * c + 3] = v[3];
+    }
+}
+
+template <int NKT, bool FULL>
+__global__ __launch_bounds__(64 * NKT) void block_attn_bwd_kernel(
+    const float* __restrict__ qhat, const float* __restrict__ kvhat, const int* __restrict__ qpos,
+    const int* __restrict__ kpos, const float* __restrict__ gacc, float* __restrict__ dq_part,
+    float* __restrict__ dkv_part, int N, int H, int D, int B, int nb) {
+    constexpr int NT = 64 * NKT, ROWS = 32 * NKT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* q_s = smem;                      // [ROWS][32 f32] swizzled, column 30 = 1.0, column 31 = 0
+    char* k_s = smem + ROWS * 128;         // same for the keys
+    char* v_s = smem + 2 * ROWS * 128;     // [v | 1.0 at column D | 0]
+    char* g_s = smem + 3 * ROWS * 128;     // upstream rows [d numer | d den | 0]
+    float* qn_s = reinterpret_cast<float*>(smem + 4 * ROWS * 128);
+    float* kn_s = qn_s + ROWS;
+    int* qidx_s = reinterpret_cast<int*>(kn_s + ROWS);
+    int* kidx_s = qidx_s + ROWS;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
+    const int bid = blockIdx.x;
+    const int h = bid % H, rest = bid / H, b = rest % nb, t = rest / nb;
+    const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
+    const int* __restrict__ qp = qpos + seg;
+    const int* __restrict__ kp = kpos + seg;
+
+    // ---- stage the four tiles (gathered rows, 16 B per lane), norms and indices
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // ROWS * 8 chunks of q^ and of G
+        const int ci = it * NT + tid, row = ci >> 3, c = ci & 7;
+        const bool ok = FULL || row < B;
+        const int src = ok ? qp[row] : 0;
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            qv = *reinterpret_cast<const f32x4*>(qhat + ((size_t)h * N + src) * 32 + c * 4);
+            gv = *reinterpret_cast<const f32x4*>(gacc + ((size_t)src * H + h) * 32 + c * 4);
+        }
+        if (c == 7) {
+            qn_s[row] = qv[3];
+            qidx_s[row] = ok ? src : -1;
+            qv[3] = 0.f;
+            qv[2] = ok ? 1.f : 0.f;  // column 30: row sums of dS ride in the MFMA
+        }
+        *reinterpret_cast<f32x4*>(q_s + sw_byte(row, c)) = qv;
+        *reinterpret_cast<f32x4*>(g_s + sw_byte(row, c)) = gv;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {  // ROWS * 16 chunks of the kvhat rows
+        const int ci = it * NT + tid, row = ci >> 4, c = ci & 15;
+        const bool ok = FULL || row < B;
+        const int src = ok ? kp[row] : 0;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (ok) x = *reinterpret_cast<const f32x4*>(kvhat + ((size_t)h * N + src) * 64 + c * 4);
+        if (c == 7) {
+            kn_s[row] = x[3];
+            kidx_s[row] = ok ? src : -1;
+            x[3] = 0.f;
+            x[2] = ok ? 1.f : 0.f;
+        }
+        if (c < 8)
+            *reinterpret_cast<f32x4*>(k_s + sw_byte(row, c)) = x;
+        else
+            *reinterpret_cast<f32x4*>(v_s + sw_byte(row, c - 8)) = x;
+    }
+    __syncthreads();
+
+    const int own = w * 32 + li;  // the query (phase Q) / key (phase K) of this lane
+    const bool own_ok = FULL || own < B;
+
+    // =========================== phase Q: d q^ ===========================
+    {
+        float qreg[16], greg[16];
+        lds_half_row(q_s, own, hh, qreg);
+        lds_half_row(g_s, own, hh, greg);
+        if (hh == 1) qreg[14] = 0.f;  // the 1.0 of column 30 is not a feature
+        const float qn = qn_s[own];
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (!FULL && kt * 32 >= B) break;
+            f32x16 x, y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x[r] = qn + kn_s[kt * 32 + hept_acc_row(r, hh)];
+                y[r] = 0.f;
+            }
+            float kf[16], vf[16];
+            lds_half_row(k_s, kt * 32 + li, hh, kf);
+            lds_half_row(v_s, kt * 32 + li, hh, vf);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qreg[s], x, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) y = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], greg[s], y, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + hept_acc_row(r, hh);
+                float ds = x[r] <= 0.f ? fminf(__expf(x[r]), 1.f) * y[r] : 0.f;
+                if (!FULL && (key >= B || !own_ok)) ds = 0.f;
+                z = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, lds_elem(k_s, key, li), z, 0, 0, 0);
+            }
+        }
+        // d q^_i = sum_j dS_ij k^_j - (sum_j dS_ij) q^_i ;  lane = column, registers = queries
+        float* __restrict__ dst = dq_part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q2 = w * 32 + hept_acc_row(r, hh);
+            const float rs = __shfl(z[r], 30 + 32 * hh);
+            if (FULL || q2 < B) dst[(size_t)qidx_s[q2] * H * 32] = z[r] - rs * lds_elem(q_s, q2, li);
+        }
+    }
+
+    // =========================== phase K: d k^, d v ===========================
+    {
+        float kreg[16], vreg[16];
+        lds_half_row(k_s, own, hh, kreg);
+        lds_half_row(v_s, own, hh, vreg);
+        if (hh == 1) kreg[14] = 0.f;
+        const float kn = kn_s[own];
+        f32x16 zk, zv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { zk[r] = 0.f; zv[r] = 0.f; }
+#pragma unroll
+        for (int qt = 0; qt < NKT; ++qt) {
+            if (!FULL && qt * 32 >= B) break;
+            f32x16 x, y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x[r] = qn_s[qt * 32 + hept_acc_row(r, hh)] + kn;
+                y[r] = 0.f;
+            }
+            float qf[16], gf[16];
+            lds_half_row(q_s, qt * 32 + li, hh, qf);
+            lds_half_row(g_s, qt * 32 + li, hh, gf);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) x = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s], kreg[s], x, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) y = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[s], vreg[s], y, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qry = qt * 32 + hept_acc_row(r, hh);
+                float p = fminf(__expf(x[r]), 1.f);
+                if (!FULL && (qry >= B || !own_ok)) p = 0.f;
+                const float ds = x[r] <= 0.f ? p * y[r] : 0.f;
+                zk = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, lds_elem(q_s, qry, li), zk, 0, 0, 0);
+                zv = __builtin_amdgcn_mfma_f32_32x32x2f32(p, lds_elem(g_s, qry, li), zv, 0, 0, 0);
+            }
+        }
+        float* __restrict__ dst = dkv_part + (size_t)t * N * H * 64 + (size_t)h * 64 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k2 = w * 32 + hept_acc_row(r, hh);
+            const float rs = __shfl(zk[r], 30 + 32 * hh);
+            if (FULL || k2 < B) {
+                float* row = dst + (size_t)kidx_s[k2] * H * 64;
+                row[0] = zk[r] - rs * lds_elem(k_s, k2, li);
+                row[32] = li < D ? zv[r] : 0.f;
+            }
+        }
+    }
+}
+
+// sum the per-table partial rows and undo the augmentation:
+//   dq,dk,dv (N, H*D);  dcs (N, H, C) = gradient of the scaled coordinates sqrt_w[h,c]*coords[n,c] (q^ and k^ share them)
+__global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict__ dq_part,
+                                                         const float* __restrict__ dkv_part, int Tl, int N, int H,
+                                                         int D, int C, float* __restrict__ dq, float* __restrict__ dk,
+                                                         float* __restrict__ dv, float* __restrict__ dcs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, h, col)
+    const size_t total = (size_t)N * H * 32;
+    if (i >= total) return;
+    const int col = (int)(i & 31);
+    const size_t nh = i >> 5;  // n * H + h
+    float sq = 0.f, sk = 0.f, sv = 0.f;
+    for (int t = 0; t < Tl; ++t) {
+        sq += dq_part[(size_t)t * total + i];
+        sk += dkv_part[((size_t)t * N * H + nh) * 64 + col];
+        sv += dkv_part[((size_t)t * N * H + nh) * 64 + 32 + col];
+    }
+    if (col < D) {
+        dq[nh * D + col] = sq;
+        dk[nh * D + col] = sk;
+        dv[nh * D + col] = sv;
+    } else if (col < D + C) {
+        dcs[nh * C + (col - D)] = sq + sk;
+    }
+}
+
+template <bool FULL>
+int launch_bwd(int nkt, dim3 grid, hipStream_t st, const float* qhat, const float* kvhat, const int* qpos,
+               const int* kpos, const float* gacc, float* dq_part, float* dkv_part, int N, int H, int D, int B,
+               int nb) {
+#define HEPT_BWD_CASE(K)                                                                                         \
+    case K: {                                                                                                    \
+        constexpr size_t lds = (size_t)4 * 32 * K * 128 + 32 * K * 16;                                           \
+        static bool raised = false;                                                                              \
+        if (lds > 65536 && !raised) {                                                                            \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_bwd_kernel<K, FULL>),              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)         \
+                return HEPT_ERR_LAUNCH;                                                                          \
+            raised = true;                                                                                       \
+        }                                                                                                        \
+        hipLaunchKernelGGL((block_attn_bwd_kernel<K, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
+                           kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);                                       \
+        break;                                                                                                   \
+    }
+    switch (nkt) {
+        HEPT_BWD_CASE(1)
+        HEPT_BWD_CASE(2)
+        HEPT_BWD_CASE(3)
+        HEPT_BWD_CASE(4)
+        HEPT_BWD_CASE(5)
+        HEPT_BWD_CASE(6)
+        HEPT_BWD_CASE(7)
+        HEPT_BWD_CASE(8)
+        default:
+            return HEPT_ERR_SHAPE;
+    }
+#undef HEPT_BWD_CASE
+    return hept_launch_status();
+}
+
+}  // namespace
+
+extern "C" int hept_block_attn_bwd(const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
+                                   const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part,
+                                   float* dkv_part, void* stream) {
+    if (!qhat || !kvhat || !qpos || !kpos || !gacc || !dq_part || !dkv_part) return HEPT_ERR_ARG;
+    if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
+        return HEPT_ERR_SHAPE;
+    const int nb = N / B, nkt = (B + 31) / 32;
+    const dim3 grid((unsigned)((size_t)Tl * nb * H));
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 32 * nkt) return launch_bwd<true>(nkt, grid, st, qhat, kvhat, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);
+    return launch_bwd<false>(nkt, grid, st, qhat, kvhat, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);
+}
+
+extern "C" int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
+                               float* dq, float* dk, float* dv, float* dcs, void* stream) {
+    if (!dq_part || !dkv_part || !dq || !dk || !dv || !dcs) return HEPT_ERR_ARG;
+    if (Tl < 1 || N < 1 || H < 1 || D < 1 || C < 1 || D + C > 30) return HEPT_ERR_SHAPE;
+    const size_t total = (size_t)N * H * 32;
+    hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dq_part, dkv_part, Tl, N, H, D, C, dq, dk, dv, dcs);
+    return hept_launch_status();
+}

@@ -13,8 +13,9 @@ Two keyword-only extensions: ``precision`` ("fp32" reference numerics /
 "bf16" MFMA tiles / "mixed16" = fp16 q̂,k̂ tiles with bf16 weights and values) and ``process_group`` (shard the ``n_hashes`` tables over
 the ranks of a ``torch.distributed`` group).
 
-Forward only (inference metric); the module runs under ``torch.no_grad()``
-semantics and raises if gradients are requested.  There is no CPU path.
+Inference (``torch.no_grad()``) runs the whole operator in one C call.  When gradients are
+required the module routes through ``hept_amd.autograd`` (HIP forward + HIP backward of the
+block attention, f32 tiles).  There is no CPU path.
 """
 from __future__ import annotations
 
@@ -72,15 +73,12 @@ class HEPTAttention(nn.Module):
         return ws
 
     def forward(self, query, key, value, **kwargs):
+        if not query.is_cuda:
+            raise RuntimeError("hept_amd.HEPTAttention needs GPU tensors: there is no CPU fallback")
         if torch.is_grad_enabled() and any(
             t.requires_grad for t in (query, key, value, kwargs["w_rpe"].weight, self.out_linear.weight)
         ):
-            raise RuntimeError(
-                "hept_amd.HEPTAttention implements the forward (inference) path only; "
-                "call it under torch.no_grad() (backward is SURVEY.md §8 f-2, not built yet)"
-            )
-        if not query.is_cuda:
-            raise RuntimeError("hept_amd.HEPTAttention needs GPU tensors: there is no CPU fallback")
+            return self._forward_train(query, key, value, **kwargs)
         coords = kwargs["coords"]
         codes = kwargs["combined_shifts"]
         w_rpe_weight = kwargs["w_rpe"].weight
@@ -106,4 +104,25 @@ class HEPTAttention(nn.Module):
                 out = self.sharding.finish(
                     acc, lambda part, n0, cnt: ops.combine_out(part, d, self.out_linear.weight,
                                                                self.out_linear.bias, n0, cnt))
+        return out.to(query.dtype)
+
+    def _forward_train(self, query, key, value, **kwargs):
+        """Differentiable path: HIP forward/backward of the block attention inside autograd (f32 tiles)."""
+        from .autograd import HeptPartialSums, rpe_scale_torch
+
+        if self.precision != "fp32":
+            raise RuntimeError("training needs precision='fp32' (the backward kernels use f32 tiles)")
+        if self.sharding is not None:
+            raise RuntimeError("table sharding is an inference feature; train with process_group=None")
+        n = query.shape[0]
+        if n % self.block_size != 0:
+            raise ValueError(f"number of points {n} is not a multiple of block_size {self.block_size}")
+        h, d = self.num_heads, self.dim_per_head
+        coords = kwargs["coords"].float()
+        sqrt_w = rpe_scale_torch(kwargs["w_rpe"].weight.float(), h, d, self.num_w_per_dist)
+        acc = HeptPartialSums.apply(query.reshape(n, h * d).float(), key.reshape(n, h * d).float(),
+                                    value.reshape(n, h * d).float(), coords, sqrt_w, self.e2lsh.alpha.detach(),
+                                    kwargs["combined_shifts"], self.block_size)
+        per_head = acc[..., :d] / acc[..., d:d + 1]                      # example/hept.py:79
+        out = self.out_linear(per_head.reshape(n, h * d))                # example/hept.py:80
         return out.to(query.dtype)

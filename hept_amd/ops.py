@@ -15,7 +15,7 @@ from ._lib import PREC_BF16, PREC_F32, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
-    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort",
+    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort", "block_attn_bwd",
 ]
 
 
@@ -177,6 +177,30 @@ def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int
                                     b.data_ptr() if b is not None else None, out.data_ptr(), _stream(part)),
                "hept_combine_out")
     return out
+
+
+def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int, block_size: int):
+    """Backward of block_attn + reduce_tables for f32 tiles: gradient rows gacc (N,H,32) -> dq, dk, dv (N, H*D)
+    and dcs (N, H, C), the gradient of the scaled coordinates shared by q^ and k^."""
+    lib = _lib.load()
+    if qhat.dtype != torch.float32:
+        raise TypeError("the backward pass needs f32 tiles (precision='fp32')")
+    h, n, _ = qhat.shape
+    tl = qpos.shape[0]
+    gacc = _f32c(gacc, "grad of the partial sums")
+    dev = qhat.device
+    dq_part = torch.empty(tl, n, h, 32, device=dev, dtype=torch.float32)
+    dkv_part = torch.empty(tl, n, h, 64, device=dev, dtype=torch.float32)
+    st = _stream(qhat)
+    _lib.check(lib.hept_block_attn_bwd(qhat.data_ptr(), kvhat.data_ptr(), qpos.data_ptr(), kpos.data_ptr(),
+                                       gacc.data_ptr(), n, h, head_dim, tl, block_size, dq_part.data_ptr(),
+                                       dkv_part.data_ptr(), st), "hept_block_attn_bwd")
+    dq = torch.empty(n, h * head_dim, device=dev, dtype=torch.float32)
+    dk, dv = torch.empty_like(dq), torch.empty_like(dq)
+    dcs = torch.empty(n, h, coords_dim, device=dev, dtype=torch.float32)
+    _lib.check(lib.hept_bwd_reduce(dq_part.data_ptr(), dkv_part.data_ptr(), tl, n, h, head_dim, coords_dim,
+                                   dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dcs.data_ptr(), st), "hept_bwd_reduce")
+    return dq, dk, dv, dcs
 
 
 def _prepare(q, k, v, coords, codes, w_rpe_weight, alpha, block_size, w_per_dist):

@@ -127,6 +127,18 @@ int hept_forward_partial(const float* q, const float* k, const float* v, const f
                          int precision, void* workspace, size_t workspace_bytes, float* acc,
                          void* stream);
 
+/* SURVEY.md §8 f-2 — backward of the block attention (the reference trains through example/hept.py:55-80 with
+ * plain autograd; there is no custom backward to mirror).  f32 tiles only.  gacc (N, H, 32) f32 is the
+ * gradient of the table-summed partial rows [d numer | d den | 0]; qhat/kvhat/qpos/kpos are the forward's.
+ * dq_part (Tl, N, H, 32) receives d q^ rows, dkv_part (Tl, N, H, 64) receives [d k^ | d v] rows (point order,
+ * one row per table).  hept_bwd_reduce sums the tables and undoes the augmentation: dq, dk, dv (N, H*D) and
+ * dcs (N, H, C) = gradient of the scaled coordinates sqrt_w[h,c] * coords[n,c]. */
+int hept_block_attn_bwd(const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
+                        const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part,
+                        float* dkv_part, void* stream);
+int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
+                    float* dq, float* dk, float* dv, float* dcs, void* stream);
+
 /* SURVEY.md §8 f-1 — replaces prepare_input (example/transformer.py:35-63: per-cloud argsorts of eta / phi,
  * quantile_partition example/hept_utils.py:6-14, bit_shift x2 :10-13, pad_and_unpad :16-32 and the gathers by
  * pad_seq :59-62) for one batch of clouds whose points are contiguous.

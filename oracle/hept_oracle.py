@@ -225,7 +225,6 @@ def out_projection(per_head: torch.Tensor, weight: torch.Tensor, bias: Optional[
 # ---------------------------------------------------------------------------
 # whole operator
 # ---------------------------------------------------------------------------
-@torch.no_grad()
 def forward_partials(
     q: torch.Tensor,
     k: torch.Tensor,
@@ -243,14 +242,25 @@ def forward_partials(
     tile_dtype: torch.dtype = torch.float32,
     qk_dtype: Optional[torch.dtype] = None,
     keep: bool = True,
+    grad: bool = False,
 ) -> Dict[str, torch.Tensor]:
     """Everything up to the per-table partials in original point order.
+
+    ``grad=True`` leaves autograd on (the reference trains through these very ops with plain
+    autograd, ``example/trainer.py:11-22``; hashing stays ``no_grad`` as in
+    ``example/hept_utils.py:64``), so ``out.backward()`` yields the reference's gradients.
 
     ``alpha``/``codes`` may hold a *subset* of the tables (table sharding,
     SURVEY.md §8e): every stage is independent per table until
     ``combine_tables``.  ``q_positions``/``k_positions`` inject permutations
     (skipping ``sort_keys``).
     """
+    if not grad:
+        with torch.no_grad():
+            return forward_partials(q, k, v, coords, codes, w_rpe_weight, alpha, block_size=block_size,
+                                    w_per_dist=w_per_dist, stable_sort=stable_sort, q_positions=q_positions,
+                                    k_positions=k_positions, tile_dtype=tile_dtype, qk_dtype=qk_dtype, keep=keep,
+                                    grad=True)
     n_heads, hash_dim, _ = alpha.shape
     head_dim = q.shape[1] // n_heads
     if q.shape[0] % block_size != 0:
@@ -260,12 +270,13 @@ def forward_partials(
     assert q_hat.shape[-1] == hash_dim
     v_h = v.reshape(v.shape[0], n_heads, head_dim).permute(1, 0, 2)
 
-    q_hashed = e2lsh_project(q_hat, alpha)
-    k_hashed = e2lsh_project(k_hat, alpha)
-    span = hash_range(q_hashed, k_hashed)
-    q_keys, k_keys = shifted_keys(q_hashed, k_hashed, codes, span)
-    q_pos = sort_keys(q_keys, stable_sort) if q_positions is None else q_positions
-    k_pos = sort_keys(k_keys, stable_sort) if k_positions is None else k_positions
+    with torch.no_grad():  # lsh_mapping is @torch.no_grad in the reference; argsort yields integers
+        q_hashed = e2lsh_project(q_hat, alpha)
+        k_hashed = e2lsh_project(k_hat, alpha)
+        span = hash_range(q_hashed, k_hashed)
+        q_keys, k_keys = shifted_keys(q_hashed, k_hashed, codes, span)
+        q_pos = sort_keys(q_keys, stable_sort) if q_positions is None else q_positions
+        k_pos = sort_keys(k_keys, stable_sort) if k_positions is None else k_positions
 
     qk_dt = tile_dtype if qk_dtype is None else qk_dtype  # "mixed16": fp16 q̂/k̂ tiles, everything else bf16
     sq = gather_blocks(_round_tile(q_hat, qk_dt), q_pos, block_size)
@@ -291,7 +302,6 @@ def forward_partials(
     return res
 
 
-@torch.no_grad()
 def forward(
     q: torch.Tensor,
     k: torch.Tensor,
@@ -311,13 +321,21 @@ def forward(
     tile_dtype: torch.dtype = torch.float32,
     qk_dtype: Optional[torch.dtype] = None,
     keep: bool = True,
+    grad: bool = False,
 ) -> Dict[str, torch.Tensor]:
     """Full operator, ``example/hept.py:43-81``; returns a dict with ``out`` (N,D) and intermediates."""
     res = forward_partials(
         q, k, v, coords, codes, w_rpe_weight, alpha,
         block_size=block_size, w_per_dist=w_per_dist, stable_sort=stable_sort,
         q_positions=q_positions, k_positions=k_positions, tile_dtype=tile_dtype, qk_dtype=qk_dtype, keep=keep,
+        grad=grad,
     )
+    if not grad:
+        with torch.no_grad():
+            per_head = combine_tables(res["numer"], res["denom"])
+            res["per_head"] = per_head
+            res["out"] = out_projection(per_head, out_weight, out_bias)
+        return res
     per_head = combine_tables(res["numer"], res["denom"])
     res["per_head"] = per_head
     res["out"] = out_projection(per_head, out_weight, out_bias)

@@ -92,6 +92,26 @@ def reference_forward(hept, hept_utils, inp, block_size, n_hashes):
     )
 
 
+def reference_gradients(hept, inp, block_size, n_hashes, seed=11):
+    """Gradients of the REAL reference module (plain autograd) for a seeded upstream gradient."""
+    H, D, K = cases.NUM_HEADS, cases.H_DIM, cases.W_PER_DIST
+    C = inp["coords"].shape[1]
+    attn = hept.HEPTAttention(D + C, h_dim=D, num_heads=H, block_size=block_size, n_hashes=n_hashes, num_w_per_dist=K)
+    with torch.no_grad():
+        attn.e2lsh.alpha.copy_(inp["alpha"])
+        attn.out_linear.weight.copy_(inp["out_weight"])
+        attn.out_linear.bias.copy_(inp["out_bias"])
+    w_rpe = torch.nn.Linear(K * (C - 1), H * D)
+    with torch.no_grad():
+        w_rpe.weight.copy_(inp["w_rpe_weight"])
+    q, k, v = (inp[x].clone().requires_grad_(True) for x in ("q", "k", "v"))
+    out = attn(q, k, v, pe=inp["coords"], w_rpe=w_rpe, coords=inp["coords"], combined_shifts=inp["combined_shifts"])
+    g_out = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed))
+    out.backward(g_out)
+    return dict(dq=q.grad, dk=k.grad, dv=v.grad, dw_rpe=w_rpe.weight.grad, dout_w=attn.out_linear.weight.grad,
+                dout_b=attn.out_linear.bias.grad)
+
+
 def key_monotonicity_digest(keys, pos):
     """Checks the reference permutation sorts its keys; returns per-(t,h) sums of sorted keys (float64)."""
     sk = torch.gather(keys, -1, pos)
@@ -171,6 +191,15 @@ def main():
             fx["k_hashed_rows"] = ref["k_hashed"][..., rows].numpy()
             fx["denom_rows"] = ref["denom"][..., rows].numpy()
             fx["per_head_rows"] = ref["per_head"][:, rows].numpy()
+            # reference gradients (same permutations: the module is deterministic) for the upstream gradient
+            # randn(seed 11) used by tests/test_gpu_backward.py
+            gr = reference_gradients(hept, inp, B, T)
+            fx["ref_grad_rows"] = rows.numpy().astype(np.int32)
+            fx["ref_dq_rows"] = gr["dq"][rows].numpy()
+            fx["ref_dk_rows"] = gr["dk"][rows].numpy()
+            fx["ref_dv_rows"] = gr["dv"][rows].numpy()
+            fx["ref_dw_rpe"] = gr["dw_rpe"].numpy()
+            fx["ref_dout_w"] = gr["dout_w"].numpy()
             if n <= 1024:
                 fx["per_head"] = ref["per_head"].numpy()
                 fx["q_hashed"] = ref["q_hashed"].numpy()

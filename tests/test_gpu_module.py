@@ -54,8 +54,8 @@ def test_module_bf16_and_errors(gpu_device):
     ref = torch.from_numpy(fx["out"])
     err = (out.cpu() - ref).abs().amax(-1)
     assert (err <= 2.5e-2 * (ref.abs().amax(-1) + 1e-3)).float().mean() >= 0.97
-    with pytest.raises(RuntimeError, match="forward .inference. path only"):
-        m(g["q"].requires_grad_(True), g["k"], g["v"], **kw)
+    with pytest.raises(RuntimeError, match="training needs precision='fp32'"):
+        m(g["q"].clone().requires_grad_(True), g["k"], g["v"], **kw)
     with torch.no_grad(), pytest.raises(ValueError, match="multiple of block_size"):
         m(g["q"][:150], g["k"][:150], g["v"][:150], w_rpe=w_rpe, coords=g["coords"][:150],
           combined_shifts=g["combined_shifts"][..., :150])

@@ -116,3 +116,24 @@ def test_table_sharding_identity_in_oracle():
                                   inp["w_rpe_weight"], inp["alpha"][:, :, t:t + 1].contiguous(), **kw)
         assert torch.equal(one["numer"][0], full["numer"][t])
         assert torch.equal(one["denom"][0], full["denom"][t])
+
+
+@pytest.mark.parametrize("name", ["g1_rand512", "g6_block100", "g4_pileup"])
+def test_oracle_gradients_equal_reference_autograd(name):
+    """The oracle with autograd on reproduces the REAL reference's gradients bit for bit (same permutations,
+    upstream gradient randn(seed 11)); they are the gradient oracle of the HIP backward."""
+    inp, fx = cases.load_case(name)
+    qp = torch.from_numpy(fx["q_positions"].astype(np.int64))
+    kp = torch.from_numpy(fx["k_positions"].astype(np.int64))
+    leaves = {k: inp[k].clone().requires_grad_(True) for k in ("q", "k", "v", "w_rpe_weight", "out_weight", "out_bias")}
+    res = ho.forward(leaves["q"], leaves["k"], leaves["v"], inp["coords"], inp["combined_shifts"], leaves["w_rpe_weight"],
+                     inp["alpha"], leaves["out_weight"], leaves["out_bias"], block_size=inp["block_size"],
+                     w_per_dist=inp["w_per_dist"], q_positions=qp, k_positions=kp, keep=False, grad=True)
+    g_out = torch.randn(res["out"].shape, generator=torch.Generator().manual_seed(11))
+    res["out"].backward(g_out)
+    rows = torch.from_numpy(fx["ref_grad_rows"].astype(np.int64))
+    assert torch.equal(leaves["q"].grad[rows], torch.from_numpy(fx["ref_dq_rows"]))
+    assert torch.equal(leaves["k"].grad[rows], torch.from_numpy(fx["ref_dk_rows"]))
+    assert torch.equal(leaves["v"].grad[rows], torch.from_numpy(fx["ref_dv_rows"]))
+    assert torch.equal(leaves["w_rpe_weight"].grad, torch.from_numpy(fx["ref_dw_rpe"]))
+    assert torch.equal(leaves["out_weight"].grad, torch.from_numpy(fx["ref_dout_w"]))
