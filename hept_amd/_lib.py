@@ -11,7 +11,7 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p
 
 from .build import LIB_PATH
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_F32, PREC_BF16, PREC_MIXED16 = 0, 1, 2
 ROW = 32
 MAX_TABLES = 8
@@ -31,9 +31,10 @@ SIGNATURES = {
     "hept_check_shape": (c_int, [c_int] * 6),
     "hept_workspace_bytes": (c_size_t, [c_int] * 7),
     "hept_rpe_scale": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
-    "hept_prep_hash": (c_int, [_P] * 7 + [c_int] * 8 + [_P] * 6),
+    "hept_prep_hash": (c_int, [_P] * 7 + [c_int] * 9 + [_P] * 6),
     "hept_sort_workspace_bytes": (c_size_t, [c_int] * 3),
     "hept_sort_tables": (c_int, [_P] * 4 + [c_int] * 5 + [_P] * 4),
+    "hept_sort_tables_src": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 4),
     "hept_argsort_workspace_bytes": (c_size_t, [c_int, c_int]),
     "hept_segmented_argsort": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "hept_block_attn": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P]),
@@ -42,6 +43,8 @@ SIGNATURES = {
     "hept_combine_out": (c_int, [_P] + [c_int] * 7 + [_P] * 4),
     "hept_forward": (c_int, [_P] * 9 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
+    "hept_forward_src": (c_int, [_P] * 7 + [c_int] + [_P] * 4 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
+    "hept_forward_partial_src": (c_int, [_P] * 7 + [c_int] + [_P] * 2 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
     "hept_block_attn_bwd": (c_int, [_P] * 5 + [c_int] * 5 + [_P] * 3),
     "hept_bwd_reduce": (c_int, [_P, _P] + [c_int] * 5 + [_P] * 5),
     "hept_prepare_workspace_bytes": (c_size_t, [c_int] * 5),

@@ -26,19 +26,30 @@ def rpe_scale_torch(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_p
 
 
 class HeptPartialSums(torch.autograd.Function):
-    """(q, k, v, coords, sqrt_w) -> acc (N, H, 32) = sum over tables of [numer | denom | 0]."""
+    """(q, k, v, coords, sqrt_w) -> acc (N, H, 32) = sum over tables of [numer | denom | 0].
+
+    ``geo`` = (eta, phi, cfac, raw_size) selects the reference's src variant (``codes`` is then None): rows at and
+    after ``raw_size`` are zero-filled in place by the reference (``src/models/attention/hept.py:89-91``), so no
+    gradient flows into them.
+    """
 
     @staticmethod
-    def forward(ctx, q, k, v, coords, sqrt_w, alpha, codes, block_size):
+    def forward(ctx, q, k, v, coords, sqrt_w, alpha, codes, block_size, geo=None):
         n, hd = q.shape
         h = alpha.shape[0]
         d = hd // h
-        ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, "fp32")
-        qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"])
+        if geo is None:
+            ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, "fp32")
+            qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"])
+        else:
+            eta, phi, cfac, raw_size = geo
+            ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, None, "fp32", raw_size=raw_size)
+            qpos, kpos = ops.sort_tables_src(ph["qproj"], ph["kproj"], eta, phi, cfac, ph["minmax"])
         part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, block_size)
         acc = ops.reduce_tables(part, d)
         ctx.save_for_backward(ph["qhat"], ph["kvhat"], qpos, kpos, coords, sqrt_w)
         ctx.dims = (d, coords.shape[1], block_size)
+        ctx.raw_size = n if geo is None else int(geo[3])
         return acc
 
     @staticmethod
@@ -46,7 +57,10 @@ class HeptPartialSums(torch.autograd.Function):
         qhat, kvhat, qpos, kpos, coords, sqrt_w = ctx.saved_tensors
         d, c, block_size = ctx.dims
         dq, dk, dv, dcs = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size)
+        if ctx.raw_size < dq.shape[0]:
+            for g in (dq, dk, dv, dcs):
+                g[ctx.raw_size:] = 0
         # scaled coordinates s[n,h,c] = sqrt_w[h,c] * coords[n,c]
         dsw = torch.einsum("nhc,nc->hc", dcs, coords) if ctx.needs_input_grad[4] else None
         dcoords = torch.einsum("nhc,hc->nc", dcs, sqrt_w) if ctx.needs_input_grad[3] else None
-        return dq, dk, dv, dcoords, dsw, None, None, None
+        return dq, dk, dv, dcoords, dsw, None, None, None, None

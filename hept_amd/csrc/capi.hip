@@ -62,21 +62,32 @@ inline void prof_call_done() {
     if (g_prof.mode != 0) ++g_prof.seen;
 }
 
+// region shift of the reference's src variant (src/models/attention/hept.py:46-56, 89-101); eta == nullptr: the
+// example variant with its integer AND codes
+struct GeoShift {
+    const float* eta = nullptr;
+    const float* phi = nullptr;
+    const float* cfac = nullptr;
+    int raw_size = -1;
+};
+
 // stages shared by hept_forward / hept_forward_partial; leaves per-table partials in w.part
 int run_tables(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
-               const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
-               int precision, const Workspace& w, float* part, void* stream) {
+               const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T,
+               int t0, int Tl, int B, int precision, const Workspace& w, float* part, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     prof_mark(0, st);
     int rc = hept_rpe_scale(w_rpe, H, D, C, K, w.sqrt_w, stream);
     if (rc) return rc;
-    rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, codes, N, H, D, C, T, t0, Tl, precision, w.qhat, w.kvhat,
-                        w.qproj, w.kproj, w.minmax, stream);
+    rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, codes, N, geo.eta ? geo.raw_size : N, H, D, C, T, t0, Tl,
+                        precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream);
     if (rc) return rc;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)Tl * H * N;
     prof_mark(1, st);
-    rc = hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0, Tl, w.sort_ws, qpos, kpos, stream);
+    rc = geo.eta ? hept_sort_tables_src(w.qproj, w.kproj, geo.eta, geo.phi, geo.cfac, w.minmax, N, H, T, t0, Tl,
+                                        w.sort_ws, qpos, kpos, stream)
+                 : hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0, Tl, w.sort_ws, qpos, kpos, stream);
     if (rc) return rc;
     prof_mark(2, st);
     rc = hept_block_attn(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, part, stream);
@@ -86,7 +97,7 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 5; }
+extern "C" int hept_abi_version(void) { return 6; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -106,17 +117,18 @@ extern "C" size_t hept_workspace_bytes(int N, int H, int D, int C, int Tl, int B
     return carve(nullptr, N, H, C, Tl, precision).bytes;
 }
 
-extern "C" int hept_forward(const float* q, const float* k, const float* v, const float* coords,
-                            const int64_t* codes, const float* w_rpe, const float* alpha, const float* out_weight,
-                            const float* out_bias, int N, int H, int D, int C, int K, int T, int B, int precision,
-                            void* workspace, size_t workspace_bytes, float* out, void* stream) {
-    if (!q || !k || !v || !coords || !codes || !w_rpe || !alpha || !out_weight || !workspace || !out)
-        return HEPT_ERR_ARG;
+namespace {
+int forward_impl(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
+                 const GeoShift& geo, const float* w_rpe, const float* alpha, const float* out_weight,
+                 const float* out_bias, int N, int H, int D, int C, int K, int T, int B, int precision,
+                 void* workspace, size_t workspace_bytes, float* out, void* stream) {
+    if (!q || !k || !v || !coords || !w_rpe || !alpha || !out_weight || !workspace || !out) return HEPT_ERR_ARG;
     int rc = hept_check_shape(N, H, D, C, T, B);
     if (rc) return rc;
     const Workspace w = carve(workspace, N, H, C, T, precision);
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
-    rc = run_tables(q, k, v, coords, codes, w_rpe, alpha, N, H, D, C, K, T, 0, T, B, precision, w, w.part, stream);
+    rc = run_tables(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, 0, T, B, precision, w, w.part,
+                    stream);
     if (rc) return rc;
     rc = hept_combine_out(w.part, hept_part_precision(precision, D), T, N, H, D, 0, N, out_weight, out_bias, out,
                           stream);
@@ -125,11 +137,11 @@ extern "C" int hept_forward(const float* q, const float* k, const float* v, cons
     return rc;
 }
 
-extern "C" int hept_forward_partial(const float* q, const float* k, const float* v, const float* coords,
-                                    const int64_t* codes, const float* w_rpe, const float* alpha, int N, int H,
-                                    int D, int C, int K, int T, int t0, int Tl, int B, int precision,
-                                    void* workspace, size_t workspace_bytes, float* acc, void* stream) {
-    if (!q || !k || !v || !coords || !codes || !w_rpe || !alpha || !workspace || !acc) return HEPT_ERR_ARG;
+int forward_partial_impl(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
+                         const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C,
+                         int K, int T, int t0, int Tl, int B, int precision, void* workspace, size_t workspace_bytes,
+                         float* acc, void* stream) {
+    if (!q || !k || !v || !coords || !w_rpe || !alpha || !workspace || !acc) return HEPT_ERR_ARG;
     int rc = hept_check_shape(N, H, D, C, Tl, B);
     if (rc) return rc;
     if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
@@ -139,11 +151,53 @@ extern "C" int hept_forward_partial(const float* q, const float* k, const float*
     const int pprec = hept_part_precision(precision, D);
     const bool direct = Tl == 1 && pprec == HEPT_PREC_F32;
     float* part = direct ? acc : w.part;
-    rc = run_tables(q, k, v, coords, codes, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B, precision, w, part, stream);
+    rc = run_tables(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B, precision, w, part,
+                    stream);
     if (!rc && !direct) rc = hept_reduce_tables(w.part, pprec, Tl, N, H, D, acc, stream);
     prof_mark(4, (hipStream_t)stream);
     prof_call_done();
     return rc;
+}
+}  // namespace
+
+extern "C" int hept_forward(const float* q, const float* k, const float* v, const float* coords,
+                            const int64_t* codes, const float* w_rpe, const float* alpha, const float* out_weight,
+                            const float* out_bias, int N, int H, int D, int C, int K, int T, int B, int precision,
+                            void* workspace, size_t workspace_bytes, float* out, void* stream) {
+    if (!codes) return HEPT_ERR_ARG;
+    return forward_impl(q, k, v, coords, codes, GeoShift{}, w_rpe, alpha, out_weight, out_bias, N, H, D, C, K, T, B,
+                        precision, workspace, workspace_bytes, out, stream);
+}
+
+extern "C" int hept_forward_partial(const float* q, const float* k, const float* v, const float* coords,
+                                    const int64_t* codes, const float* w_rpe, const float* alpha, int N, int H,
+                                    int D, int C, int K, int T, int t0, int Tl, int B, int precision,
+                                    void* workspace, size_t workspace_bytes, float* acc, void* stream) {
+    if (!codes) return HEPT_ERR_ARG;
+    return forward_partial_impl(q, k, v, coords, codes, GeoShift{}, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B,
+                                precision, workspace, workspace_bytes, acc, stream);
+}
+
+extern "C" int hept_forward_src(const float* q, const float* k, const float* v, const float* coords,
+                                const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
+                                const float* w_rpe, const float* alpha, const float* out_weight,
+                                const float* out_bias, int N, int H, int D, int C, int K, int T, int B,
+                                int precision, void* workspace, size_t workspace_bytes, float* out, void* stream) {
+    if (!eta_idx || !phi_idx || !cfac) return HEPT_ERR_ARG;
+    if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    return forward_impl(q, k, v, coords, nullptr, GeoShift{eta_idx, phi_idx, cfac, raw_size}, w_rpe, alpha,
+                        out_weight, out_bias, N, H, D, C, K, T, B, precision, workspace, workspace_bytes, out, stream);
+}
+
+extern "C" int hept_forward_partial_src(const float* q, const float* k, const float* v, const float* coords,
+                                        const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
+                                        const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K,
+                                        int T, int t0, int Tl, int B, int precision, void* workspace,
+                                        size_t workspace_bytes, float* acc, void* stream) {
+    if (!eta_idx || !phi_idx || !cfac) return HEPT_ERR_ARG;
+    if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    return forward_partial_impl(q, k, v, coords, nullptr, GeoShift{eta_idx, phi_idx, cfac, raw_size}, w_rpe, alpha, N,
+                                H, D, C, K, T, t0, Tl, B, precision, workspace, workspace_bytes, acc, stream);
 }
 
 extern "C" int hept_profile_enable(int mode, int max_calls) {

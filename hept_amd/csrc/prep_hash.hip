@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict
 template <int D, int C, int TILE, int ROLE>
 __device__ __forceinline__ void prep_role(const float* __restrict__ x, const float* __restrict__ coords,
                                           const float* __restrict__ sw_s, const float* __restrict__ alpha_s,
-                                          const int64_t* __restrict__ codes, int N, int t0, int Tl,
+                                          const int64_t* __restrict__ codes, int N, int raw_size, int t0, int Tl,
                                           char* __restrict__ out_rows, float* __restrict__ proj,
                                           float* __restrict__ red_s, f32x4* __restrict__ tile_s,
                                           float* __restrict__ minmax, int slot) {
@@ -109,12 +109,19 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
         f32x4 xr[D4];
 #pragma unroll
         for (int j = 0; j < D4; ++j) xr[j] = buf[lane * ROW4 + j];
+        // src variant (src/models/attention/hept.py:89-96): rows >= raw_size are padding: q^ = k^ = v = 0,
+        // they take part in the hash range with projection 0 and then hash to +inf (sorted last)
+        const bool is_pad = n >= raw_size;
+        if (is_pad) {
+#pragma unroll
+            for (int j = 0; j < D4; ++j) xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         float a[32];
         if (ROLE != 2) {
             float cs[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) cs[c] = live ? coords[(size_t)n * C + c] : 0.f;
-            if (ROLE == 0) {
+            for (int c = 0; c < C; ++c) cs[c] = (live && !is_pad) ? coords[(size_t)n * C + c] : 0.f;
+            if (ROLE == 0 && codes) {
                 // largest AND code of this (table, head): bounds the sort-key range for sort_tables
 #pragma unroll
                 for (int t = 0; t < HEPT_MAX_TABLES; ++t)
@@ -155,7 +162,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
 #pragma unroll
                 for (int e = 0; e < E; ++e) acc = fmaf(a[e], alpha_s[(h * E + e) * HEPT_MAX_TABLES + t], acc);
                 if (live) {
-                    proj[((size_t)t * H + h) * N + n] = acc;
+                    proj[((size_t)t * H + h) * N + n] = is_pad ? INFINITY : acc;
                     mn[t] = fminf(mn[t], acc);
                     mx[t] = fmaxf(mx[t], acc);
                 }
@@ -239,7 +246,7 @@ template <int D, int C, int TILE>
 __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
-    const int64_t* __restrict__ codes, int N, int T, int t0, int Tl, void* __restrict__ qhat_,
+    const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
     void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
     constexpr int H = 8, E = D + C;
     static_assert(D % 4 == 0 && E <= 30 && D <= 28, "row packing needs D%4==0, E<=30");
@@ -258,31 +265,31 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
         __syncthreads();
     }
     if (role == 0)
-        prep_role<D, C, TILE, 0>(q, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(qhat_), qproj,
+        prep_role<D, C, TILE, 0>(q, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(qhat_), qproj,
                                  red_s, tile_s, minmax, blockIdx.x);
     else if (role == 1)
-        prep_role<D, C, TILE, 1>(k, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
+        prep_role<D, C, TILE, 1>(k, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
                                  red_s, tile_s, minmax, PREP_WGS_PER_ROLE + blockIdx.x);
     else
-        prep_role<D, C, TILE, 2>(v, coords, sw_s, alpha_s, codes, N, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
+        prep_role<D, C, TILE, 2>(v, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
                                  red_s, tile_s, minmax, 0);
 }
 
 template <int D, int C>
 int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w,
-                const float* alpha, const int64_t* codes, int N, int T, int t0, int Tl, int precision, void* qhat,
-                void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
+                const float* alpha, const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision,
+                void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
     // q- and k-role workgroups each write one of the HEPT_PREP_GRID partial slots the sort kernel reduces
     const dim3 grid(PREP_WGS_PER_ROLE, 3);
     if (precision == HEPT_PREC_BF16)
         hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_BF16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords,
-                           sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     else if (precision == HEPT_PREC_MIXED16)
         hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_MIXED16>), grid, dim3(PREP_THREADS), 0, st, q, k, v,
-                           coords, sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     else
         hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_F32>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords,
-                           sqrt_w, alpha, codes, N, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     return hept_launch_status();
 }
 
@@ -296,10 +303,11 @@ extern "C" int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, fl
 }
 
 extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
-                              const float* sqrt_w, const float* alpha, const int64_t* codes, int N, int H, int D,
-                              int C, int T, int t0, int Tl, int precision, void* qhat, void* kvhat, float* qproj,
-                              float* kproj, float* minmax, void* stream) {
-    if (!q || !k || !v || !coords || !sqrt_w || !alpha || !codes || !qhat || !kvhat || !qproj || !kproj || !minmax)
+                              const float* sqrt_w, const float* alpha, const int64_t* codes, int N, int raw_size,
+                              int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat, void* kvhat,
+                              float* qproj, float* kproj, float* minmax, void* stream) {
+    if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    if (!q || !k || !v || !coords || !sqrt_w || !alpha || !qhat || !kvhat || !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
     if (H != 8 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
     if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16 && precision != HEPT_PREC_MIXED16)
@@ -307,8 +315,8 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
     hipStream_t st = (hipStream_t)stream;
 #define HEPT_PREP_CASE(DD, CC)                                                                             \
     if (D == DD && C == CC)                                                                                \
-        return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, alpha, codes, N, T, t0, Tl, precision, qhat,   \
-                                   kvhat, qproj, kproj, minmax, st);
+        return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, precision, \
+                                   qhat, kvhat, qproj, kproj, minmax, st);
     HEPT_PREP_CASE(24, 6)
     HEPT_PREP_CASE(24, 4)
     HEPT_PREP_CASE(24, 2)

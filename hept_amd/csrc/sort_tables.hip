@@ -46,9 +46,10 @@ __device__ __forceinline__ float from_ordered(unsigned int u) {
 }
 // monotone 16-bit bucket id; scale = 65536 / (kmax - kmin), 0 when all keys are equal
 __device__ __forceinline__ unsigned int id16_of(unsigned int u, float kmin, float scale) {
-    const float x = (from_ordered(u) - kmin) * scale;
+    // the float clamp keeps +inf keys (the src variant's padding rows) and inf * 0 = NaN in the last bucket
+    const float x = fminf((from_ordered(u) - kmin) * scale, (float)(ID_BUCKETS - 1));
     const int b = (int)x;
-    return (unsigned int)(b < 0 ? 0 : (b > ID_BUCKETS - 1 ? ID_BUCKETS - 1 : b));
+    return (unsigned int)(b < 0 ? 0 : b);
 }
 
 // per-segment id map parameters, written once by K1 (chunk 0) and read by the later kernels
@@ -56,9 +57,14 @@ struct SegParams {
     float kmin, scale;
 };
 
-// K1: keys0[seg][n] = ordered bits of (proj + float(code) * span); hist[seg][chunk][256] of the low id byte
+// K1: keys0[seg][n] = ordered bits of (proj + float(code) * span); hist[seg][chunk][256] of the low id byte.
+// SRC = true: the src variant's float shift (get_geo_shift, src/models/attention/hept.py:46-56) replaces
+// float(code) * span:  shift = (phi * span) * cfac + eta * span, every operation rounded on its own; the
+// key bound uses the third partial column as max(phi * cfac + eta).
+template <bool SRC>
 __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
     const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
+    const float* __restrict__ eta_idx, const float* __restrict__ phi_idx, const float* __restrict__ cfac,
     const float* __restrict__ minmax, int N, int H, int t0, int Tl, unsigned int* __restrict__ keys0,
     unsigned int* __restrict__ hist, SegParams* __restrict__ seg_params, int n_chunks) {
     __shared__ unsigned int h_s[RADIX];
@@ -102,9 +108,35 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
     if (chunk == 0 && tid == 0) seg_params[seg] = SegParams{lo, scale};
 
     const float* proj = (is_k ? kproj : qproj) + (size_t)th * N;
-    const int64_t* code = codes + ((size_t)(t0 + t) * H + h) * N;
+    const size_t row_off = ((size_t)(t0 + t) * H + h) * N;
     unsigned int* kout = keys0 + (size_t)seg * N;
     const int base = chunk * SORT_CHUNK;
+    if constexpr (SRC) {
+        const float cf = cfac[(size_t)(t0 + t) * H + h];
+        const float* eta = eta_idx + row_off;
+        const float* phi = phi_idx + row_off;
+#pragma unroll 4
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            const int n = base + i * SORT_THREADS + tid;
+            if (n < N) {
+                float t1 = eta[n] * span;
+                asm volatile("" : "+v"(t1));
+                float t2 = phi[n] * span;
+                asm volatile("" : "+v"(t2));
+                t2 = t2 * cf;
+                asm volatile("" : "+v"(t2));
+                float t3 = t2 + t1;
+                asm volatile("" : "+v"(t3));
+                const unsigned int u = ordered_bits(proj[n] + t3);
+                kout[n] = u;
+                atomicAdd(&h_s[id16_of(u, lo, scale) & 0xFF], 1u);
+            }
+        }
+        __syncthreads();
+        hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
+        return;
+    }
+    const int64_t* code = codes + row_off;
     // two separately rounded ops per key, as the two eager ops of the reference; HIP's __fmul_rn /
     // __fadd_rn are plain * and + and would be contracted to one fma without -ffp-contract=off
     // (Makefile) -- the asm barrier makes it explicit here as well
@@ -390,6 +422,31 @@ __global__ __launch_bounds__(SORT_THREADS) void neighbour_rank_kernel(const unsi
 #undef WIN
 }
 
+// src variant: per (table, head) upper bound of the shift in units of span: max_n (phi * cfac + eta), written into
+// the third column of partial slot 0 (the prep kernel left 0 there), so that K1 bounds the key range with it
+__global__ __launch_bounds__(SORT_THREADS) void src_bound_kernel(const float* __restrict__ eta_idx,
+                                                                 const float* __restrict__ phi_idx,
+                                                                 const float* __restrict__ cfac, int N, int H, int t0,
+                                                                 float* __restrict__ minmax) {
+    __shared__ float red_s[SORT_WAVES];
+    const int th = blockIdx.x, t = th / H, h = th % H, tid = threadIdx.x;
+    const size_t row_off = ((size_t)(t0 + t) * H + h) * N;
+    const float cf = cfac[(size_t)(t0 + t) * H + h];
+    float m = 0.f;
+    for (int n = tid; n < N; n += SORT_THREADS) {
+        const float e = eta_idx[row_off + n], p = phi_idx[row_off + n];
+        if (e < INFINITY && p < INFINITY) m = fmaxf(m, fmaf(p, cf, e));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) red_s[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+        minmax[(((size_t)t * H + h) * HEPT_PREP_GRID + 0) * 4 + 2] = m * 1.0001f + 1.f;  // slack for the roundings
+    }
+}
+
 // ---- generic front end (hept_segmented_argsort): S segments of L raw fp32 keys, +inf allowed as padding ----
 // finite min/max of one segment -> id map parameters
 __global__ __launch_bounds__(SORT_THREADS) void raw_range_kernel(const float* __restrict__ keys, int L,
@@ -503,8 +560,27 @@ extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const in
     const int segs = 2 * Tl * H;
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(sort_ws, segs, N);
-    hipLaunchKernelGGL(keygen_hist_kernel, dim3(n_chunks, segs), dim3(SORT_THREADS), 0, st, qproj, kproj, codes, minmax,
-                       N, H, t0, Tl, b.keys0, b.hist, b.params, n_chunks);
+    hipLaunchKernelGGL(keygen_hist_kernel<false>, dim3(n_chunks, segs), dim3(SORT_THREADS), 0, st, qproj, kproj, codes,
+                       nullptr, nullptr, nullptr, minmax, N, H, t0, Tl, b.keys0, b.hist, b.params, n_chunks);
+    run_passes(b, segs, N, qpos, st);
+    return hept_launch_status();
+}
+
+extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, const float* eta_idx,
+                                    const float* phi_idx, const float* cfac, float* minmax, int N, int H, int T,
+                                    int t0, int Tl, void* sort_ws, int32_t* qpos, int32_t* kpos, void* stream) {
+    if (!qproj || !kproj || !eta_idx || !phi_idx || !cfac || !minmax || !sort_ws || !qpos || !kpos)
+        return HEPT_ERR_ARG;
+    if (N < 1 || H < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (kpos != qpos + (size_t)Tl * H * N) return HEPT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int segs = 2 * Tl * H;
+    const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
+    const SortBuffers b = carve_sort(sort_ws, segs, N);
+    hipLaunchKernelGGL(src_bound_kernel, dim3(Tl * H), dim3(SORT_THREADS), 0, st, eta_idx, phi_idx, cfac, N, H, t0,
+                       minmax);
+    hipLaunchKernelGGL(keygen_hist_kernel<true>, dim3(n_chunks, segs), dim3(SORT_THREADS), 0, st, qproj, kproj, nullptr,
+                       eta_idx, phi_idx, cfac, minmax, N, H, t0, Tl, b.keys0, b.hist, b.params, n_chunks);
     run_passes(b, segs, N, qpos, st);
     return hept_launch_status();
 }

@@ -9,6 +9,11 @@ int64, optional ignored ``pe``; same attribute and state-dict names
 (``out_linear.weight``, ``out_linear.bias``, ``e2lsh.alpha``), so a reference
 checkpoint loads with ``strict=True``.
 
+The same class also stands in for the reference's ``src`` variant (``src/models/attention/hept.py:59-117``,
+SURVEY.md §8 f-3): construct with ``variant="src"`` (adds the unused ``e2lsh.beta`` parameter that variant's
+checkpoints carry) and call ``forward`` with that variant's kwargs — ``raw_size``, ``regions_h``,
+``region_indices`` as built by ``hept_amd.prep.prepare_input_src`` — instead of ``combined_shifts``.
+
 Two keyword-only extensions: ``precision`` ("fp32" reference numerics /
 "bf16" MFMA tiles / "mixed16" = fp16 q̂,k̂ tiles with bf16 weights and values) and ``process_group`` (shard the ``n_hashes`` tables over
 the ranks of a ``torch.distributed`` group).
@@ -37,18 +42,24 @@ class E2LSH(nn.Module):
     use it on its own; the fused operator reads ``alpha`` directly.
     """
 
-    def __init__(self, n_hashes, n_heads, dim, r=1):
+    def __init__(self, n_hashes, n_heads, dim, r=1, with_beta: bool = False):
         super().__init__()
         self.alpha = nn.Parameter(torch.normal(0, 1, (n_heads, dim, n_hashes)))
         self.alpha.requires_grad = False
+        if with_beta:  # src/models/model_utils/hash_utils.py:322: drawn, stored in checkpoints, never read
+            self.beta = nn.Parameter(r * torch.rand(1, n_hashes))
+            self.beta.requires_grad = False
 
     def forward(self, vecs):
         return torch.bmm(vecs, self.alpha).permute(2, 0, 1)
 
 
 class HEPTAttention(nn.Module):
-    def __init__(self, hash_dim, *, precision: str = "fp32", process_group=None, **kwargs):
+    def __init__(self, hash_dim, *, precision: str = "fp32", process_group=None, variant: str = "example", **kwargs):
         super().__init__()
+        if variant not in ("example", "src"):
+            raise ValueError(f"variant must be 'example' or 'src', got {variant!r}")
+        self.variant = variant
         self.dim_per_head = kwargs["h_dim"]
         self.num_heads = kwargs["num_heads"]
         self.out_linear = nn.Linear(self.num_heads * self.dim_per_head, self.dim_per_head)
@@ -56,7 +67,7 @@ class HEPTAttention(nn.Module):
         self.block_size = kwargs["block_size"]
         self.n_hashes = kwargs["n_hashes"]
         self.num_w_per_dist = kwargs["num_w_per_dist"]
-        self.e2lsh = E2LSH(n_hashes=self.n_hashes, n_heads=self.num_heads, dim=hash_dim)
+        self.e2lsh = E2LSH(n_hashes=self.n_hashes, n_heads=self.num_heads, dim=hash_dim, with_beta=variant == "src")
 
         self.precision = precision
         ops.precision_code(precision)  # validate early
@@ -80,7 +91,7 @@ class HEPTAttention(nn.Module):
         ):
             return self._forward_train(query, key, value, **kwargs)
         coords = kwargs["coords"]
-        codes = kwargs["combined_shifts"]
+        src = "combined_shifts" not in kwargs  # the src variant's kwargs: raw_size, regions_h, region_indices
         w_rpe_weight = kwargs["w_rpe"].weight
         n = query.shape[0]
         if n % self.block_size != 0:
@@ -94,13 +105,24 @@ class HEPTAttention(nn.Module):
             if self.sharding is None:
                 ws = self._scratch(ops.workspace_bytes(n, h, d, c, self.n_hashes, self.block_size, self.precision),
                                    query.device)
-                out = ops.forward(q2, k2, v2, coords.float(), codes, w_rpe_weight, self.e2lsh.alpha,
-                                  self.out_linear.weight, self.out_linear.bias, workspace=ws, **common)
+                if src:
+                    out = ops.forward_src(q2, k2, v2, coords.float(), kwargs["region_indices"], kwargs["regions_h"],
+                                          kwargs["raw_size"], w_rpe_weight, self.e2lsh.alpha, self.out_linear.weight,
+                                          self.out_linear.bias, workspace=ws, **common)
+                else:
+                    out = ops.forward(q2, k2, v2, coords.float(), kwargs["combined_shifts"], w_rpe_weight,
+                                      self.e2lsh.alpha, self.out_linear.weight, self.out_linear.bias, workspace=ws,
+                                      **common)
             else:
                 t0, tl = self.sharding.local_tables()
                 ws = self._scratch(ops.workspace_bytes(n, h, d, c, tl, self.block_size, self.precision), query.device)
-                acc = ops.forward_partial(q2, k2, v2, coords.float(), codes, w_rpe_weight, self.e2lsh.alpha,
-                                          t0=t0, tl=tl, workspace=ws, **common)
+                if src:
+                    acc = ops.forward_partial_src(q2, k2, v2, coords.float(), kwargs["region_indices"],
+                                                  kwargs["regions_h"], kwargs["raw_size"], w_rpe_weight,
+                                                  self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, **common)
+                else:
+                    acc = ops.forward_partial(q2, k2, v2, coords.float(), kwargs["combined_shifts"], w_rpe_weight,
+                                              self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, **common)
                 out = self.sharding.finish(
                     acc, lambda part, n0, cnt: ops.combine_out(part, d, self.out_linear.weight,
                                                                self.out_linear.bias, n0, cnt))
@@ -120,9 +142,13 @@ class HEPTAttention(nn.Module):
         h, d = self.num_heads, self.dim_per_head
         coords = kwargs["coords"].float()
         sqrt_w = rpe_scale_torch(kwargs["w_rpe"].weight.float(), h, d, self.num_w_per_dist)
+        geo = None
+        if "combined_shifts" not in kwargs:
+            geo = ops.geo_args(kwargs["region_indices"], kwargs["regions_h"], self.n_hashes, h, n) + (
+                int(kwargs["raw_size"]),)
         acc = HeptPartialSums.apply(query.reshape(n, h * d).float(), key.reshape(n, h * d).float(),
                                     value.reshape(n, h * d).float(), coords, sqrt_w, self.e2lsh.alpha.detach(),
-                                    kwargs["combined_shifts"], self.block_size)
+                                    kwargs.get("combined_shifts"), self.block_size, geo)
         per_head = acc[..., :d] / acc[..., d:d + 1]                      # example/hept.py:79
         out = self.out_linear(per_head.reshape(n, h * d))                # example/hept.py:80
         return out.to(query.dtype)

@@ -15,7 +15,7 @@ from ._lib import PREC_BF16, PREC_F32, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
-    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort", "block_attn_bwd",
+    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args",
 ]
 
 
@@ -66,15 +66,18 @@ def rpe_scale(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dis
     return out
 
 
-def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int = 0, tl: Optional[int] = None) -> Dict[str, torch.Tensor]:
+def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int = 0, tl: Optional[int] = None,
+              raw_size: Optional[int] = None) -> Dict[str, torch.Tensor]:
     lib = _lib.load()
     q, k, v, coords, sqrt_w, alpha = (_f32c(x, nm) for x, nm in
                                       ((q, "query"), (k, "key"), (v, "value"), (coords, "coords"),
                                        (sqrt_w, "sqrt_w"), (alpha, "alpha")))
     n, h, d, c, t = _dims(q, coords, alpha)
-    if codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n):
-        raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}")
-    codes = codes.contiguous()
+    if codes is not None:
+        if codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n):
+            raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}")
+        codes = codes.contiguous()
+    raw_size = n if raw_size is None else int(raw_size)
     tl = t - t0 if tl is None else tl
     prec = precision_code(precision)
     # dtype tag of the row buffers: bf16 / f16 (mixed16: q^,k^ halves are fp16, the v half of kvhat is bf16) / f32
@@ -86,7 +89,8 @@ def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int =
     kproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
     minmax = torch.empty(tl, h, _lib.PREP_GRID, 4, device=dev, dtype=torch.float32)
     _lib.check(lib.hept_prep_hash(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), sqrt_w.data_ptr(),
-                                  alpha.data_ptr(), codes.data_ptr(), n, h, d, c, t, t0, tl, prec, qhat.data_ptr(), kvhat.data_ptr(),
+                                  alpha.data_ptr(), codes.data_ptr() if codes is not None else None, n, raw_size, h, d, c,
+                                  t, t0, tl, prec, qhat.data_ptr(), kvhat.data_ptr(),
                                   qproj.data_ptr(), kproj.data_ptr(), minmax.data_ptr(), _stream(q)),
                "hept_prep_hash")
     return dict(qhat=qhat, kvhat=kvhat, qproj=qproj, kproj=kproj, minmax=minmax)
@@ -105,6 +109,21 @@ def sort_tables(qproj, kproj, codes, minmax, t0: int = 0) -> Tuple[torch.Tensor,
     _lib.check(lib.hept_sort_tables(qproj.data_ptr(), kproj.data_ptr(), codes.data_ptr(), minmax.data_ptr(), n, h, t,
                                     t0, tl, ws.data_ptr(), pos[0].data_ptr(), pos[1].data_ptr(), _stream(qproj)),
                "hept_sort_tables")
+    return pos[0], pos[1]
+
+
+def sort_tables_src(qproj, kproj, eta_idx, phi_idx, cfac, minmax, t0: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """src-variant keys (hash + get_geo_shift): stable ascending permutations (Tl,H,N) int32 for q and k."""
+    lib = _lib.load()
+    tl, h, n = qproj.shape
+    eta_idx, phi_idx, cfac = (_f32c(x, nm) for x, nm in ((eta_idx, "region_indices[0]"), (phi_idx, "region_indices[1]"),
+                                                          (cfac, "cfac")))
+    t = eta_idx.numel() // (h * n)
+    ws = torch.empty(int(lib.hept_sort_workspace_bytes(n, h, tl)), device=qproj.device, dtype=torch.uint8)
+    pos = torch.empty(2, tl, h, n, device=qproj.device, dtype=torch.int32)
+    _lib.check(lib.hept_sort_tables_src(qproj.data_ptr(), kproj.data_ptr(), eta_idx.data_ptr(), phi_idx.data_ptr(),
+                                        cfac.data_ptr(), minmax.data_ptr(), n, h, t, t0, tl, ws.data_ptr(),
+                                        pos[0].data_ptr(), pos[1].data_ptr(), _stream(qproj)), "hept_sort_tables_src")
     return pos[0], pos[1]
 
 
@@ -203,6 +222,22 @@ def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int
     return dq, dk, dv, dcs
 
 
+def geo_args(region_indices, regions_h, n_tables: int, n_heads: int, n: int):
+    """The src variant's caller tensors in the C ABI's layout: eta, phi (T,H,N) f32 and cfac (T,H) f32
+    (= ``ceil(regions_h[0]) + 1``, reference ``src/models/attention/hept.py:53``)."""
+    eta, phi = region_indices
+    eta = _f32c(eta, "region_indices[0]")
+    phi = _f32c(phi, "region_indices[1]")
+    if tuple(eta.shape) != (n_tables * n_heads, n) or phi.shape != eta.shape:
+        raise ValueError(f"region_indices must be two {(n_tables * n_heads, n)} tensors, got {tuple(eta.shape)} "
+                         f"and {tuple(phi.shape)}")
+    rh = _f32c(regions_h, "regions_h")
+    if tuple(rh.shape) != (2, n_tables * n_heads):
+        raise ValueError(f"regions_h must have shape {(2, n_tables * n_heads)}, got {tuple(rh.shape)}")
+    cfac = (torch.ceil(rh[0]) + 1).contiguous()
+    return eta, phi, cfac
+
+
 def _prepare(q, k, v, coords, codes, w_rpe_weight, alpha, block_size, w_per_dist):
     q, k, v, coords, w, alpha = (_f32c(x, nm) for x, nm in
                                  ((q, "query"), (k, "key"), (v, "value"), (coords, "coords"),
@@ -212,11 +247,11 @@ def _prepare(q, k, v, coords, codes, w_rpe_weight, alpha, block_size, w_per_dist
         raise ValueError("query, key, value and coords must agree on the number of points")
     if n % block_size != 0:
         raise ValueError(f"number of points {n} is not a multiple of block_size {block_size}")
-    if codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n):
+    if codes is not None and (codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n)):
         raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}, got {codes.dtype} {tuple(codes.shape)}")
     if w.shape != (h * d, (c - 1) * w_per_dist):
         raise ValueError(f"w_rpe.weight must have shape {(h * d, (c - 1) * w_per_dist)}, got {tuple(w.shape)}")
-    return q, k, v, coords, codes.contiguous(), w, alpha, (n, h, d, c, t)
+    return q, k, v, coords, codes.contiguous() if codes is not None else None, w, alpha, (n, h, d, c, t)
 
 
 def forward(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *, block_size: int, w_per_dist: int,
@@ -256,6 +291,52 @@ def forward_partial(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: 
                                         w.data_ptr(), alpha.data_ptr(), n, h, d, c, w_per_dist, t, t0, tl, block_size,
                                         prec, workspace.data_ptr(), workspace.numel(), acc.data_ptr(), _stream(q)),
                "hept_forward_partial")
+    return acc
+
+
+def forward_src(q, k, v, coords, region_indices, regions_h, raw_size: int, w_rpe_weight, alpha, out_weight, out_bias,
+                *, block_size: int, w_per_dist: int, precision="fp32",
+                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Whole operator of the reference's src variant (``src/models/attention/hept.py:74-117``); (N, D) float32."""
+    lib = _lib.load()
+    q, k, v, coords, _, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, None, w_rpe_weight, alpha, block_size,
+                                                             w_per_dist)
+    eta, phi, cfac = geo_args(region_indices, regions_h, t, h, n)
+    prec = precision_code(precision)
+    _lib.check(lib.hept_check_shape(n, h, d, c, t, block_size), "hept_check_shape")
+    need = int(lib.hept_workspace_bytes(n, h, d, c, t, block_size, prec))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
+    ow = _f32c(out_weight, "out_linear.weight")
+    ob = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
+    out = torch.empty(n, d, device=q.device, dtype=torch.float32)
+    _lib.check(lib.hept_forward_src(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), eta.data_ptr(),
+                                    phi.data_ptr(), cfac.data_ptr(), int(raw_size), w.data_ptr(), alpha.data_ptr(),
+                                    ow.data_ptr(), ob.data_ptr() if ob is not None else None, n, h, d, c, w_per_dist,
+                                    t, block_size, prec, workspace.data_ptr(), workspace.numel(), out.data_ptr(),
+                                    _stream(q)), "hept_forward_src")
+    return out
+
+
+def forward_partial_src(q, k, v, coords, region_indices, regions_h, raw_size: int, w_rpe_weight, alpha, *,
+                        block_size: int, w_per_dist: int, t0: int, tl: int, precision="fp32",
+                        workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src variant, tables [t0, t0+tl) only: acc (N, H, 32) = sum over those tables of [numer | denom]."""
+    lib = _lib.load()
+    q, k, v, coords, _, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, None, w_rpe_weight, alpha, block_size,
+                                                             w_per_dist)
+    eta, phi, cfac = geo_args(region_indices, regions_h, t, h, n)
+    prec = precision_code(precision)
+    _lib.check(lib.hept_check_shape(n, h, d, c, tl, block_size), "hept_check_shape")
+    need = int(lib.hept_workspace_bytes(n, h, d, c, tl, block_size, prec))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
+    acc = torch.empty(n, h, 32, device=q.device, dtype=torch.float32)
+    _lib.check(lib.hept_forward_partial_src(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(),
+                                            eta.data_ptr(), phi.data_ptr(), cfac.data_ptr(), int(raw_size),
+                                            w.data_ptr(), alpha.data_ptr(), n, h, d, c, w_per_dist, t, t0, tl,
+                                            block_size, prec, workspace.data_ptr(), workspace.numel(),
+                                            acc.data_ptr(), _stream(q)), "hept_forward_partial_src")
     return acc
 
 

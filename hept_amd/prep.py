@@ -26,7 +26,8 @@ from typing import Dict, Tuple
 
 import torch
 
-__all__ = ["get_regions", "quantile_partition", "bit_shift", "pad_and_unpad", "prepare_input", "prepare_input_hip"]
+__all__ = ["get_regions", "quantile_partition", "bit_shift", "pad_and_unpad", "prepare_input", "prepare_input_hip",
+           "prepare_input_src"]
 
 
 def get_regions(num_regions, num_or_hashes, num_heads, num_and_hashes=2, generator=None) -> torch.Tensor:
@@ -183,3 +184,37 @@ def prepare_input(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Dict[s
         pad_seq, unpad_seq = pad_and_unpad(batch, block_size, codes[0, 0], sizes)
         kwargs = {"combined_shifts": codes[..., pad_seq], "coords": coords[pad_seq]}
         return x[pad_seq], kwargs, unpad_seq
+
+
+def _stable_argsort_rows(keys: torch.Tensor) -> torch.Tensor:
+    """Stable ascending argsort of every row; GPU rows go through the library's exact segmented sort."""
+    if keys.is_cuda:
+        from . import ops
+
+        return ops.segmented_argsort(keys.float().contiguous()).long()
+    return torch.sort(keys, dim=-1, stable=True).indices
+
+
+def prepare_input_src(x, coords, helper_funcs) -> Tuple[torch.Tensor, Dict]:
+    """Caller-side preparation of the reference's ``src`` variant; ``src/models/baselines/transformer.py:43-57``.
+
+    One cloud per call (the reference asserts ``batch.max() == 0``).  Pads ``x`` with zero rows and ``coords`` with
+    +inf rows up to a multiple of ``block_size``, ranks eta (``coords[:, 0]``) and phi (``coords[:, 1]``) with the
+    pads last, turns the ranks into float region ids per (table, head) with ``quantile_partition``, then zeroes the
+    pad coordinates.  Returns the padded ``x`` and the kwargs of ``HEPTAttention.forward``: ``raw_size``,
+    ``coords``, ``region_indices`` = [eta (T*H, N), phi (T*H, N)] and ``regions_h`` (2, T*H).  Ties are broken by
+    ascending index (the reference's ``argsort`` leaves them undefined); runs on the device of its inputs.
+    """
+    block_size, regions = int(helper_funcs["block_size"]), helper_funcs["regions"]
+    with torch.no_grad():
+        raw_size = x.shape[0]
+        n_pad = (-raw_size) % block_size
+        x_p = torch.cat([x, x.new_zeros((n_pad,) + tuple(x.shape[1:]))]) if n_pad else x
+        coords_p = torch.cat([coords, coords.new_full((n_pad, coords.shape[1]), float("inf"))]) if n_pad \
+            else coords.clone()
+        order = _stable_argsort_rows(coords_p[:, :2].t().contiguous())
+        n_tables, _, num_heads = regions.shape
+        regions_h = regions.permute(1, 0, 2).reshape(2, n_tables * num_heads)  # "c a h -> a (c h)"
+        region_indices = [quantile_partition(order[axis], regions_h[axis][:, None]) for axis in (0, 1)]
+        coords_p[raw_size:] = 0.0
+    return x_p, {"raw_size": raw_size, "coords": coords_p, "region_indices": region_indices, "regions_h": regions_h}

@@ -11,9 +11,9 @@ from typing import Dict, Optional, Sequence
 
 import torch
 
-from .prep import get_regions, prepare_input
+from .prep import get_regions, prepare_input, prepare_input_src
 
-__all__ = ["make_inputs", "WORKLOADS", "workload_inputs"]
+__all__ = ["make_inputs", "make_inputs_src", "WORKLOADS", "workload_inputs"]
 
 
 def _linear_init(gen: torch.Generator, out_f: int, in_f: int, bias: bool):
@@ -111,6 +111,63 @@ def make_inputs(
         out["cluster_id"] = cluster_id
     out = {name: t.to(device) for name, t in out.items()}
     out["n_raw"] = n_raw
+    return out
+
+
+def make_inputs_src(
+    raw_size: int,
+    *,
+    block_size: int,
+    n_hashes: int,
+    coords_dim: int = 6,
+    num_heads: int = 8,
+    h_dim: int = 24,
+    num_regions: int = 150,
+    num_w_per_dist: int = 10,
+    seed: int = 0,
+    device: str = "cpu",
+    regions: Optional[torch.Tensor] = None,
+    cluster_size: int = 0,
+    cluster_spread: float = 0.05,
+    qk_scale: float = 1.0,
+    coords_scale: float = 1.0,
+) -> Dict[str, torch.Tensor]:
+    """One cloud in the calling convention of the reference's src variant.
+
+    The cloud is padded once, at the end, to a multiple of ``block_size``
+    (``src/models/baselines/transformer.py:43-57``).  q, k, v of the padding rows are drawn like every other
+    row (in the model they are W(norm(0)), not zero): the operator itself has to blank them.
+    """
+    gen = torch.Generator().manual_seed(seed)
+    n = raw_size + (-raw_size) % block_size
+    hd = num_heads * h_dim
+    q = torch.randn(n, hd, generator=gen)
+    k = torch.randn(n, hd, generator=gen)
+    v = torch.randn(n, hd, generator=gen)
+    coords = torch.randn(raw_size, coords_dim, generator=gen)
+    if cluster_size > 0:
+        n_clu = (n + cluster_size - 1) // cluster_size
+        cluster_id = (torch.randperm(n, generator=gen) // cluster_size).clamp(max=n_clu - 1)
+        centres = torch.randn(n_clu, 3 * hd + coords_dim, generator=gen)[cluster_id]
+        q = centres[:, :hd] + cluster_spread * q
+        k = centres[:, :hd] + cluster_spread * k
+        v = centres[:, 2 * hd : 3 * hd] + cluster_spread * v
+        coords = centres[:raw_size, 3 * hd :] + cluster_spread * coords
+    q, k, coords = q * qk_scale, k * qk_scale, coords * coords_scale
+    w_rpe, _ = _linear_init(gen, hd, (coords_dim - 1) * num_w_per_dist, bias=False)
+    alpha = torch.randn(num_heads, h_dim + coords_dim, n_hashes, generator=gen)
+    out_w, out_b = _linear_init(gen, h_dim, hd, bias=True)
+    if regions is None:
+        regions = get_regions(num_regions, n_hashes, num_heads, generator=gen)
+    _, kw = prepare_input_src(torch.zeros(raw_size, 1), coords, {"block_size": block_size, "regions": regions})
+    out = {
+        "q": q, "k": k, "v": v, "coords": kw["coords"].contiguous(),
+        "eta_idx": kw["region_indices"][0].contiguous(), "phi_idx": kw["region_indices"][1].contiguous(),
+        "regions_h": kw["regions_h"].contiguous(), "w_rpe_weight": w_rpe, "alpha": alpha, "out_weight": out_w,
+        "out_bias": out_b, "regions": regions, "coords_raw": coords,
+    }
+    out = {name: t.to(device) for name, t in out.items()}
+    out["raw_size"] = raw_size
     return out
 
 

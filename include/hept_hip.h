@@ -72,9 +72,12 @@ int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, float* sqrt_w
  * (example/hept_utils.py:45-47) and the min/max of lsh_mapping (:66-70).
  * minmax: (Tl, H, HEPT_PREP_GRID, 4) f32 per-workgroup partials [hash min, hash max, largest AND
  * code, 0]; reduced by hept_sort_tables (the code maximum bounds the sort-key range). */
+/* raw_size < N selects the padding rule of the reference's src variant (src/models/attention/hept.py:89-96):
+ * rows >= raw_size are zero rows that hash to +inf (raw_size == N: no such rows).  codes may be NULL (src
+ * variant: the key range then comes from hept_sort_tables_src). */
 int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
                    const float* sqrt_w, const float* alpha, const int64_t* codes,
-                   int N, int H, int D, int C, int T, int t0, int Tl, int precision,
+                   int N, int raw_size, int H, int D, int C, int T, int t0, int Tl, int precision,
                    void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
                    void* stream);
 #define HEPT_PREP_GRID 1024
@@ -86,6 +89,13 @@ size_t hept_sort_workspace_bytes(int N, int H, int Tl);
 int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* codes,
                      const float* minmax, int N, int H, int T, int t0, int Tl,
                      void* sort_ws, int32_t* qpos, int32_t* kpos, void* stream);
+
+/* The reference's src variant: keys = hash + get_geo_shift (src/models/attention/hept.py:46-56,
+ * 98-101): shift = (phi_idx * span) * cfac + eta_idx * span with every product / sum rounded separately, where
+ * eta_idx, phi_idx (T, H, N) f32 are the caller's region_indices and cfac (T, H) f32 = ceil(regions_h[0]) + 1. */
+int hept_sort_tables_src(const float* qproj, const float* kproj, const float* eta_idx, const float* phi_idx,
+                         const float* cfac, float* minmax, int N, int H, int T, int t0, int Tl,
+                         void* sort_ws, int32_t* qpos, int32_t* kpos, void* stream);
 
 /* Generic form of the same sort: stable ascending argsort of S segments of L fp32 keys each
  * (row-major (S, L); +inf is a legal padding key and sorts last).  pos (S, L) i32.  Used by
@@ -126,6 +136,22 @@ int hept_forward_partial(const float* q, const float* k, const float* v, const f
                          int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
                          int precision, void* workspace, size_t workspace_bytes, float* acc,
                          void* stream);
+
+/* SURVEY.md §8 f-3 — the reference's src variant of the same operator (src/models/attention/hept.py:74-117, caller
+ * src/models/baselines/transformer.py:43-57): no AND codes; the sort key is hash + get_geo_shift (see
+ * hept_sort_tables_src) and rows >= raw_size are padding (zeroed q^, k^, v; hash +inf).  eta_idx / phi_idx (T, H, N)
+ * f32 = kwargs["region_indices"] viewed "(c h) n -> c h n"; cfac (T, H) f32 = ceil(kwargs["regions_h"][0]) + 1. */
+int hept_forward_src(const float* q, const float* k, const float* v, const float* coords,
+                     const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
+                     const float* w_rpe, const float* alpha, const float* out_weight, const float* out_bias,
+                     int N, int H, int D, int C, int K, int T, int B, int precision,
+                     void* workspace, size_t workspace_bytes, float* out, void* stream);
+int hept_forward_partial_src(const float* q, const float* k, const float* v, const float* coords,
+                             const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
+                             const float* w_rpe, const float* alpha,
+                             int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
+                             int precision, void* workspace, size_t workspace_bytes, float* acc,
+                             void* stream);
 
 /* SURVEY.md §8 f-2 — backward of the block attention (the reference trains through example/hept.py:55-80 with
  * plain autograd; there is no custom backward to mirror).  f32 tiles only.  gacc (N, H, 32) f32 is the

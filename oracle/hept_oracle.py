@@ -44,6 +44,7 @@ __all__ = [
     "e2lsh_project",
     "hash_range",
     "shifted_keys",
+    "geo_shift",
     "sort_keys",
     "gather_blocks",
     "block_rbf_attention",
@@ -141,6 +142,21 @@ def shifted_keys(
     """
     offs = codes * span  # int64 * fp32 -> fp32 (type promotion), rounded once
     return q_hashed + offs, k_hashed + offs
+
+
+def geo_shift(regions_h: torch.Tensor, span: torch.Tensor, region_indices, n_tables: int) -> torch.Tensor:
+    """Float region shift of the reference's ``src`` variant, shape (T,H,N); ``src/models/attention/hept.py:46-56``.
+
+    ``region_indices`` = (eta, phi), each (T*H, N) float, rows ordered ``(c h)``; ``regions_h`` (2, T*H);
+    ``span`` (T,H,1).  Operation order as the reference: ``eta*span``; ``(phi*span) * (ceil(regions_h[0]) + 1)``;
+    then phi part + eta part.  The reference computes the same tensor twice (for q and for k).
+    """
+    eta, phi = region_indices
+    span_f = span.reshape(-1, span.shape[-1])  # "c h d -> (c h) d", src/models/attention/hept.py:94
+    shift_eta = eta * span_f
+    shift_phi = phi * span_f * (torch.ceil(regions_h[0][:, None]) + 1)
+    res = shift_phi + shift_eta
+    return res.reshape(n_tables, -1, res.shape[-1])
 
 
 def sort_keys(keys: torch.Tensor, stable: bool = True) -> torch.Tensor:
@@ -243,8 +259,15 @@ def forward_partials(
     qk_dtype: Optional[torch.dtype] = None,
     keep: bool = True,
     grad: bool = False,
+    geo: Optional[Dict] = None,
 ) -> Dict[str, torch.Tensor]:
     """Everything up to the per-table partials in original point order.
+
+    ``geo`` selects the reference's ``src`` variant (``src/models/attention/hept.py:74-117``): a dict with
+    ``raw_size``, ``region_indices`` (eta, phi) and ``regions_h`` as built by the caller
+    (``src/models/baselines/transformer.py:43-57``); ``codes`` is then unused (pass None).  Rows at and after
+    ``raw_size`` are zeroed in q̂, k̂ and v (``:89-91``), still take part in the hash range with their zero
+    hashes, and are then given the hash +inf (``:95-96``) so that they sort last.
 
     ``grad=True`` leaves autograd on (the reference trains through these very ops with plain
     autograd, ``example/trainer.py:11-22``; hashing stays ``no_grad`` as in
@@ -260,7 +283,7 @@ def forward_partials(
             return forward_partials(q, k, v, coords, codes, w_rpe_weight, alpha, block_size=block_size,
                                     w_per_dist=w_per_dist, stable_sort=stable_sort, q_positions=q_positions,
                                     k_positions=k_positions, tile_dtype=tile_dtype, qk_dtype=qk_dtype, keep=keep,
-                                    grad=True)
+                                    grad=True, geo=geo)
     n_heads, hash_dim, _ = alpha.shape
     head_dim = q.shape[1] // n_heads
     if q.shape[0] % block_size != 0:
@@ -269,12 +292,31 @@ def forward_partials(
     q_hat, k_hat = augment_qk(q, k, coords, sqrt_w)
     assert q_hat.shape[-1] == hash_dim
     v_h = v.reshape(v.shape[0], n_heads, head_dim).permute(1, 0, 2)
+    if geo is not None:
+        # the reference's in-place zero fill of the padding rows (:89-91), written the same way so that autograd
+        # records the same graph (gradient accumulation order included)
+        raw = int(geo["raw_size"])
+        if not v_h.requires_grad and not torch.is_grad_enabled():
+            q_hat, k_hat, v_h = q_hat.clone(), k_hat.clone(), v_h.clone()
+        elif v_h.is_leaf or v_h._base is not None and v_h._base.is_leaf:
+            v_h = (v * 1.0).reshape(v.shape[0], n_heads, head_dim).permute(1, 0, 2)
+        q_hat[:, raw:] = 0.0
+        k_hat[:, raw:] = 0.0
+        v_h[:, raw:] = 0.0
 
     with torch.no_grad():  # lsh_mapping is @torch.no_grad in the reference; argsort yields integers
         q_hashed = e2lsh_project(q_hat, alpha)
         k_hashed = e2lsh_project(k_hat, alpha)
         span = hash_range(q_hashed, k_hashed)
-        q_keys, k_keys = shifted_keys(q_hashed, k_hashed, codes, span)
+        if geo is None:
+            q_keys, k_keys = shifted_keys(q_hashed, k_hashed, codes, span)
+        else:
+            q_hashed = q_hashed.clone()
+            k_hashed = k_hashed.clone()
+            q_hashed[..., int(geo["raw_size"]):] = float("inf")
+            k_hashed[..., int(geo["raw_size"]):] = float("inf")
+            shift = geo_shift(geo["regions_h"], span, geo["region_indices"], alpha.shape[-1])
+            q_keys, k_keys = q_hashed + shift, k_hashed + shift
         q_pos = sort_keys(q_keys, stable_sort) if q_positions is None else q_positions
         k_pos = sort_keys(k_keys, stable_sort) if k_positions is None else k_positions
 
@@ -322,13 +364,15 @@ def forward(
     qk_dtype: Optional[torch.dtype] = None,
     keep: bool = True,
     grad: bool = False,
+    geo: Optional[Dict] = None,
 ) -> Dict[str, torch.Tensor]:
-    """Full operator, ``example/hept.py:43-81``; returns a dict with ``out`` (N,D) and intermediates."""
+    """Full operator, ``example/hept.py:43-81`` (``geo`` given: ``src/models/attention/hept.py:74-117``);
+    returns a dict with ``out`` (N,D) and intermediates."""
     res = forward_partials(
         q, k, v, coords, codes, w_rpe_weight, alpha,
         block_size=block_size, w_per_dist=w_per_dist, stable_sort=stable_sort,
         q_positions=q_positions, k_positions=k_positions, tile_dtype=tile_dtype, qk_dtype=qk_dtype, keep=keep,
-        grad=grad,
+        grad=grad, geo=geo,
     )
     if not grad:
         with torch.no_grad():

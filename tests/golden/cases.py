@@ -18,7 +18,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-from hept_amd.synthetic import make_inputs  # noqa: E402
+from hept_amd.synthetic import make_inputs, make_inputs_src  # noqa: E402
 
 GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
 
@@ -56,6 +56,44 @@ CASES: Dict[str, dict] = {
 }
 
 NUM_HEADS, H_DIM, W_PER_DIST = 8, 24, 10
+
+# Cases of the reference's src variant (src/models/attention/hept.py with the caller-side
+# preparation of src/models/baselines/transformer.py:43-57): one cloud, padded at the end.
+SRC_CASES: Dict[str, dict] = {
+    # S1: small, 24 padding rows, everything stored
+    "s1_src1000": dict(raw_size=1000, block_size=128, n_hashes=3, coords_dim=6, num_regions=150, seed=201,
+                       qk_scale=0.3, coords_scale=0.1),
+    # S2: block size 100 of the reference's own yaml; raw size a multiple of it (no padding rows)
+    "s2_src5000": dict(raw_size=5000, block_size=100, n_hashes=3, coords_dim=6, num_regions=150, seed=202,
+                       cluster_size=8, qk_scale=0.25, coords_scale=0.3),
+    # S3: pileup shape (C=4, B=256), 187 padding rows
+    "s3_src_pileup": dict(raw_size=2885, block_size=256, n_hashes=3, coords_dim=4, num_regions=140, seed=203,
+                          qk_scale=0.3, coords_scale=0.05),
+}
+
+
+def build_inputs_src(name: str, stored: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, torch.Tensor]:
+    """Inputs of src-variant case ``name``; ``stored`` supplies ``regions`` (the reference's own draw)."""
+    cfg = dict(SRC_CASES[name])
+    stored = stored or {}
+    regions = torch.from_numpy(np.asarray(stored["regions"])).float() if "regions" in stored else None
+    raw_size = cfg.pop("raw_size")
+    inp = make_inputs_src(raw_size, num_heads=NUM_HEADS, h_dim=H_DIM, num_w_per_dist=W_PER_DIST, regions=regions,
+                          **cfg)
+    for key in ("eta_patch", "phi_patch"):  # tie-induced differences from the reference's unstable argsort
+        if key + "_idx" in stored and len(stored[key + "_idx"]):
+            idx = torch.from_numpy(np.asarray(stored[key + "_idx"]).astype(np.int64))
+            inp[key[:3] + "_idx"][tuple(idx.T)] = torch.from_numpy(np.asarray(stored[key + "_val"])).float()
+    inp["block_size"] = cfg["block_size"]
+    inp["w_per_dist"] = W_PER_DIST
+    return inp
+
+
+def load_case_src(name: str):
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    with np.load(path) as z:
+        fx = {k: z[k] for k in z.files}
+    return build_inputs_src(name, fx), fx
 
 
 def build_inputs(name: str, stored: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, torch.Tensor]:
@@ -122,7 +160,10 @@ def input_checksums(inp: Dict[str, torch.Tensor]) -> np.ndarray:
         t = inp[key].double().flatten()
         w = torch.arange(1, t.numel() + 1, dtype=torch.float64) % 8191
         vals.append(float((t * w).sum()))
-    vals.append(float(inp["combined_shifts"].double().sum()))
+    if "combined_shifts" in inp:
+        vals.append(float(inp["combined_shifts"].double().sum()))
+    else:
+        vals.append(float(inp["eta_idx"].double().sum() + 3 * inp["phi_idx"].double().sum()))
     return np.asarray(vals, dtype=np.float64)
 
 
