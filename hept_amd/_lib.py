@@ -11,7 +11,7 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p
 
 from .build import LIB_PATH
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_F32, PREC_BF16, PREC_MIXED16 = 0, 1, 2
 ROW = 32
 MAX_TABLES = 8
@@ -39,12 +39,12 @@ SIGNATURES = {
     "hept_segmented_argsort": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "hept_block_attn": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P]),
     "hept_part_precision": (c_int, [c_int, c_int]),
-    "hept_reduce_tables": (c_int, [_P] + [c_int] * 5 + [_P, _P]),
+    "hept_reduce_tables": (c_int, [_P] + [c_int] * 5 + [_P, c_int, _P]),
     "hept_combine_out": (c_int, [_P] + [c_int] * 7 + [_P] * 4),
     "hept_forward": (c_int, [_P] * 9 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
-    "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
+    "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 11 + [_P, c_size_t, _P, _P]),
     "hept_forward_src": (c_int, [_P] * 7 + [c_int] + [_P] * 4 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
-    "hept_forward_partial_src": (c_int, [_P] * 7 + [c_int] + [_P] * 2 + [c_int] * 10 + [_P, c_size_t, _P, _P]),
+    "hept_forward_partial_src": (c_int, [_P] * 7 + [c_int] + [_P] * 2 + [c_int] * 11 + [_P, c_size_t, _P, _P]),
     "hept_block_attn_bwd": (c_int, [_P] * 5 + [c_int] * 5 + [_P] * 3),
     "hept_bwd_reduce": (c_int, [_P, _P] + [c_int] * 5 + [_P] * 5),
     "hept_prepare_workspace_bytes": (c_size_t, [c_int] * 5),

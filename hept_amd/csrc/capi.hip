@@ -97,7 +97,7 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 6; }
+extern "C" int hept_abi_version(void) { return 7; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -139,21 +139,22 @@ int forward_impl(const float* q, const float* k, const float* v, const float* co
 
 int forward_partial_impl(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
                          const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C,
-                         int K, int T, int t0, int Tl, int B, int precision, void* workspace, size_t workspace_bytes,
-                         float* acc, void* stream) {
+                         int K, int T, int t0, int Tl, int B, int precision, int acc_precision, void* workspace,
+                         size_t workspace_bytes, float* acc, void* stream) {
     if (!q || !k || !v || !coords || !w_rpe || !alpha || !workspace || !acc) return HEPT_ERR_ARG;
     int rc = hept_check_shape(N, H, D, C, Tl, B);
     if (rc) return rc;
     if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (acc_precision != HEPT_PREC_F32 && acc_precision != hept_part_precision(precision, D)) return HEPT_ERR_SHAPE;
     const Workspace w = carve(workspace, N, H, C, Tl, precision);
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
-    // one local table in the f32 row format: block_attn scatters straight into acc, no reduction pass
+    // one local table already in the requested row format: block_attn scatters straight into acc, no reduction pass
     const int pprec = hept_part_precision(precision, D);
-    const bool direct = Tl == 1 && pprec == HEPT_PREC_F32;
+    const bool direct = Tl == 1 && pprec == acc_precision;
     float* part = direct ? acc : w.part;
     rc = run_tables(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B, precision, w, part,
                     stream);
-    if (!rc && !direct) rc = hept_reduce_tables(w.part, pprec, Tl, N, H, D, acc, stream);
+    if (!rc && !direct) rc = hept_reduce_tables(w.part, pprec, Tl, N, H, D, acc, acc_precision, stream);
     prof_mark(4, (hipStream_t)stream);
     prof_call_done();
     return rc;
@@ -172,10 +173,11 @@ extern "C" int hept_forward(const float* q, const float* k, const float* v, cons
 extern "C" int hept_forward_partial(const float* q, const float* k, const float* v, const float* coords,
                                     const int64_t* codes, const float* w_rpe, const float* alpha, int N, int H,
                                     int D, int C, int K, int T, int t0, int Tl, int B, int precision,
-                                    void* workspace, size_t workspace_bytes, float* acc, void* stream) {
+                                    int acc_precision, void* workspace, size_t workspace_bytes, float* acc,
+                                    void* stream) {
     if (!codes) return HEPT_ERR_ARG;
     return forward_partial_impl(q, k, v, coords, codes, GeoShift{}, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B,
-                                precision, workspace, workspace_bytes, acc, stream);
+                                precision, acc_precision, workspace, workspace_bytes, acc, stream);
 }
 
 extern "C" int hept_forward_src(const float* q, const float* k, const float* v, const float* coords,
@@ -192,12 +194,13 @@ extern "C" int hept_forward_src(const float* q, const float* k, const float* v, 
 extern "C" int hept_forward_partial_src(const float* q, const float* k, const float* v, const float* coords,
                                         const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
                                         const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K,
-                                        int T, int t0, int Tl, int B, int precision, void* workspace,
-                                        size_t workspace_bytes, float* acc, void* stream) {
+                                        int T, int t0, int Tl, int B, int precision, int acc_precision,
+                                        void* workspace, size_t workspace_bytes, float* acc, void* stream) {
     if (!eta_idx || !phi_idx || !cfac) return HEPT_ERR_ARG;
     if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
     return forward_partial_impl(q, k, v, coords, nullptr, GeoShift{eta_idx, phi_idx, cfac, raw_size}, w_rpe, alpha, N,
-                                H, D, C, K, T, t0, Tl, B, precision, workspace, workspace_bytes, acc, stream);
+                                H, D, C, K, T, t0, Tl, B, precision, acc_precision, workspace, workspace_bytes, acc,
+                                stream);
 }
 
 extern "C" int hept_profile_enable(int mode, int max_calls) {

@@ -156,8 +156,10 @@ __device__ __forceinline__ void load_half_row(const float* __restrict__ row, int
     }
 }
 
-// acc (N,H,32) f32 = sum over tables; P16 input rows are widened (denominator moves to column D)
-template <bool P16>
+// acc = sum over tables.  OUT16 = false: (N,H,32) f32 rows, P16 input rows are widened (denominator moves to
+// column D).  OUT16 = true (P16 input only): the sum is stored again as a packed 64-B row (numerators rounded to
+// bf16 once more, denominator exact f32) -- the form table sharding exchanges between GPUs.
+template <bool P16, bool OUT16>
 __global__ __launch_bounds__(256) void reduce_tables_kernel(const float* __restrict__ part, int Tl, int D,
                                                             size_t n_rows, float* __restrict__ acc) {
     constexpr int ROWF = P16 ? 16 : 32;
@@ -173,17 +175,33 @@ __global__ __launch_bounds__(256) void reduce_tables_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 16; ++u) s[u] += x[u];
         }
-        f32x4* dst = reinterpret_cast<f32x4*>(acc + row * 32 + 16 * hh);
+        if constexpr (OUT16) {
+            u32x4* dst = reinterpret_cast<u32x4*>(acc + row * 16 + 8 * hh);
+            if (hh == 0) {
+                dst[0] = u32x4{hept_pack_bf16(s[0], s[1]), hept_pack_bf16(s[2], s[3]), hept_pack_bf16(s[4], s[5]),
+                               hept_pack_bf16(s[6], s[7])};
+                dst[1] = u32x4{hept_pack_bf16(s[8], s[9]), hept_pack_bf16(s[10], s[11]), hept_pack_bf16(s[12], s[13]),
+                               hept_pack_bf16(s[14], s[15])};
+            } else {  // widened columns 16..23 = numerators, 24 = denominator
+                dst[0] = u32x4{hept_pack_bf16(s[0], s[1]), hept_pack_bf16(s[2], s[3]), hept_pack_bf16(s[4], s[5]),
+                               hept_pack_bf16(s[6], s[7])};
+                dst[1] = u32x4{__float_as_uint(s[8]), 0u, 0u, 0u};
+            }
+        } else {
+            f32x4* dst = reinterpret_cast<f32x4*>(acc + row * 32 + 16 * hh);
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) dst[c4] = f32x4{s[4 * c4], s[4 * c4 + 1], s[4 * c4 + 2], s[4 * c4 + 3]};
+            for (int c4 = 0; c4 < 4; ++c4) dst[c4] = f32x4{s[4 * c4], s[4 * c4 + 1], s[4 * c4 + 2], s[4 * c4 + 3]};
+        }
     }
 }
 
 }  // namespace
 
 extern "C" int hept_reduce_tables(const float* part, int part_precision, int Tl, int N, int H, int D, float* acc,
-                                  void* stream) {
+                                  int acc_precision, void* stream) {
     if (!part || !acc) return HEPT_ERR_ARG;
+    if (acc_precision != HEPT_PREC_F32 && !(acc_precision == HEPT_PREC_BF16 && part_precision == HEPT_PREC_BF16))
+        return HEPT_ERR_SHAPE;
     if (Tl < 1 || N < 1 || H < 1 || D < 1 || D > 28) return HEPT_ERR_SHAPE;
     const size_t n_rows = (size_t)N * H;
     const size_t blocks = (n_rows * 2 + 255) / 256;
@@ -191,9 +209,12 @@ extern "C" int hept_reduce_tables(const float* part, int part_precision, int Tl,
     hipStream_t st = (hipStream_t)stream;
     if (part_precision == HEPT_PREC_BF16) {
         if (D != 24) return HEPT_ERR_SHAPE;  // packed rows exist for D == 24 only
-        hipLaunchKernelGGL(reduce_tables_kernel<true>, dim3(grid), dim3(256), 0, st, part, Tl, D, n_rows, acc);
+        if (acc_precision == HEPT_PREC_BF16)
+            hipLaunchKernelGGL((reduce_tables_kernel<true, true>), dim3(grid), dim3(256), 0, st, part, Tl, D, n_rows, acc);
+        else
+            hipLaunchKernelGGL((reduce_tables_kernel<true, false>), dim3(grid), dim3(256), 0, st, part, Tl, D, n_rows, acc);
     } else if (part_precision == HEPT_PREC_F32) {
-        hipLaunchKernelGGL(reduce_tables_kernel<false>, dim3(grid), dim3(256), 0, st, part, Tl, D, n_rows, acc);
+        hipLaunchKernelGGL((reduce_tables_kernel<false, false>), dim3(grid), dim3(256), 0, st, part, Tl, D, n_rows, acc);
     } else {
         return HEPT_ERR_SHAPE;
     }

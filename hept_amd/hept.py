@@ -115,14 +115,16 @@ class HEPTAttention(nn.Module):
                                       **common)
             else:
                 t0, tl = self.sharding.local_tables()
+                packed = self.sharding.packed_ok and ops.packed_partials(self.precision, d)
                 ws = self._scratch(ops.workspace_bytes(n, h, d, c, tl, self.block_size, self.precision), query.device)
                 if src:
                     acc = ops.forward_partial_src(q2, k2, v2, coords.float(), kwargs["region_indices"],
                                                   kwargs["regions_h"], kwargs["raw_size"], w_rpe_weight,
-                                                  self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, **common)
+                                                  self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, packed=packed,
+                                                  **common)
                 else:
                     acc = ops.forward_partial(q2, k2, v2, coords.float(), kwargs["combined_shifts"], w_rpe_weight,
-                                              self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, **common)
+                                              self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, packed=packed, **common)
                 out = self.sharding.finish(
                     acc, lambda part, n0, cnt: ops.combine_out(part, d, self.out_linear.weight,
                                                                self.out_linear.bias, n0, cnt))

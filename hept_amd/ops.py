@@ -15,7 +15,7 @@ from ._lib import PREC_BF16, PREC_F32, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
-    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args",
+    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args", "packed_partials",
 ]
 
 
@@ -173,12 +173,16 @@ def unpack_part(part: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def reduce_tables(part: torch.Tensor, head_dim: int = 24) -> torch.Tensor:
+def reduce_tables(part: torch.Tensor, head_dim: int = 24, packed: bool = False) -> torch.Tensor:
+    """Sum of the per-table partial rows: f32 rows (N,H,32), or with ``packed`` (packed input only) packed rows
+    (N,H,16) int32 again -- the form table sharding sends over xGMI."""
     lib = _lib.load()
     tl, n, h, _ = part.shape
-    acc = torch.empty(n, h, 32, device=part.device, dtype=torch.float32)
+    if packed and part.dtype != torch.int32:
+        raise TypeError("packed sums need packed partial rows (16-bit tiles with head_dim 24)")
+    acc = torch.empty(n, h, 16 if packed else 32, device=part.device, dtype=torch.int32 if packed else torch.float32)
     _lib.check(lib.hept_reduce_tables(part.data_ptr(), _part_prec(part), tl, n, h, head_dim, acc.data_ptr(),
-                                      _stream(part)), "hept_reduce_tables")
+                                      PREC_BF16 if packed else PREC_F32, _stream(part)), "hept_reduce_tables")
     return acc
 
 
@@ -275,9 +279,20 @@ def forward(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *
     return out
 
 
+def packed_partials(precision, head_dim: int) -> bool:
+    """True if (precision, head_dim) produces packed 64-B partial rows (16-bit tiles, head_dim 24)."""
+    return _lib.load().hept_part_precision(precision_code(precision), head_dim) == PREC_BF16
+
+
+def _acc_buffer(n, h, packed, device):
+    return torch.empty(n, h, 16 if packed else 32, device=device, dtype=torch.int32 if packed else torch.float32)
+
+
 def forward_partial(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: int, w_per_dist: int, t0: int,
-                    tl: int, precision="fp32", workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Tables [t0, t0+tl) only: returns acc (N, H, 32) = sum over those tables of [numer | denom]."""
+                    tl: int, precision="fp32", workspace: Optional[torch.Tensor] = None,
+                    packed: bool = False) -> torch.Tensor:
+    """Tables [t0, t0+tl) only: returns acc (N, H, 32) = sum over those tables of [numer | denom]; ``packed``:
+    the same sum as packed rows (N, H, 16) int32 (needs ``packed_partials(precision, D)``)."""
     lib = _lib.load()
     q, k, v, coords, codes, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, codes, w_rpe_weight, alpha,
                                                                 block_size, w_per_dist)
@@ -286,11 +301,11 @@ def forward_partial(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: 
     need = int(lib.hept_workspace_bytes(n, h, d, c, tl, block_size, prec))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
-    acc = torch.empty(n, h, 32, device=q.device, dtype=torch.float32)
+    acc = _acc_buffer(n, h, packed, q.device)
     _lib.check(lib.hept_forward_partial(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), codes.data_ptr(),
                                         w.data_ptr(), alpha.data_ptr(), n, h, d, c, w_per_dist, t, t0, tl, block_size,
-                                        prec, workspace.data_ptr(), workspace.numel(), acc.data_ptr(), _stream(q)),
-               "hept_forward_partial")
+                                        prec, PREC_BF16 if packed else PREC_F32, workspace.data_ptr(),
+                                        workspace.numel(), acc.data_ptr(), _stream(q)), "hept_forward_partial")
     return acc
 
 
@@ -320,7 +335,7 @@ def forward_src(q, k, v, coords, region_indices, regions_h, raw_size: int, w_rpe
 
 def forward_partial_src(q, k, v, coords, region_indices, regions_h, raw_size: int, w_rpe_weight, alpha, *,
                         block_size: int, w_per_dist: int, t0: int, tl: int, precision="fp32",
-                        workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        workspace: Optional[torch.Tensor] = None, packed: bool = False) -> torch.Tensor:
     """src variant, tables [t0, t0+tl) only: acc (N, H, 32) = sum over those tables of [numer | denom]."""
     lib = _lib.load()
     q, k, v, coords, _, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, None, w_rpe_weight, alpha, block_size,
@@ -331,12 +346,13 @@ def forward_partial_src(q, k, v, coords, region_indices, regions_h, raw_size: in
     need = int(lib.hept_workspace_bytes(n, h, d, c, tl, block_size, prec))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
-    acc = torch.empty(n, h, 32, device=q.device, dtype=torch.float32)
+    acc = _acc_buffer(n, h, packed, q.device)
     _lib.check(lib.hept_forward_partial_src(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(),
                                             eta.data_ptr(), phi.data_ptr(), cfac.data_ptr(), int(raw_size),
                                             w.data_ptr(), alpha.data_ptr(), n, h, d, c, w_per_dist, t, t0, tl,
-                                            block_size, prec, workspace.data_ptr(), workspace.numel(),
-                                            acc.data_ptr(), _stream(q)), "hept_forward_partial_src")
+                                            block_size, prec, PREC_BF16 if packed else PREC_F32,
+                                            workspace.data_ptr(), workspace.numel(), acc.data_ptr(), _stream(q)),
+               "hept_forward_partial_src")
     return acc
 
 

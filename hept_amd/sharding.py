@@ -7,11 +7,16 @@ slice of tables, computes ``acc_r (N, H, 32) = sum_t [numer | denom]`` with the
 HIP kernels, and the ranks then sum ``acc`` with ONE exchange step over
 RCCL/xGMI:
 
-* ``mode="reduce_scatter"`` (default on NCCL/RCCL): reduce-scatter over point
-  slices -> every rank divides and applies ``out_linear`` on its N/G slice ->
-  all-gather of the (N, D) output.  Moves (G-1)/G * (|acc| + |out|) per rank
-  instead of 2 (G-1)/G |acc| for a ring all-reduce; xGMI is point-to-point, so
-  per-link bytes are what matters.
+* ``mode="all_to_all"`` (default on NCCL/RCCL): every rank sends point slice g
+  of its ``acc`` straight to rank g (one all-to-all: G-1 concurrent
+  point-to-point transfers per rank, one per xGMI link, no ring), rank g sums
+  the G slices it received inside the HIP ``combine_out`` kernel (they are read
+  as G "tables"), divides, applies ``out_linear`` on its N/G points, and an
+  all-gather distributes the (N, D) output.  ``acc`` travels in the row format
+  the caller chose: with the 16-bit tile modes the packed 64-B rows (bf16
+  numerators, f32 denominator) halve the bytes on the links.
+* ``mode="reduce_scatter"``: the same split with RCCL's reduce-scatter doing the
+  sum (f32 rows only).
 * ``mode="all_reduce"``: all-reduce of ``acc``, every rank finishes all points
   (used on backends without reduce-scatter, e.g. gloo in the CPU tests).
 
@@ -48,9 +53,11 @@ class TableSharding:
         self.world = dist.get_world_size(group)
         self.n_tables = n_tables
         backend = dist.get_backend(group)
-        self.mode = mode or ("reduce_scatter" if backend == "nccl" else "all_reduce")
-        if self.mode not in ("reduce_scatter", "all_reduce"):
+        self.mode = mode or ("all_to_all" if backend == "nccl" else "all_reduce")
+        if self.mode not in ("all_to_all", "reduce_scatter", "all_reduce"):
             raise ValueError(f"unknown mode {self.mode}")
+        if self.mode == "all_to_all" and self.world > 8:
+            raise ValueError("all_to_all mode sums at most 8 received slices (one node)")
         table_slice(n_tables, self.rank, self.world)  # validate
 
     def local_tables(self) -> Tuple[int, int]:
@@ -63,26 +70,39 @@ class TableSharding:
         n0 = min(rank * per, n_points)
         return n0, min(per, n_points - n0)
 
-    def finish(self, acc: torch.Tensor, finish_fn: Callable[[torch.Tensor, int, int], torch.Tensor]) -> torch.Tensor:
-        """Sum ``acc`` (N, H, 32) over the ranks; return the full (N, D) output on every rank.
+    @property
+    def packed_ok(self) -> bool:
+        """Whether ``finish`` accepts packed (int32) rows: only the all-to-all moves them without arithmetic."""
+        return self.mode == "all_to_all"
 
-        ``finish_fn(part, n0, count)`` turns summed partials into outputs: it reads rows
-        ``part[n0 : n0 + count]`` and returns ``(count, D)`` (``count`` may be 0).
+    def finish(self, acc: torch.Tensor, finish_fn: Callable[[torch.Tensor, int, int], torch.Tensor]) -> torch.Tensor:
+        """Sum ``acc`` (N, H, row) over the ranks; return the full (N, D) output on every rank.
+
+        ``finish_fn(part, n0, count)`` turns partial rows into outputs: ``part`` is (N', H, row) or a stack
+        (G, N', H, row) whose leading dimension it has to sum; it reads rows ``[n0, n0 + count)`` and returns
+        ``(count, D)`` (``count`` may be 0).
         """
         n = acc.shape[0]
         if self.world == 1 and not self.always_exchange:
             return finish_fn(acc, 0, n)
+        if self.mode != "all_to_all" and acc.dtype != torch.float32:
+            raise TypeError(f"mode {self.mode} sums inside the collective and needs f32 rows")
         if self.mode == "all_reduce":
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
             return finish_fn(acc, 0, n)
         per = (n + self.world - 1) // self.world
         padded = per * self.world
-        if padded != n:  # reduce_scatter_tensor needs equal shards
+        if padded != n:  # the collectives need equal shards
             acc = torch.cat([acc, acc.new_zeros((padded - n,) + tuple(acc.shape[1:]))], dim=0)
-        mine = torch.empty((per,) + tuple(acc.shape[1:]), device=acc.device, dtype=acc.dtype)
-        dist.reduce_scatter_tensor(mine, acc, op=dist.ReduceOp.SUM, group=self.group)
         _, cnt = self.point_slice(n)
-        out_slice = finish_fn(mine, 0, cnt)
+        if self.mode == "all_to_all":
+            recv = torch.empty((self.world, per) + tuple(acc.shape[1:]), device=acc.device, dtype=acc.dtype)
+            dist.all_to_all_single(recv, acc, group=self.group)  # recv[g] = rank g's rows of my point slice
+            out_slice = finish_fn(recv, 0, cnt)
+        else:
+            mine = torch.empty((per,) + tuple(acc.shape[1:]), device=acc.device, dtype=acc.dtype)
+            dist.reduce_scatter_tensor(mine, acc, op=dist.ReduceOp.SUM, group=self.group)
+            out_slice = finish_fn(mine, 0, cnt)
         d = out_slice.shape[1]
         if cnt != per:
             out_slice = torch.cat([out_slice, out_slice.new_zeros((per - cnt, d))], dim=0)

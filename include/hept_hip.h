@@ -112,10 +112,11 @@ int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, co
  * HEPT_PREC_F32. */
 int hept_part_precision(int precision, int D);
 
-/* acc = sum_t part[t], widened to the f32 row format (table-sharded ranks reduce `acc` across GPUs
- * afterwards). */
+/* acc = sum_t part[t] (table-sharded ranks exchange `acc` between GPUs afterwards).  acc_precision
+ * HEPT_PREC_F32: f32 rows (N, H, 32).  HEPT_PREC_BF16 (packed input only): packed 64-B rows again
+ * (numerators rounded to bf16 once more, denominators exact) -- half the bytes on the xGMI links. */
 int hept_reduce_tables(const float* part, int part_precision, int Tl, int N, int H, int D, float* acc,
-                       void* stream);
+                       int acc_precision, void* stream);
 
 /* replaces the cross-table combine (example/hept.py:79) and out_linear (:80) for points
  * [n0, n0+n_count): out[n] = bias + W . (sum_t numer / sum_t denom).  `part` may hold Tl >= 1
@@ -125,7 +126,8 @@ int hept_combine_out(const float* part, int part_precision, int Tl, int N, int H
                      void* stream);
 
 /* Whole operator for tables [t0, t0+Tl): everything above in one call.
- * hept_forward writes out (N, D); hept_forward_partial stops at acc (N, H, 32). */
+ * hept_forward writes out (N, D); hept_forward_partial stops at acc (N, H, row) in the row format
+ * acc_precision (HEPT_PREC_F32, or hept_part_precision(precision, D)). */
 int hept_forward(const float* q, const float* k, const float* v, const float* coords,
                  const int64_t* codes, const float* w_rpe, const float* alpha,
                  const float* out_weight, const float* out_bias,
@@ -134,8 +136,8 @@ int hept_forward(const float* q, const float* k, const float* v, const float* co
 int hept_forward_partial(const float* q, const float* k, const float* v, const float* coords,
                          const int64_t* codes, const float* w_rpe, const float* alpha,
                          int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
-                         int precision, void* workspace, size_t workspace_bytes, float* acc,
-                         void* stream);
+                         int precision, int acc_precision, void* workspace, size_t workspace_bytes,
+                         float* acc, void* stream);
 
 /* SURVEY.md §8 f-3 — the reference's src variant of the same operator (src/models/attention/hept.py:74-117, caller
  * src/models/baselines/transformer.py:43-57): no AND codes; the sort key is hash + get_geo_shift (see
@@ -150,8 +152,8 @@ int hept_forward_partial_src(const float* q, const float* k, const float* v, con
                              const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
                              const float* w_rpe, const float* alpha,
                              int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
-                             int precision, void* workspace, size_t workspace_bytes, float* acc,
-                             void* stream);
+                             int precision, int acc_precision, void* workspace, size_t workspace_bytes,
+                             float* acc, void* stream);
 
 /* SURVEY.md §8 f-2 — backward of the block attention (the reference trains through example/hept.py:55-80 with
  * plain autograd; there is no custom backward to mirror).  f32 tiles only.  gacc (N, H, 32) f32 is the

@@ -2,7 +2,8 @@
 
 The per-rank partials are produced by the ORACLE here (there is no GPU in this container and the
 product has no CPU compute path); what is under test is the product's sharding logic: table slices,
-the exchange step (all-reduce / reduce-scatter + all-gather), point slices and the finishing call.
+the exchange step (all-reduce / reduce-scatter + all-gather / all-to-all of f32 or packed rows + all-gather),
+point slices and the finishing call.
 """
 import os
 import socket
@@ -14,6 +15,7 @@ import torch.multiprocessing as mp
 
 import cases
 import hept_oracle as ho
+from hept_amd.ops import unpack_part
 from hept_amd.sharding import TableSharding, table_slice
 
 
@@ -47,10 +49,24 @@ def _acc_from_oracle(inp, t0, tl):
     return acc
 
 
+def _pack_rows(acc):
+    """f32 rows (N,H,32) -> the packed 64-B row format of the 16-bit HIP modes: (N,H,16) int32 =
+    [24 bf16 numerators | f32 denominator | 0] (include/hept_hip.h, hept_part_precision)."""
+    n, h, _ = acc.shape
+    bits = acc[..., :24].to(torch.bfloat16).view(torch.int16).to(torch.int32) & 0xFFFF
+    out = torch.zeros(n, h, 16, dtype=torch.int32)
+    out[..., :12] = bits[..., 0::2] | (bits[..., 1::2] << 16)
+    out[..., 12] = acc[..., 24].contiguous().view(torch.int32)
+    return out
+
+
 def _finish_cpu(inp):
     d = inp["out_weight"].shape[0]
 
     def fn(part, n0, cnt):
+        part = unpack_part(part)          # packed rows -> f32 rows (no-op for f32)
+        if part.dim() == 4:               # all_to_all: one slice per source rank, summed here
+            part = part.sum(0)
         rows = part[n0:n0 + cnt]
         per_head = rows[..., :d] / rows[..., d:d + 1]
         return torch.nn.functional.linear(per_head.reshape(cnt, -1), inp["out_weight"], inp["out_bias"])
@@ -66,10 +82,14 @@ def _worker(rank, world, port, mode, name, ret):
         torch.set_num_threads(2)
         inp, _ = cases.load_case(name)
         n_tables = inp["alpha"].shape[2]
-        sh = TableSharding(n_tables, dist.group.WORLD, mode=mode)
+        sh = TableSharding(n_tables, dist.group.WORLD, mode="all_to_all" if mode == "all_to_all_packed" else mode)
         t0, tl = sh.local_tables()
         acc = _acc_from_oracle(inp, t0, tl)
-        if mode == "reduce_scatter":
+        packed = mode == "all_to_all_packed"
+        if packed:
+            acc, mode = _pack_rows(acc), "all_to_all"
+            sh.mode = "all_to_all"
+        if mode in ("reduce_scatter", "all_to_all"):
             # gloo has no reduce_scatter: emulate the collective pair so that the slicing / padding /
             # gather logic of TableSharding.finish still runs end to end
             orig_rs, orig_ag = dist.reduce_scatter_tensor, dist.all_gather_into_tensor
@@ -87,7 +107,7 @@ def _worker(rank, world, port, mode, name, ret):
 
             dist.reduce_scatter_tensor, dist.all_gather_into_tensor = rs, ag
         out = sh.finish(acc, _finish_cpu(inp))
-        if mode == "reduce_scatter":
+        if mode in ("reduce_scatter", "all_to_all"):
             dist.reduce_scatter_tensor, dist.all_gather_into_tensor = orig_rs, orig_ag
         if rank == 0:
             ret["out"] = out.clone()
@@ -100,16 +120,24 @@ def _worker(rank, world, port, mode, name, ret):
 
 
 @pytest.mark.parametrize("mode,name", [("all_reduce", "g6_block100"), ("reduce_scatter", "g6_block100"),
-                                       ("all_reduce", "g1_rand512")])
+                                       ("all_reduce", "g1_rand512"), ("all_to_all", "g6_block100"),
+                                       ("all_to_all_packed", "g6_block100")])
 def test_two_rank_table_sharding_matches_single_process(mode, name):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), mode, name, ret), nprocs=world, join=True)
     inp, _ = cases.load_case(name)
+    assert ret["same_on_all_ranks"]
+    if mode == "all_to_all_packed":
+        # expected: every rank's sum rounded to the packed row format once, then summed and finished
+        n_tables = inp["alpha"].shape[2]
+        accs = [unpack_part(_pack_rows(_acc_from_oracle(inp, *table_slice(n_tables, r, world)))) for r in range(world)]
+        want = _finish_cpu(inp)(torch.stack(accs), 0, accs[0].shape[0])
+        torch.testing.assert_close(ret["out"], want, rtol=1e-5, atol=1e-6)
+        return
     ref = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
                      inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=inp["block_size"],
                      w_per_dist=inp["w_per_dist"], keep=False)["out"]
-    assert ret["same_on_all_ranks"]
     # the sharded sum adds the same per-table terms in a different association: fp32 round-off only
     torch.testing.assert_close(ret["out"], ref, rtol=1e-5, atol=1e-6)
