@@ -102,7 +102,21 @@ class HEPTAttention(nn.Module):
             q2 = query.reshape(n, h * d).float()
             k2 = key.reshape(n, h * d).float()
             v2 = value.reshape(n, h * d).float()
-            if self.sharding is None:
+            if self.sharding is None and torch.compiler.is_compiling():
+                # one opaque graph node instead of a ctypes call Dynamo cannot trace (hept_amd/library.py)
+                from .library import forward_op, forward_src_op
+
+                if src:
+                    eta, phi = kwargs["region_indices"]
+                    out = forward_src_op(q2, k2, v2, coords.float(), eta, phi, kwargs["regions_h"],
+                                         int(kwargs["raw_size"]), w_rpe_weight, self.e2lsh.alpha,
+                                         self.out_linear.weight, self.out_linear.bias, self.block_size,
+                                         self.num_w_per_dist, self.precision)
+                else:
+                    out = forward_op(q2, k2, v2, coords.float(), kwargs["combined_shifts"], w_rpe_weight,
+                                     self.e2lsh.alpha, self.out_linear.weight, self.out_linear.bias, self.block_size,
+                                     self.num_w_per_dist, self.precision)
+            elif self.sharding is None:
                 ws = self._scratch(ops.workspace_bytes(n, h, d, c, self.n_hashes, self.block_size, self.precision),
                                    query.device)
                 if src:

@@ -89,3 +89,28 @@ def test_module_refuses_cpu_tensors():
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
         m(q, q, q, w_rpe=torch.nn.Linear(50, 192), coords=torch.zeros(128, 6),
           combined_shifts=torch.zeros(2, 8, 128, dtype=torch.int64))
+
+
+def test_custom_ops_trace_with_fake_tensors():
+    """torch.library registration (hept_amd/library.py): under FakeTensorMode the ops run their shape-only kernels,
+    so a compiler can capture the operator as one node without touching the GPU library."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from hept_amd import library  # noqa: F401  (registers the ops)
+
+    with FakeTensorMode():
+        n = 1024
+        f = lambda *s, dt=torch.float32: torch.empty(*s, device="cuda", dtype=dt)  # noqa: E731
+        out = torch.ops.hept_amd.forward(f(n, 192), f(n, 192), f(n, 192), f(n, 6), f(3, 8, n, dt=torch.int64),
+                                         f(192, 50), f(8, 30, 3), f(24, 192), f(24), 128, 10, "bf16")
+        assert tuple(out.shape) == (n, 24) and out.dtype == torch.float32 and out.device.type == "cuda"
+        out = torch.ops.hept_amd.forward_src(f(n, 192), f(n, 192), f(n, 192), f(n, 6), f(24, n), f(24, n), f(2, 24),
+                                             1000, f(192, 50), f(8, 30, 3), f(24, 192), None, 128, 10, "fp32")
+        assert tuple(out.shape) == (n, 24)
+    # no CPU kernel is registered: CPU tensors are refused by the dispatcher
+    import pytest
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.hept_amd.forward(torch.zeros(128, 192), torch.zeros(128, 192), torch.zeros(128, 192),
+                                   torch.zeros(128, 6), torch.zeros(3, 8, 128, dtype=torch.int64), torch.zeros(192, 50),
+                                   torch.zeros(8, 30, 3), torch.zeros(24, 192), None, 128, 10, "fp32")

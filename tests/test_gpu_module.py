@@ -17,6 +17,8 @@ def _module(inp, dev, **extra):
     m = HEPTAttention(e, h_dim=d, num_heads=h, block_size=inp["block_size"], n_hashes=t, num_w_per_dist=10,
                       n_layers=4, num_regions=150, pe_type="none", **extra)
     sd = {"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"], "e2lsh.alpha": inp["alpha"]}
+    if extra.get("variant") == "src":
+        sd["e2lsh.beta"] = torch.zeros(1, t)
     m.load_state_dict(sd, strict=True)
     w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0])
     with torch.no_grad():
@@ -61,3 +63,31 @@ def test_module_bf16_and_errors(gpu_device):
           combined_shifts=g["combined_shifts"][..., :150])
     with pytest.raises(ValueError):
         HEPTAttention(30, h_dim=24, num_heads=8, block_size=64, n_hashes=2, num_w_per_dist=10, precision="fp8")
+
+
+@pytest.mark.parametrize("variant", ["example", "src"])
+def test_module_under_torch_compile_is_one_graph(variant, gpu_device):
+    """torch.compile(model) as in example/example.ipynb:161: with the operator registered through torch.library
+    Dynamo captures the module call as ONE graph (fullgraph=True raises on any graph break) and the compiled
+    module returns what the eager one returns.  backend='aot_eager': capture + functionalisation, no codegen."""
+    import torch._dynamo
+
+    if variant == "example":
+        inp, _ = cases.load_case("g1_rand512")
+        extra = dict(combined_shifts=inp["combined_shifts"].to(gpu_device))
+    else:
+        inp, _ = cases.load_case_src("s1_src1000")
+        extra = dict(raw_size=inp["raw_size"], regions_h=inp["regions_h"].to(gpu_device),
+                     region_indices=[inp["eta_idx"].to(gpu_device), inp["phi_idx"].to(gpu_device)])
+    m, w_rpe = _module(inp, gpu_device, **({"variant": "src"} if variant == "src" else {}))
+    q, k, v, coords = (inp[x].to(gpu_device) for x in ("q", "k", "v", "coords"))
+
+    def run(mod):
+        with torch.no_grad():
+            return mod(q, k, v, w_rpe=w_rpe, coords=coords, **extra)
+
+    eager = run(m)
+    torch._dynamo.reset()
+    compiled = torch.compile(m, backend="aot_eager", fullgraph=True)
+    out = run(compiled)
+    assert torch.equal(out, eager)
