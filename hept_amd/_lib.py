@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 
 from .build import LIB_PATH
 
@@ -43,6 +43,9 @@ SIGNATURES = {
     "hept_combine_out": (c_int, [_P] + [c_int] * 7 + [_P] * 4),
     "hept_forward": (c_int, [_P] * 9 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_partial": (c_int, [_P] * 7 + [c_int] * 11 + [_P, c_size_t, _P, _P]),
+    "hept_prep_hash_fused": (c_int, [_P] * 3 + [c_float] + [_P] * 7 + [c_int] * 9 + [_P] * 6),
+    "hept_combine_ffn": (c_int, [_P] + [c_int] * 7 + [_P] * 5 + [c_float] + [_P] * 6),
+    "hept_attn_block_forward": (c_int, [_P] * 4 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_src": (c_int, [_P] * 7 + [c_int] + [_P] * 4 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_partial_src": (c_int, [_P] * 7 + [c_int] + [_P] * 2 + [c_int] * 11 + [_P, c_size_t, _P, _P]),
     "hept_block_attn_bwd": (c_int, [_P] * 5 + [c_int] * 5 + [_P] * 3),
@@ -77,6 +80,14 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(f"libhept_hip.so ABI version {got}, Python binding expects {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
+
+
+class AttnParams(ctypes.Structure):
+    """``hept_attn_params`` of include/hept_hip.h."""
+
+    _fields_ = [(name, c_void_p) for name in (
+        "norm1_w", "norm1_b", "w_q", "w_k", "w_v", "w_rpe", "alpha", "out_w", "out_b", "norm2_w", "norm2_b",
+        "ff1_w", "ff1_b", "ff2_w", "ff2_b")] + [("eps1", c_float), ("eps2", c_float)]
 
 
 def check(rc: int, what: str) -> None:

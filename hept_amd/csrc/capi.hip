@@ -203,6 +203,43 @@ extern "C" int hept_forward_partial_src(const float* q, const float* k, const fl
                                 stream);
 }
 
+extern "C" int hept_attn_block_forward(const float* x, const float* coords, const int64_t* codes,
+                                       const hept_attn_params* p, int N, int H, int D, int C, int K, int T, int B,
+                                       int precision, void* workspace, size_t workspace_bytes, float* y,
+                                       void* stream) {
+    if (!x || !coords || !codes || !p || !workspace || !y) return HEPT_ERR_ARG;
+    if (!p->norm1_w || !p->norm1_b || !p->w_q || !p->w_k || !p->w_v || !p->w_rpe || !p->alpha || !p->out_w ||
+        !p->norm2_w || !p->norm2_b || !p->ff1_w || !p->ff1_b || !p->ff2_w || !p->ff2_b)
+        return HEPT_ERR_ARG;
+    int rc = hept_check_shape(N, H, D, C, T, B);
+    if (rc) return rc;
+    if (D != 24) return HEPT_ERR_SHAPE;
+    const Workspace w = carve(workspace, N, H, C, T, precision);
+    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    prof_mark(0, st);
+    rc = hept_rpe_scale(p->w_rpe, H, D, C, K, w.sqrt_w, stream);
+    if (rc) return rc;
+    rc = hept_prep_hash_fused(x, p->norm1_w, p->norm1_b, p->eps1, p->w_q, p->w_k, p->w_v, coords, w.sqrt_w, p->alpha,
+                              codes, N, N, H, D, C, T, 0, T, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax,
+                              stream);
+    if (rc) return rc;
+    int32_t* qpos = w.pos;
+    int32_t* kpos = w.pos + (size_t)T * H * N;
+    prof_mark(1, st);
+    rc = hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, 0, T, w.sort_ws, qpos, kpos, stream);
+    if (rc) return rc;
+    prof_mark(2, st);
+    rc = hept_block_attn(w.qhat, w.kvhat, qpos, kpos, N, H, D, T, B, precision, w.part, stream);
+    if (rc) return rc;
+    prof_mark(3, st);
+    rc = hept_combine_ffn(w.part, hept_part_precision(precision, D), T, N, H, D, 0, N, p->out_w, p->out_b, x,
+                          p->norm2_w, p->norm2_b, p->eps2, p->ff1_w, p->ff1_b, p->ff2_w, p->ff2_b, y, stream);
+    prof_mark(4, st);
+    prof_call_done();
+    return rc;
+}
+
 extern "C" int hept_profile_enable(int mode, int max_calls) {
     if (mode < 0 || mode > 2 || max_calls < 0) return HEPT_ERR_ARG;
     if (g_prof.ev) {

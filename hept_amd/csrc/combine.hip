@@ -62,12 +62,28 @@ struct RawRow {
 // head pair are requested before the current pair is reduced (the kernel runs at ~2 waves per SIMD, so the
 // overlap has to come from inside the wave).  Tables are summed in the reference's order (t = 0, 1, ...);
 // the division is one correctly rounded reciprocal per row followed by multiplies (<= 1 ulp from a/b).
-template <bool P16>
+// FFN = true (SURVEY.md §8 f-4, D = 24): the rest of the Attn block in the epilogue (example/transformer.py:161-165,
+// eval mode: dropout is the identity): y1 = x + aggr; y = y1 + ff.2(relu(ff.0(norm2(y1)))).  The 32 x D tile of
+// aggregated rows goes through a wave-private LDS tile so that lane (point, half) holds a whole row; each half
+// computes 12 hidden and 12 output units (weights are LDS broadcasts), the halves swap hidden units by shuffle.
+struct FfnIn {
+    const float* x;      // (n_count, D) block input rows, row n0 first
+    const float* ln_w;   // norm2.weight, norm2.bias
+    const float* ln_b;
+    const float* w1;     // ff.0.weight (D, D), ff.0.bias
+    const float* b1;
+    const float* w2;     // ff.2.weight (D, D), ff.2.bias
+    const float* b2;
+    float eps;
+};
+constexpr int FFN_D = 24, FFN_PITCH = 25, FFN_WFLOATS = 2 * FFN_D * FFN_D + 4 * FFN_D;
+
+template <bool P16, bool FFN = false>
 __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
                                                                   int H, int D, int n0, int n_count,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ bias,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, FfnIn ffn = FfnIn{}) {
     constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
     constexpr int TMAX = HEPT_MAX_TABLES;
     extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H (even-padded)][28 (d)][32 (c, zero padded)]
@@ -78,6 +94,20 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         wt_s[i] = (c < D && d < D && h < H) ? W[(size_t)c * HD + h * D + d] : 0.f;  // W is (D, H*D) row-major
     }
     const float bia = (li < D && bias) ? bias[li] : 0.f;
+    float* ffn_s = wt_s + HP * 28 * 32;                        // [w1 | w2 | b1 | b2 | ln_w | ln_b]
+    float* stage_s = ffn_s + FFN_WFLOATS + w * 32 * FFN_PITCH;  // this wave's 32 x D tile
+    if constexpr (FFN) {
+        for (int i = tid; i < FFN_D * FFN_D; i += CMB_THREADS) {
+            ffn_s[i] = ffn.w1[i];
+            ffn_s[FFN_D * FFN_D + i] = ffn.w2[i];
+        }
+        if (tid < FFN_D) {
+            ffn_s[2 * FFN_D * FFN_D + tid] = ffn.b1[tid];
+            ffn_s[2 * FFN_D * FFN_D + FFN_D + tid] = ffn.b2[tid];
+            ffn_s[2 * FFN_D * FFN_D + 2 * FFN_D + tid] = ffn.ln_w[tid];
+            ffn_s[2 * FFN_D * FFN_D + 3 * FFN_D + tid] = ffn.ln_b[tid];
+        }
+    }
     __syncthreads();
     const size_t tstride = (size_t)N * H * ROWF;
     const int n_tiles = (n_count + 31) / 32;
@@ -120,10 +150,80 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
 #pragma unroll
             for (int t = 0; t < 3; ++t) cur[t] = nxt[t];
         }
+        if constexpr (FFN) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i2 = tile * 32 + hept_acc_row(r, hh);
-            if (i2 < n_count && li < D) out[(size_t)i2 * D + li] = acc[r] + bia;
+            for (int r = 0; r < 16; ++r)
+                if (li < FFN_D) stage_s[hept_acc_row(r, hh) * FFN_PITCH + li] = acc[r] + bia;
+            // (one wave's LDS accesses execute in order: the tile is complete when the reads below are issued)
+            const bool valid = i < n_count;
+            const f32x4* xs = reinterpret_cast<const f32x4*>(ffn.x + (size_t)(valid ? i : n_count - 1) * FFN_D);
+            float y1[FFN_D];
+#pragma unroll
+            for (int j = 0; j < FFN_D / 4; ++j) {
+                const f32x4 xv = xs[j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) y1[4 * j + u] = xv[u] + stage_s[li * FFN_PITCH + 4 * j + u];
+            }
+            float mean = 0.f;
+#pragma unroll
+            for (int j = 0; j < FFN_D; ++j) mean += y1[j];
+            mean *= 1.0f / FFN_D;
+            float var = 0.f;
+#pragma unroll
+            for (int j = 0; j < FFN_D; ++j) { const float dlt = y1[j] - mean; var = fmaf(dlt, dlt, var); }
+            const float rstd = 1.0f / sqrtf(var * (1.0f / FFN_D) + ffn.eps);
+            const float* g_s = ffn_s + 2 * FFN_D * FFN_D + 2 * FFN_D;
+            float z[FFN_D];
+#pragma unroll
+            for (int j = 0; j < FFN_D; ++j) z[j] = (y1[j] - mean) * rstd * g_s[j] + g_s[FFN_D + j];
+            // hidden units [12 hh, 12 hh + 12) of ff.0 + ReLU
+            float hid[FFN_D];
+#pragma unroll
+            for (int uu = 0; uu < FFN_D / 2; ++uu) {
+                const int u = hh * (FFN_D / 2) + uu;
+                const float* wr = ffn_s + u * FFN_D;
+                float a = ffn_s[2 * FFN_D * FFN_D + u];
+#pragma unroll
+                for (int j = 0; j < FFN_D; ++j) a = fmaf(wr[j], z[j], a);
+                hid[uu] = fmaxf(a, 0.f);
+            }
+            // swap halves: afterwards hid[0..11] = units 0..11, hid[12..23] = units 12..23 in both lanes
+#pragma unroll
+            for (int uu = 0; uu < FFN_D / 2; ++uu) {
+                const float other = __shfl_xor(hid[uu], 32);
+                hid[FFN_D / 2 + uu] = hh ? hid[uu] : other;
+                hid[uu] = hh ? other : hid[uu];
+            }
+            float yo[FFN_D / 2];
+#pragma unroll
+            for (int uu = 0; uu < FFN_D / 2; ++uu) {
+                const int u = hh * (FFN_D / 2) + uu;
+                const float* wr = ffn_s + FFN_D * FFN_D + u * FFN_D;
+                float a = ffn_s[2 * FFN_D * FFN_D + FFN_D + u];
+#pragma unroll
+                for (int j = 0; j < FFN_D; ++j) a = fmaf(wr[j], hid[j], a);
+                yo[uu] = a;
+            }
+            if (valid) {
+                f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)i * FFN_D + hh * (FFN_D / 2));
+#pragma unroll
+                for (int c4 = 0; c4 < FFN_D / 8; ++c4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        // y1[12 hh + 4 c4 + u] with a compile-time index in both halves
+                        const float res = hh ? y1[FFN_D / 2 + 4 * c4 + u] : y1[4 * c4 + u];
+                        o[u] = res + yo[4 * c4 + u];
+                    }
+                    dst[c4] = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i2 = tile * 32 + hept_acc_row(r, hh);
+                if (i2 < n_count && li < D) out[(size_t)i2 * D + li] = acc[r] + bia;
+            }
         }
     }
 }
@@ -235,13 +335,39 @@ extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, i
     hipStream_t st = (hipStream_t)stream;
     if (part_precision == HEPT_PREC_BF16) {
         if (D != 24) return HEPT_ERR_SHAPE;  // packed rows keep the denominator at widened column 24
-        hipLaunchKernelGGL(combine_out_kernel<true>, dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D, n0,
-                           n_count, out_weight, out_bias, out);
+        hipLaunchKernelGGL((combine_out_kernel<true, false>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
+                           n0, n_count, out_weight, out_bias, out, FfnIn{});
     } else if (part_precision == HEPT_PREC_F32) {
-        hipLaunchKernelGGL(combine_out_kernel<false>, dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D, n0,
-                           n_count, out_weight, out_bias, out);
+        hipLaunchKernelGGL((combine_out_kernel<false, false>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
+                           n0, n_count, out_weight, out_bias, out, FfnIn{});
     } else {
         return HEPT_ERR_SHAPE;
     }
+    return hept_launch_status();
+}
+
+extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
+                                int n_count, const float* out_weight, const float* out_bias, const float* x,
+                                const float* norm_w, const float* norm_b, float eps, const float* ff1_w,
+                                const float* ff1_b, const float* ff2_w, const float* ff2_b, float* y, void* stream) {
+    if (!part || !out_weight || !x || !norm_w || !norm_b || !ff1_w || !ff1_b || !ff2_w || !ff2_b || !y)
+        return HEPT_ERR_ARG;
+    if (Tl < 1 || N < 1 || H < 1 || H > 15 || D != FFN_D || n0 < 0 || n_count < 0 || n0 + n_count > N)
+        return HEPT_ERR_SHAPE;
+    if (n_count == 0) return HEPT_OK;
+    const size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * 32 + FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH);
+    const int n_tiles = (n_count + 31) / 32;
+    const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
+    const int grid = wgs < 2048 ? wgs : 2048;
+    hipStream_t st = (hipStream_t)stream;
+    const FfnIn ffn{x, norm_w, norm_b, ff1_w, ff1_b, ff2_w, ff2_b, eps};
+    if (part_precision == HEPT_PREC_BF16)
+        hipLaunchKernelGGL((combine_out_kernel<true, true>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
+                           n0, n_count, out_weight, out_bias, y, ffn);
+    else if (part_precision == HEPT_PREC_F32)
+        hipLaunchKernelGGL((combine_out_kernel<false, true>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
+                           n0, n_count, out_weight, out_bias, y, ffn);
+    else
+        return HEPT_ERR_SHAPE;
     return hept_launch_status();
 }

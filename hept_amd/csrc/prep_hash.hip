@@ -59,13 +59,25 @@ __global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict
 // in order: no barrier): chunks -> padded rows (odd 16-B pitch: conflict-free) -> lane m = p*8 + h owns
 // row (p, h); finished rows -> [head][point] order (+1 slot per head: conflict-free) -> linear chunks.
 // Splitting the roles keeps every wave light (few registers, many waves per CU).
-template <int D, int C, int TILE, int ROLE>
+// FUSED: x is the (N, D) input of the Attn block instead of a (N, H*D) projection: every lane
+// applies LayerNorm to its point's row (example/transformer.py:155) and computes ITS head's D outputs of the
+// bias-free projection (w_q / w_k / w_v, :156) from the LDS-resident weight slab of this role -- q, k, v never
+// exist in HBM.
+struct FusedIn {
+    const float* ln_w;   // norm1.weight (D)
+    const float* ln_b;   // norm1.bias (D)
+    const float* w_s;    // LDS: this role's projection weight, [h][d][j] at head pitch FUSED_WPITCH
+    float eps;
+};
+constexpr int FUSED_WPITCH = 24 * 24 + 4;  // head pitch = 4 (mod 32) dwords: the 8 heads' 16-B reads hit 8 distinct bank groups
+
+template <int D, int C, int TILE, int ROLE, bool FUSED = false>
 __device__ __forceinline__ void prep_role(const float* __restrict__ x, const float* __restrict__ coords,
                                           const float* __restrict__ sw_s, const float* __restrict__ alpha_s,
                                           const int64_t* __restrict__ codes, int N, int raw_size, int t0, int Tl,
                                           char* __restrict__ out_rows, float* __restrict__ proj,
                                           float* __restrict__ red_s, f32x4* __restrict__ tile_s,
-                                          float* __restrict__ minmax, int slot) {
+                                          float* __restrict__ minmax, int slot, FusedIn fin = FusedIn{}) {
     constexpr int H = 8, E = D + C, HD = H * D, D4 = D / 4;
     constexpr int WAVES = PREP_THREADS / HEPT_WAVE;
     constexpr bool BF16 = TILE != HEPT_PREC_F32;      // 16-bit tiles
@@ -96,7 +108,42 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
         const int rows = min(PREP_POINTS, N - n0);
         const int n = n0 + p;
         const bool live = p < rows;
-        {
+        f32x4 xr[D4];
+        if constexpr (FUSED) {
+            float xv[D];
+            const f32x4* xs = reinterpret_cast<const f32x4*>(x + (size_t)(live ? n : n0) * D);
+#pragma unroll
+            for (int j = 0; j < D4; ++j) {
+                const f32x4 v4 = xs[j];
+                xv[4 * j] = v4[0]; xv[4 * j + 1] = v4[1]; xv[4 * j + 2] = v4[2]; xv[4 * j + 3] = v4[3];
+            }
+            float mean = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) mean += xv[j];
+            mean *= 1.0f / D;
+            float var = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) { const float dlt = xv[j] - mean; var = fmaf(dlt, dlt, var); }
+            const float rstd = 1.0f / sqrtf(var * (1.0f / D) + fin.eps);
+#pragma unroll
+            for (int j = 0; j < D; ++j) xv[j] = (xv[j] - mean) * rstd * fin.ln_w[j] + fin.ln_b[j];
+            const float* wrow = fin.w_s + h * FUSED_WPITCH;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < D4; ++j) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + d * D + 4 * j);
+                    acc = fmaf(wv[0], xv[4 * j], acc);
+                    acc = fmaf(wv[1], xv[4 * j + 1], acc);
+                    acc = fmaf(wv[2], xv[4 * j + 2], acc);
+                    acc = fmaf(wv[3], xv[4 * j + 3], acc);
+                }
+                xr[d / 4][d % 4] = acc;
+                // keep the 144 weight reads from being hoisted in front of the fma chains (they would need ~600 VGPRs)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
             const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)n0 * HD);
             const int valid_chunks = rows * (HD / 4);
             f32x4 xin[LOADS];
@@ -105,10 +152,9 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
                 xin[j] = (j * 64 + lane < valid_chunks) ? src[j * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < LOADS; ++j) buf[wslot[j]] = xin[j];
-        }
-        f32x4 xr[D4];
 #pragma unroll
-        for (int j = 0; j < D4; ++j) xr[j] = buf[lane * ROW4 + j];
+            for (int j = 0; j < D4; ++j) xr[j] = buf[lane * ROW4 + j];
+        }
         // src variant (src/models/attention/hept.py:89-96): rows >= raw_size are padding: q^ = k^ = v = 0,
         // they take part in the hash range with projection 0 and then hash to +inf (sorted last)
         const bool is_pad = n >= raw_size;
@@ -275,6 +321,59 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
                                  red_s, tile_s, minmax, 0);
 }
 
+// Attn-block front end: LayerNorm + the three projections fused into the row builder (D = 24 only)
+template <int C, int TILE>
+__global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
+    const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+    const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
+    const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
+    void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
+    constexpr int D = 24, H = 8, E = D + C;
+    __shared__ float alpha_s[H * E * HEPT_MAX_TABLES];
+    __shared__ float sw_s[H * C];
+    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * HEPT_MAX_TABLES * H * 4];
+    __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * PREP_WAVE_SLOTS];
+    __shared__ __attribute__((aligned(16))) float w_s[H * FUSED_WPITCH];
+    const int role = blockIdx.y;
+    const float* wsrc = role == 0 ? wq : (role == 1 ? wk : wv);
+    for (int i = threadIdx.x; i < H * D * D; i += PREP_THREADS) w_s[(i / (D * D)) * FUSED_WPITCH + i % (D * D)] = wsrc[i];
+    if (role != 2) {
+        for (int i = threadIdx.x; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
+            const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
+            alpha_s[i] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
+        }
+        for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
+    }
+    __syncthreads();
+    const FusedIn fin{ln_w, ln_b, w_s, eps};
+    if (role == 0)
+        prep_role<D, C, TILE, 0, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(qhat_),
+                                       qproj, red_s, tile_s, minmax, blockIdx.x, fin);
+    else if (role == 1)
+        prep_role<D, C, TILE, 1, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
+                                       kproj, red_s, tile_s, minmax, PREP_WGS_PER_ROLE + blockIdx.x, fin);
+    else
+        prep_role<D, C, TILE, 2, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
+                                       nullptr, red_s, tile_s, minmax, 0, fin);
+}
+
+template <int C>
+int launch_prep_fused(const float* x, const float* ln_w, const float* ln_b, float eps, const float* wq, const float* wk,
+                      const float* wv, const float* coords, const float* sqrt_w, const float* alpha,
+                      const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision, void* qhat,
+                      void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
+    const dim3 grid(PREP_WGS_PER_ROLE, 3);
+#define HEPT_FUSED_LAUNCH(TILE)                                                                                       \
+    hipLaunchKernelGGL((prep_fused_kernel<C, TILE>), grid, dim3(PREP_THREADS), 0, st, x, ln_w, ln_b, eps, wq, wk, wv, \
+                       coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
+    if (precision == HEPT_PREC_BF16) HEPT_FUSED_LAUNCH(HEPT_PREC_BF16);
+    else if (precision == HEPT_PREC_MIXED16) HEPT_FUSED_LAUNCH(HEPT_PREC_MIXED16);
+    else HEPT_FUSED_LAUNCH(HEPT_PREC_F32);
+#undef HEPT_FUSED_LAUNCH
+    return hept_launch_status();
+}
+
 template <int D, int C>
 int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w,
                 const float* alpha, const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision,
@@ -324,5 +423,29 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
     HEPT_PREP_CASE(16, 4)
     HEPT_PREP_CASE(8, 4)
 #undef HEPT_PREP_CASE
+    return HEPT_ERR_SHAPE;
+}
+
+extern "C" int hept_prep_hash_fused(const float* x, const float* norm_w, const float* norm_b, float eps,
+                                    const float* w_q, const float* w_k, const float* w_v, const float* coords,
+                                    const float* sqrt_w, const float* alpha, const int64_t* codes, int N, int raw_size,
+                                    int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat,
+                                    void* kvhat, float* qproj, float* kproj, float* minmax, void* stream) {
+    if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    if (!x || !norm_w || !norm_b || !w_q || !w_k || !w_v || !coords || !sqrt_w || !alpha || !qhat || !kvhat ||
+        !qproj || !kproj || !minmax)
+        return HEPT_ERR_ARG;
+    if (H != 8 || D != 24 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16 && precision != HEPT_PREC_MIXED16)
+        return HEPT_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define HEPT_FUSED_CASE(CC)                                                                                         \
+    if (C == CC)                                                                                                    \
+        return launch_prep_fused<CC>(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, N, raw_size, \
+                                     T, t0, Tl, precision, qhat, kvhat, qproj, kproj, minmax, st);
+    HEPT_FUSED_CASE(6)
+    HEPT_FUSED_CASE(4)
+    HEPT_FUSED_CASE(2)
+#undef HEPT_FUSED_CASE
     return HEPT_ERR_SHAPE;
 }

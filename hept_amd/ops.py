@@ -15,7 +15,7 @@ from ._lib import PREC_BF16, PREC_F32, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
-    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args", "packed_partials",
+    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args", "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward",
 ]
 
 
@@ -354,6 +354,104 @@ def forward_partial_src(q, k, v, coords, region_indices, regions_h, raw_size: in
                                             workspace.data_ptr(), workspace.numel(), acc.data_ptr(), _stream(q)),
                "hept_forward_partial_src")
     return acc
+
+
+def prep_hash_fused(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, precision="fp32",
+                    t0: int = 0, tl: Optional[int] = None, raw_size: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """``prep_hash`` with LayerNorm and the q/k/v projections fused in: ``x`` is the (N, D) input of the Attn block
+    (reference ``example/transformer.py:155-156``); same outputs as :func:`prep_hash`."""
+    lib = _lib.load()
+    x, norm_w, norm_b, w_q, w_k, w_v, coords, sqrt_w, alpha = (
+        _f32c(t_, nm) for t_, nm in ((x, "x"), (norm_w, "norm1.weight"), (norm_b, "norm1.bias"), (w_q, "w_q.weight"),
+                                     (w_k, "w_k.weight"), (w_v, "w_v.weight"), (coords, "coords"),
+                                     (sqrt_w, "sqrt_w"), (alpha, "e2lsh.alpha")))
+    n, d = x.shape
+    h, e, t = alpha.shape
+    c = e - d
+    if tuple(w_q.shape) != (h * d, d) or w_k.shape != w_q.shape or w_v.shape != w_q.shape:
+        raise ValueError(f"w_q/w_k/w_v must have shape {(h * d, d)}")
+    if coords.shape != (n, c) or norm_w.numel() != d or norm_b.numel() != d:
+        raise ValueError("coords / norm1 parameters do not match x")
+    if codes is not None:
+        if codes.dtype != torch.int64 or tuple(codes.shape) != (t, h, n):
+            raise ValueError(f"combined_shifts must be an int64 tensor of shape {(t, h, n)}")
+        codes = codes.contiguous()
+    raw_size = n if raw_size is None else int(raw_size)
+    tl = t - t0 if tl is None else tl
+    prec = precision_code(precision)
+    dt = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16}[prec]
+    dev = x.device
+    qhat = torch.empty(h, n, 32, device=dev, dtype=dt)
+    kvhat = torch.empty(h, n, 64, device=dev, dtype=dt)
+    qproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
+    kproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
+    minmax = torch.empty(tl, h, _lib.PREP_GRID, 4, device=dev, dtype=torch.float32)
+    _lib.check(lib.hept_prep_hash_fused(x.data_ptr(), norm_w.data_ptr(), norm_b.data_ptr(), float(eps), w_q.data_ptr(),
+                                        w_k.data_ptr(), w_v.data_ptr(), coords.data_ptr(), sqrt_w.data_ptr(),
+                                        alpha.data_ptr(), codes.data_ptr() if codes is not None else None, n, raw_size,
+                                        h, d, c, t, t0, tl, prec, qhat.data_ptr(), kvhat.data_ptr(), qproj.data_ptr(),
+                                        kproj.data_ptr(), minmax.data_ptr(), _stream(x)), "hept_prep_hash_fused")
+    return {"qhat": qhat, "kvhat": kvhat, "qproj": qproj, "kproj": kproj, "minmax": minmax}
+
+
+def combine_ffn(part: torch.Tensor, head_dim: int, out_weight, out_bias, x, norm_w, norm_b, eps, ff1_w, ff1_b, ff2_w,
+                ff2_b, n0: int = 0, n_count: Optional[int] = None) -> torch.Tensor:
+    """``combine_out`` followed by the rest of the Attn block (residual, norm2, feed-forward, residual) in the
+    same kernel; reference ``example/transformer.py:161-165`` in eval mode.  ``x`` is the full (N, D) block input."""
+    lib = _lib.load()
+    if part.dim() == 3:
+        part = part.unsqueeze(0)
+    tl, n, h, _ = part.shape
+    n_count = n - n0 if n_count is None else n_count
+    ts = [_f32c(t_, nm) for t_, nm in ((out_weight, "out_linear.weight"), (x, "x"), (norm_w, "norm2.weight"),
+                                       (norm_b, "norm2.bias"), (ff1_w, "ff.0.weight"), (ff1_b, "ff.0.bias"),
+                                       (ff2_w, "ff.2.weight"), (ff2_b, "ff.2.bias"))]
+    ow, x, nw, nb, w1, b1, w2, b2 = ts
+    ob = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
+    y = torch.empty(n_count, head_dim, device=part.device, dtype=torch.float32)
+    _lib.check(lib.hept_combine_ffn(part.data_ptr(), _part_prec(part), tl, n, h, head_dim, n0, n_count, ow.data_ptr(),
+                                    ob.data_ptr() if ob is not None else None, x[n0:].data_ptr(), nw.data_ptr(),
+                                    nb.data_ptr(), float(eps), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                    b2.data_ptr(), y.data_ptr(), _stream(part)), "hept_combine_ffn")
+    return y
+
+
+def attn_block_forward(x, coords, codes, params: Dict[str, torch.Tensor], *, num_heads: int, block_size: int,
+                       w_per_dist: int, eps1: float = 1e-5, eps2: float = 1e-5, precision="fp32",
+                       workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The whole Attn block (reference ``example/transformer.py:154-165``, eval mode) in one C call.
+    ``params`` holds the block's tensors under the reference's state-dict names."""
+    lib = _lib.load()
+    names = {"norm1_w": "norm1.weight", "norm1_b": "norm1.bias", "w_q": "w_q.weight", "w_k": "w_k.weight",
+             "w_v": "w_v.weight", "w_rpe": "w_rpe.weight", "alpha": "attn.e2lsh.alpha",
+             "out_w": "attn.out_linear.weight", "out_b": "attn.out_linear.bias", "norm2_w": "norm2.weight",
+             "norm2_b": "norm2.bias", "ff1_w": "ff.0.weight", "ff1_b": "ff.0.bias", "ff2_w": "ff.2.weight",
+             "ff2_b": "ff.2.bias"}
+    x = _f32c(x, "x")
+    coords = _f32c(coords, "coords")
+    keep = {f: _f32c(params[k], k) for f, k in names.items()}
+    n, d = x.shape
+    h = num_heads
+    e, t = keep["alpha"].shape[1], keep["alpha"].shape[2]
+    c = e - d
+    if n % block_size != 0:
+        raise ValueError(f"number of points {n} is not a multiple of block_size {block_size}")
+    if codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n):
+        raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}")
+    codes = codes.contiguous()
+    prec = precision_code(precision)
+    _lib.check(lib.hept_check_shape(n, h, d, c, t, block_size), "hept_check_shape")
+    need = int(lib.hept_workspace_bytes(n, h, d, c, t, block_size, prec))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x.device, dtype=torch.uint8)
+    st = _lib.AttnParams(**{f: v.data_ptr() for f, v in keep.items()}, eps1=float(eps1), eps2=float(eps2))
+    y = torch.empty(n, d, device=x.device, dtype=torch.float32)
+    import ctypes
+
+    _lib.check(lib.hept_attn_block_forward(x.data_ptr(), coords.data_ptr(), codes.data_ptr(), ctypes.byref(st), n, h,
+                                           d, c, w_per_dist, t, block_size, prec, workspace.data_ptr(),
+                                           workspace.numel(), y.data_ptr(), _stream(x)), "hept_attn_block_forward")
+    return y
 
 
 def profile_enable(mode: int, max_calls: int = 0, stride: int = 1) -> None:

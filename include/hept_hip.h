@@ -155,6 +155,46 @@ int hept_forward_partial_src(const float* q, const float* k, const float* v, con
                              int precision, int acc_precision, void* workspace, size_t workspace_bytes,
                              float* acc, void* stream);
 
+/* SURVEY.md §8 f-4 — the Attn block around the operator (example/transformer.py:131-165), eval mode, D == 24:
+ *   x_normed = norm1(x); q,k,v = w_q/w_k/w_v(x_normed); aggr = HEPTAttention(q,k,v,...);
+ *   x = x + aggr; y = x + ff(norm2(x))                                  (dropout is the identity in eval)
+ * hept_prep_hash_fused = hept_prep_hash with LayerNorm and the three bias-free projections computed while the rows
+ * are staged: x is (N, D), q/k/v never exist in HBM.  hept_combine_ffn = hept_combine_out with the residual,
+ * norm2 and the two-layer feed-forward in the epilogue; x and y point at row n0.  hept_attn_block_forward runs
+ * the whole block (rpe_scale, prep_hash_fused, sort_tables, block_attn, combine_ffn) in one call. */
+typedef struct {
+    const float* norm1_w;  /* (D) */
+    const float* norm1_b;
+    const float* w_q;      /* (H*D, D), no bias */
+    const float* w_k;
+    const float* w_v;
+    const float* w_rpe;    /* (H*D, (C-1)*K) */
+    const float* alpha;    /* (H, D+C, T) */
+    const float* out_w;    /* (D, H*D) */
+    const float* out_b;    /* (D) or NULL */
+    const float* norm2_w;
+    const float* norm2_b;
+    const float* ff1_w;    /* ff.0: (D, D), (D) */
+    const float* ff1_b;
+    const float* ff2_w;    /* ff.2 */
+    const float* ff2_b;
+    float eps1, eps2;      /* LayerNorm eps of norm1 / norm2 */
+} hept_attn_params;
+
+int hept_prep_hash_fused(const float* x, const float* norm_w, const float* norm_b, float eps,
+                         const float* w_q, const float* w_k, const float* w_v, const float* coords,
+                         const float* sqrt_w, const float* alpha, const int64_t* codes,
+                         int N, int raw_size, int H, int D, int C, int T, int t0, int Tl, int precision,
+                         void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, void* stream);
+int hept_combine_ffn(const float* part, int part_precision, int Tl, int N, int H, int D, int n0, int n_count,
+                     const float* out_weight, const float* out_bias, const float* x,
+                     const float* norm_w, const float* norm_b, float eps,
+                     const float* ff1_w, const float* ff1_b, const float* ff2_w, const float* ff2_b,
+                     float* y, void* stream);
+int hept_attn_block_forward(const float* x, const float* coords, const int64_t* codes,
+                            const hept_attn_params* params, int N, int H, int D, int C, int K, int T, int B,
+                            int precision, void* workspace, size_t workspace_bytes, float* y, void* stream);
+
 /* SURVEY.md §8 f-2 — backward of the block attention (the reference trains through example/hept.py:55-80 with
  * plain autograd; there is no custom backward to mirror).  f32 tiles only.  gacc (N, H, 32) f32 is the
  * gradient of the table-summed partial rows [d numer | d den | 0]; qhat/kvhat/qpos/kpos are the forward's.

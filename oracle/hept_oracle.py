@@ -53,6 +53,7 @@ __all__ = [
     "out_projection",
     "forward",
     "forward_partials",
+    "attn_block",
     "HeptShapes",
 ]
 
@@ -383,4 +384,42 @@ def forward(
     per_head = combine_tables(res["numer"], res["denom"])
     res["per_head"] = per_head
     res["out"] = out_projection(per_head, out_weight, out_bias)
+    return res
+
+
+def attn_block(
+    x: torch.Tensor,
+    coords: torch.Tensor,
+    codes: torch.Tensor,
+    params: Dict[str, torch.Tensor],
+    *,
+    num_heads: int,
+    block_size: int,
+    w_per_dist: int,
+    eps: float = 1e-5,
+    **kw,
+) -> Dict[str, torch.Tensor]:
+    """The ``Attn`` block around the operator in eval mode (dropout = identity), ``example/transformer.py:154-165``.
+
+    ``params`` holds the block's tensors under the reference's state-dict names.  Returns ``y`` (N, D), the
+    operator's output ``aggr`` and the operator's intermediates.
+    """
+    import torch.nn.functional as F
+
+    d = x.shape[1]
+    with torch.no_grad():
+        x_normed = F.layer_norm(x, (d,), params["norm1.weight"], params["norm1.bias"], eps)      # :155
+        q = F.linear(x_normed, params["w_q.weight"])                                             # :156
+        k = F.linear(x_normed, params["w_k.weight"])
+        v = F.linear(x_normed, params["w_v.weight"])
+        res = forward(q, k, v, coords, codes, params["w_rpe.weight"], params["attn.e2lsh.alpha"],
+                      params["attn.out_linear.weight"], params["attn.out_linear.bias"], block_size=block_size,
+                      w_per_dist=w_per_dist, **kw)                                               # :157
+        x1 = x + res["out"]                                                                      # :161
+        hidden = F.relu(F.linear(F.layer_norm(x1, (d,), params["norm2.weight"], params["norm2.bias"], eps),
+                                 params["ff.0.weight"], params["ff.0.bias"]))
+        ff_output = F.linear(hidden, params["ff.2.weight"], params["ff.2.bias"])                 # :162
+        res["aggr"] = res["out"]
+        res["q"], res["k"], res["v"] = q, k, v
+        res["y"] = x1 + ff_output                                                                # :163
     return res

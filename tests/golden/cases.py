@@ -125,6 +125,7 @@ def build_inputs(name: str, stored: Optional[Dict[str, np.ndarray]] = None) -> D
             torch.from_numpy(np.asarray(stored["norm1_bias"])).float(),
         )
         ps = inp["pad_seq"]
+        inp["x"] = x[ps].contiguous()  # block-level input (Attn cases)
         for key, wkey in (("q", "w_q"), ("k", "w_k"), ("v", "w_v")):
             w = torch.from_numpy(np.asarray(stored[wkey])).float()
             inp[key] = torch.nn.functional.linear(xn, w)[ps].contiguous()
@@ -151,6 +152,43 @@ def build_inputs(name: str, stored: Optional[Dict[str, np.ndarray]] = None) -> D
     inp["block_size"] = cfg["block_size"]
     inp["w_per_dist"] = W_PER_DIST
     return inp
+
+
+# Attn-block cases (reference example/transformer.py:131-165, eval mode): the block input x (N, 24),
+# coords and AND codes of an operator case, and a full set of block weights stored in the fixture.
+ATTN_CASES: Dict[str, dict] = {
+    # A1: the shipped checkpoint's layer 0 (attns.0.*, w_q and w_k scaled by G3's qk_scale: see make_golden_attn.py)
+    # on the tracking-6k cloud of G3
+    "a1_attn_ckpt6k": dict(base="g3_ckpt6k"),
+    # A2: default-initialised block, block_size 100, two clouds (G6's coords and codes), x ~ N(0,1)
+    "a2_attn_rand": dict(base="g6_block100", seed=301),
+}
+ATTN_KEYS = ("norm1.weight", "norm1.bias", "w_q.weight", "w_k.weight", "w_v.weight", "w_rpe.weight", "w_rpe.bias",
+             "attn.e2lsh.alpha", "attn.out_linear.weight", "attn.out_linear.bias", "norm2.weight", "norm2.bias",
+             "ff.0.weight", "ff.0.bias", "ff.2.weight", "ff.2.bias")
+
+
+def build_inputs_attn(name: str, stored: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, torch.Tensor]:
+    """x, coords, combined_shifts (+ ``params`` when the fixture is given) of Attn-block case ``name``."""
+    cfg = ATTN_CASES[name]
+    base, _ = load_case(cfg["base"])
+    out = {"coords": base["coords"], "combined_shifts": base["combined_shifts"], "block_size": base["block_size"],
+           "w_per_dist": W_PER_DIST}
+    if "x" in base:
+        out["x"] = base["x"]
+    else:
+        gen = torch.Generator().manual_seed(cfg["seed"])
+        out["x"] = torch.randn(base["q"].shape[0], H_DIM, generator=gen)
+    if stored is not None:
+        out["params"] = {k: torch.from_numpy(np.asarray(stored["p:" + k])).float() for k in ATTN_KEYS}
+    return out
+
+
+def load_case_attn(name: str):
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    with np.load(path) as z:
+        fx = {k: z[k] for k in z.files}
+    return build_inputs_attn(name, fx), fx
 
 
 def input_checksums(inp: Dict[str, torch.Tensor]) -> np.ndarray:
