@@ -1,4 +1,5 @@
-// sort_tables: AND-shifted sort keys + stable segmented sort (two 8-bit passes on a 16-bit bucket id + in-bucket ranking).
+// sort_tables: AND-shifted sort keys + exact stable segmented sort: one counting pass on the top bits of a monotone
+// bucket id, then every bucket is finished inside LDS.  Three kernels.
 //
 // Replaces, for tables [t0, t0+Tl) (reference file:line):
 //   hash_shift = max - min            example/hept_utils.py:70
@@ -9,22 +10,22 @@
 // exactly torch.sort(stable=True): ascending key, ties in ascending point index (the
 // reference's own argsort is unstable and leaves tie order undefined, SURVEY.md §7 hard part 1).
 //
-// Integer/byte work, HBM/L2-bound.  Every key gets a MONOTONE 16-bit bucket id
-//     id(key) = trunc((key - kmin) * 65536 / (kmax - kmin)),
+// Integer/byte work, HBM/L2-bound.  Every key gets a MONOTONE bucket id of HEPT_ID_BITS bits
+//     id(key) = trunc((key - kmin) * 2^bits / (kmax - kmin)),
 // where [kmin,kmax] = [hash min, hash max + largest code * span] is known before any key exists (from the
 // prep kernel's partials).  id() is a monotone non-decreasing function of the key itself (fp32 subtract,
 // multiply and truncate are monotone), so id order never contradicts key order and equal keys share an id.
-//   K1 keygen      key -> order-preserving u32, per-chunk histogram of the LOW id byte
-//   K2 scan        histogram -> exclusive offsets [segment][chunk][256]
-//   K3 scatter     stable counting-sort pass on the low byte (wave-level ballots, 64-wide; no data-path
-//                  atomics); the chunk is bucket-sorted in LDS first so that the global writes are runs of
-//                  ~16 consecutive (key,index) pairs instead of single 8-byte scatters
-//   K4 hist        per-chunk histogram of the HIGH id byte of the pass-1 order;  K5 = K2;  K6 = K3 (high byte)
-//   K7 rank        keys are now grouped by id (~N/65536 * clumping, a handful per id): every element counts the
-//                  same-id neighbours that sort before it (u64 compare of (key << 32 | index): inside an id the
-//                  stable passes kept ascending index order) -> final position
+//   K1 keygen       key -> order-preserving u32, per-chunk histogram of the top HEPT_TOP_BITS id bits
+//   K3 scatter      counting pass on the top bits: every workgroup reduces its segment's chunk histograms to its own
+//                   global offsets (no separate scan kernel), bucket-sorts its 4096-key chunk inside LDS (slot = LDS
+//                   atomic on the digit counter) and writes runs of consecutive (key,index) pairs
+//   K4 bucket sort  one workgroup per (segment, bucket): histogram / prefix / scatter on the LOW id bits inside LDS
+//                   groups the pairs by their full id, then every pair counts the members of its id group that are
+//                   smaller as u64 (key << 32 | index) -> final position.  Groups are 1-3 pairs.
 // The result is the exact stable sort for ANY input; cost O(N + sum group^2).  Adversarial inputs (all keys
-// inside 1/65536 of the range) degrade to O(N^2) neighbour scans per segment — slow, never wrong.
+// inside 2^-bits of the range) degrade to O(N^2) compares per segment -- slow, never wrong.
+// History (tracking-60k, 48 segments x 60 032 keys): 4-pass LSD radix 144 us -> two 8-bit LSD passes + windowed
+// neighbour rank 89 us -> this design 44 us.
 #include "common.h"
 
 namespace {
@@ -34,7 +35,23 @@ constexpr int SORT_WAVES = SORT_THREADS / HEPT_WAVE;
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_ITEMS;  // 4096 keys per workgroup
 constexpr int RADIX = 256;
-constexpr int ID_BUCKETS = 65536;
+#ifndef HEPT_ID_BITS
+#define HEPT_ID_BITS 17
+#endif
+#ifndef HEPT_TOP_BITS
+#define HEPT_TOP_BITS 8
+#endif
+#ifndef HEPT_BKT_THREADS
+#define HEPT_BKT_THREADS 128
+#endif
+#ifndef HEPT_BKT_CAP
+#define HEPT_BKT_CAP 1024
+#endif
+constexpr int ID_BUCKETS = 1 << HEPT_ID_BITS;       // resolution of the monotone bucket id (exact in fp32: <= 2^24)
+constexpr int TOP_SHIFT = HEPT_ID_BITS - HEPT_TOP_BITS;  // K3 partitions by the top id bits ...
+constexpr int NTOP = 1 << HEPT_TOP_BITS;            // ... into NTOP buckets per segment (digits < RADIX)
+constexpr int LOBINS = 1 << TOP_SHIFT;              // K4 groups a bucket by the remaining low id bits
+static_assert(NTOP <= RADIX, "the histogram / scan / scatter arrays hold RADIX digits");
 
 __device__ __forceinline__ unsigned int ordered_bits(float key) {
     if (key == 0.f) key = 0.f;  // -0.0 and +0.0 compare equal in the reference sort
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
                 asm volatile("" : "+v"(t3));
                 const unsigned int u = ordered_bits(proj[n] + t3);
                 kout[n] = u;
-                atomicAdd(&h_s[id16_of(u, lo, scale) & 0xFF], 1u);
+                atomicAdd(&h_s[id16_of(u, lo, scale) >> TOP_SHIFT], 1u);
             }
         }
         __syncthreads();
@@ -161,13 +178,13 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
             u[3] = make_key(pj[3], c23[1]);
             *reinterpret_cast<u32x4*>(kout + n) = u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&h_s[id16_of(u[e], lo, scale) & 0xFF], 1u);
+            for (int e = 0; e < 4; ++e) atomicAdd(&h_s[id16_of(u[e], lo, scale) >> TOP_SHIFT], 1u);
         } else {
             for (int e = 0; e < 4; ++e)
                 if (n + e < N) {
                     const unsigned int u = make_key(proj[n + e], code[n + e]);
                     kout[n + e] = u;
-                    atomicAdd(&h_s[id16_of(u, lo, scale) & 0xFF], 1u);
+                    atomicAdd(&h_s[id16_of(u, lo, scale) >> TOP_SHIFT], 1u);
                 }
         }
     }
@@ -175,74 +192,17 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
     hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
 }
 
-// K4: histogram of the high id byte over the pass-1 order
-__global__ __launch_bounds__(SORT_THREADS) void hist_hi_kernel(const unsigned long long* __restrict__ pairs,
-                                                               const SegParams* __restrict__ seg_params, int N,
-                                                               unsigned int* __restrict__ hist, int n_chunks) {
-    __shared__ unsigned int h_s[RADIX];
-    const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
-    const SegParams rg = seg_params[seg];
-    h_s[tid] = 0;
-    __syncthreads();
-    const uint2* src = reinterpret_cast<const uint2*>(pairs + (size_t)seg * N);
-    const int base = chunk * SORT_CHUNK;
-#pragma unroll 8
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int n = base + i * SORT_THREADS + tid;
-        if (n < N) atomicAdd(&h_s[id16_of(src[n].y, rg.kmin, rg.scale) >> 8], 1u);
-    }
-    __syncthreads();
-    hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
-}
-
-// K2/K5: one workgroup per segment, one thread per digit.
-// hist[seg][c][d] <- (keys of this segment with a smaller digit) + (same digit in earlier chunks)
-__global__ __launch_bounds__(RADIX) void scan_kernel(unsigned int* __restrict__ hist, int n_chunks) {
-    constexpr int BATCH = 16;
-    __shared__ unsigned int wsum_s[RADIX / HEPT_WAVE];
-    const int d = threadIdx.x, lane = d & 63, w = d >> 6, seg = blockIdx.x;
-    unsigned int* hseg = hist + (size_t)seg * n_chunks * RADIX + d;
-    unsigned int total = 0;
-    for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
-        unsigned int x[BATCH];
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i) x[i] = (c0 + i < n_chunks) ? hseg[(size_t)(c0 + i) * RADIX] : 0u;
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i) total += x[i];
-    }
-    unsigned int incl = total;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int y = __shfl_up(incl, off);
-        if (lane >= off) incl += y;
-    }
-    if (lane == 63) wsum_s[w] = incl;
-    __syncthreads();
-    unsigned int run = incl - total;
-    for (int ww = 0; ww < w; ++ww) run += wsum_s[ww];
-    for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
-        unsigned int x[BATCH];
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i) x[i] = (c0 + i < n_chunks) ? hseg[(size_t)(c0 + i) * RADIX] : 0u;
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i) {
-            if (c0 + i < n_chunks) hseg[(size_t)(c0 + i) * RADIX] = run;
-            run += x[i];
-        }
-    }
-}
-
-// K3/K6: one stable counting-sort pass on one id byte.  HI = false: source is keys0 (index implicit), digit =
-// low byte; HI = true: source is the pass-1 pairs, digit = high byte.
-template <bool HI>
+// K3: counting-sort pass on the top id bits: keys0 (index implicit) -> (key, index) pairs grouped into the NTOP
+// buckets of their segment (any order inside a bucket: K4 ranks full pairs).  A chunk of 4096 keys is bucket-sorted
+// inside LDS first (local slot = LDS atomic on the digit counter), so that the global writes are runs of
+// consecutive pairs instead of single 8-byte scatters.
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned int* __restrict__ keys0,
-                                                               const unsigned long long* __restrict__ src_pairs,
                                                                const SegParams* __restrict__ seg_params,
-                                                               const unsigned int* __restrict__ offs, int N,
-                                                               int n_chunks,
+                                                               const unsigned int* __restrict__ hist, int N,
+                                                               int n_chunks, unsigned int* __restrict__ bstart,
                                                                unsigned long long* __restrict__ dst_pairs) {
     __shared__ unsigned long long stage_s[SORT_CHUNK];   // the chunk, digit-sorted (32 KiB)
-    __shared__ unsigned int cnt_s[SORT_WAVES][RADIX];    // per-wave digit counters -> exclusive wave prefix
+    __shared__ unsigned int cnt_s[RADIX];                // keys of the chunk per digit
     __shared__ unsigned int start_s[RADIX];              // first local position of a digit
     __shared__ unsigned int goff_s[RADIX];               // global offset of the digit's first key of this chunk
     __shared__ unsigned int wsum_s[SORT_WAVES];
@@ -250,53 +210,60 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
     const int seg = blockIdx.y, chunk = blockIdx.x;
     const SegParams rg = seg_params[seg];
     const size_t seg_off = (size_t)seg * N;
+    cnt_s[tid] = 0;
+    // global offset of digit `tid` for this chunk = (keys of the segment with a smaller digit) + (same digit in
+    // earlier chunks): every workgroup reduces the segment's chunk histograms itself (a few KiB from L2) instead
+    // of waiting for a separate scan kernel
+    unsigned int own = 0, tot = 0;
+    {
+        const unsigned int* hseg = hist + (size_t)seg * n_chunks * RADIX + tid;
+        for (int c0 = 0; c0 < n_chunks; c0 += 8) {
+            unsigned int x[8];
 #pragma unroll
-    for (int ww = 0; ww < SORT_WAVES; ++ww) cnt_s[ww][tid] = 0;
-    goff_s[tid] = offs[((size_t)seg * n_chunks + chunk) * RADIX + tid];
-
-    // wave w owns 1024 consecutive keys, 16 rounds of 64 (stable: index order)
-    unsigned long long pr[SORT_ITEMS];
-    const int wbase = chunk * SORT_CHUNK + w * (SORT_ITEMS * HEPT_WAVE);
+            for (int i = 0; i < 8; ++i) x[i] = (c0 + i < n_chunks) ? hseg[(size_t)(c0 + i) * RADIX] : 0u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                tot += x[i];
+                own += (c0 + i < chunk) ? x[i] : 0u;
+            }
+        }
+    }
+    unsigned int key[SORT_ITEMS];
+    const int base = chunk * SORT_CHUNK;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int n = wbase + r * HEPT_WAVE + lane;
-        if (HI)
-            pr[r] = n < N ? src_pairs[seg_off + n] : ~0ull;
-        else
-            pr[r] = n < N ? (((unsigned long long)keys0[seg_off + n] << 32) | (unsigned int)n) : ~0ull;
+        const int n = base + r * SORT_THREADS + tid;
+        key[r] = n < N ? keys0[seg_off + n] : 0u;
+    }
+    {
+        unsigned int incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) wsum_s[w] = incl;
+        __syncthreads();
+        unsigned int excl = incl - tot;
+#pragma unroll
+        for (int ww = 0; ww < SORT_WAVES; ++ww)
+            if (ww < w) excl += wsum_s[ww];
+        goff_s[tid] = excl + own;
+        if (chunk == 0) bstart[(size_t)seg * RADIX + tid] = excl;
     }
     __syncthreads();
     unsigned short rank[SORT_ITEMS];
     unsigned char dig[SORT_ITEMS];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int n = wbase + r * HEPT_WAVE + lane;
-        const bool valid = n < N;
-        const unsigned int id = id16_of((unsigned int)(pr[r] >> 32), rg.kmin, rg.scale);
-        const unsigned int dg = valid ? (HI ? id >> 8 : id & 0xFF) : 0xFFu;
+        const int n = base + r * SORT_THREADS + tid;
+        const unsigned int dg = id16_of(key[r], rg.kmin, rg.scale) >> TOP_SHIFT;
         dig[r] = (unsigned char)dg;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const unsigned int prior = cnt_s[w][dg];
-        const unsigned int ahead = __popcll(peers & lt_mask);
-        if (valid && ahead == 0) cnt_s[w][dg] = prior + __popcll(peers);
-        rank[r] = (unsigned short)(prior + ahead);
+        rank[r] = n < N ? (unsigned short)atomicAdd(&cnt_s[dg], 1u) : (unsigned short)0;
     }
     __syncthreads();
-    // digit `tid`: exclusive prefix over the waves, then over the digits -> first local position of the digit
-    unsigned int total = 0;
-#pragma unroll
-    for (int ww = 0; ww < SORT_WAVES; ++ww) {
-        const unsigned int c = cnt_s[ww][tid];
-        cnt_s[ww][tid] = total;
-        total += c;
-    }
+    // digit `tid`: exclusive prefix over the digits -> first local position of the digit
+    const unsigned int total = cnt_s[tid];
     unsigned int incl = total;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -311,115 +278,141 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
         if (ww < w) first += wsum_s[ww];
     start_s[tid] = first;
     __syncthreads();
-    // bucket-sort the chunk inside LDS
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int n = wbase + r * HEPT_WAVE + lane;
-        if (n < N) stage_s[start_s[dig[r]] + cnt_s[w][dig[r]] + rank[r]] = pr[r];
+        const int n = base + r * SORT_THREADS + tid;
+        if (n < N) stage_s[start_s[dig[r]] + rank[r]] = ((unsigned long long)key[r] << 32) | (unsigned int)n;
     }
     __syncthreads();
     // write out: consecutive local positions of one digit are consecutive global positions
-    const int n_valid = min(SORT_CHUNK, N - chunk * SORT_CHUNK);
+    const int n_valid = min(SORT_CHUNK, N - base);
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int lp = r * SORT_THREADS + tid;
         if (lp < n_valid) {
             const unsigned long long p = stage_s[lp];
-            const unsigned int id = id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale);
-            const unsigned int dg = HI ? id >> 8 : id & 0xFF;
+            const unsigned int dg = id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale) >> TOP_SHIFT;
             dst_pairs[seg_off + goff_s[dg] + (lp - start_s[dg])] = p;
         }
     }
 }
 
-// K7: final position of every element.  After the two passes the pairs are ordered by id, and id is monotone
-// in the key, so everything left of an element's id group is smaller and everything right of it is larger as
-// u64 (key << 32 | index); inside the group the stable passes kept ascending index.  Hence, for ANY window
-// [i-K, i+K] that contains the whole group:
-//        final position(i) = (i - K) + #{ j in window : pair_j < pair_i }
-// -- a branch-free count with no id logic (slots left of the segment hold 0, slots right of it ~0, which
-// makes the formula exact at the segment ends as well).  A thread owns 4 consecutive positions and streams
-// the staged pairs of their joint window once.  Only when a group reaches a window edge (groups are ~5
-// keys at tracking-60k; adversarial inputs can make them arbitrarily long) the element is recounted with
-// plain loops over its whole group.
-constexpr int RANK_PER_THREAD = 4;
-constexpr int RANK_SPAN = SORT_THREADS * RANK_PER_THREAD;  // positions per workgroup
-constexpr int RANK_K = 24;
-__global__ __launch_bounds__(SORT_THREADS) void neighbour_rank_kernel(const unsigned long long* __restrict__ pairs,
-                                                                      const SegParams* __restrict__ seg_params,
-                                                                      int N, int* __restrict__ pos_out) {
-    constexpr int W = RANK_SPAN + 2 * RANK_K;
-    // slot(g) = g + g/4: a thread's window starts at a multiple of 4, so lane t reads slot 5t + const ->
-    // 10-dword lane stride, bank-conflict free for ds_read_b64 (a plain layout is 4-way conflicted)
-    __shared__ unsigned long long p_s[W + W / 4 + 1];
-    const int seg = blockIdx.y, tid = threadIdx.x;
-    const int i0 = blockIdx.x * RANK_SPAN;
+// K4: every (segment, high-byte bucket) is finished by one workgroup.  A bucket holds the pairs whose id shares the
+// high byte, contiguous after K3; id is monotone in the key, so the bucket's final positions are exactly its own
+// range [start, end) and only the order inside it is left.  Histogram of the LOW id byte -> exclusive prefix
+// -> scatter (any order): the pairs are now grouped by their full 16-bit id, group g = [first[g], first[g+1]), and
+//        final position(i) = start + first[g] + #{ j in group g : pair_j < pair_i }        (pairs are unique u64)
+// Groups are ~1-5 pairs at tracking-60k.  A bucket larger than the LDS tile takes the same three steps through a
+// global scratch copy (streaming; slower, never wrong); adversarial inputs (all keys inside 1/65536 of the key
+// range) cost O(group^2) compares.
+// The whole bucket is loaded into registers with every load in flight at once; only the grouped copy lives in LDS.
+// One bins array serves as histogram, exclusive prefix and scatter cursor: after the scatter cur[d] is one past the
+// last slot of group d, i.e. group d = [cur[d-1], cur[d]).
+constexpr int BKT_THREADS = HEPT_BKT_THREADS;
+constexpr int BKT_WAVES = BKT_THREADS / HEPT_WAVE;
+constexpr int BKT_BINS_PER_THREAD = LOBINS / BKT_THREADS;
+static_assert(LOBINS % BKT_THREADS == 0, "every thread owns the same number of bins");
+template <int CAP>
+__global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned long long* __restrict__ pairs,
+                                                                  unsigned long long* __restrict__ scratch,
+                                                                  const SegParams* __restrict__ seg_params,
+                                                                  const unsigned int* __restrict__ bstart, int N,
+                                                                  int* __restrict__ pos_out) {
+    __shared__ unsigned long long tile_s[CAP];
+    __shared__ unsigned int cur_s[LOBINS + 1];  // [0] stays 0; bin d lives at [d + 1]
+    __shared__ unsigned int wsum_s[BKT_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int seg = blockIdx.y, bucket = blockIdx.x;
+    const unsigned int* o = bstart + (size_t)seg * RADIX;  // keys of the segment with a smaller digit (written by K3)
+    const int start = (int)o[bucket];
+    const int end = bucket == NTOP - 1 ? N : (int)o[bucket + 1];
+    const int nb = end - start;
+    if (nb <= 0) return;
+    const unsigned long long* src = pairs + (size_t)seg * N + start;
+    int* out = pos_out + (size_t)seg * N + start;
     const SegParams rg = seg_params[seg];
-    const unsigned long long* pr = pairs + (size_t)seg * N;
-    auto id_of = [&](unsigned long long p) { return id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale); };
-    for (int j = tid; j < W; j += SORT_THREADS) {
-        const int g = i0 - RANK_K + j;
-        p_s[j + (j >> 2)] = g < 0 ? 0ull : (g < N ? pr[g] : ~0ull);
+    auto lo_of = [&](unsigned long long p) {
+        return id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
+    };
+    const bool in_lds = nb <= CAP;
+    unsigned int* bin_s = cur_s + 1;
+#pragma unroll
+    for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) bin_s[u * BKT_THREADS + tid] = 0;
+    if (tid == 0) cur_s[0] = 0;
+    constexpr int ITEMS = CAP / BKT_THREADS;
+    unsigned long long mine[ITEMS];
+    if (in_lds) {
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int i = u * BKT_THREADS + tid;
+            mine[u] = i < nb ? src[i] : 0ull;
+        }
     }
     __syncthreads();
-    const int b = i0 + RANK_PER_THREAD * tid;  // first of this thread's 4 positions
-    if (b >= N) return;
-    const unsigned long long* win0 = p_s + 5 * tid;  // window slot j of this thread lives at win0[j + j/4]
-#define WIN(j) win0[(j) + ((j) >> 2)]
-    unsigned long long mine[RANK_PER_THREAD];
-    int cnt[RANK_PER_THREAD];
+    if (in_lds) {
 #pragma unroll
-    for (int e = 0; e < RANK_PER_THREAD; ++e) {
-        mine[e] = WIN(RANK_K + e);
-        cnt[e] = 0;
+        for (int u = 0; u < ITEMS; ++u)
+            if (u * BKT_THREADS + tid < nb) atomicAdd(&bin_s[lo_of(mine[u])], 1u);
+    } else {
+        for (int i = tid; i < nb; i += BKT_THREADS) atomicAdd(&bin_s[lo_of(src[i])], 1u);
     }
+    __syncthreads();
+    {   // exclusive prefix over the bins: thread owns bins BPT*tid .. BPT*tid + BPT - 1
+        unsigned int c[BKT_BINS_PER_THREAD], tot = 0;
 #pragma unroll
-    for (int j = 0; j < 2 * RANK_K + RANK_PER_THREAD; ++j) {
-        const unsigned long long p = WIN(j);
+        for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) { c[u] = bin_s[BKT_BINS_PER_THREAD * tid + u]; tot += c[u]; }
+        unsigned int incl = tot;
 #pragma unroll
-        for (int e = 0; e < RANK_PER_THREAD; ++e)
-            if (j >= e && j <= e + 2 * RANK_K) cnt[e] += p < mine[e];  // window of element e: [e, e + 2K]
-    }
-#pragma unroll
-    for (int e = 0; e < RANK_PER_THREAD; ++e) {
-        const int i = b + e;
-        if (i >= N) break;
-        int pos = i - RANK_K + cnt[e];
-        // does the id group reach a window edge?  (edge slots outside the segment never belong to it)
-        const unsigned int id = id_of(mine[e]);
-        const bool left_open = i - RANK_K >= 0 && id_of(WIN(e)) == id;
-        const bool right_open = i + RANK_K < N && id_of(WIN(e + 2 * RANK_K)) == id;
-        if (left_open || right_open) {
-            // walk the whole group from memory, 8 independent loads per round trip
-            int smaller = 0, first = i;
-            bool go = true;
-            for (int j = i - 1; go && j >= 0; j -= 8) {
-                unsigned long long p[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) p[u] = j - u >= 0 ? pr[j - u] : 0ull;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    go = go && j - u >= 0 && id_of(p[u]) == id;
-                    smaller += go && p[u] < mine[e];
-                    first = go ? j - u : first;
-                }
-            }
-            go = true;
-            for (int j = i + 1; go && j < N; j += 8) {
-                unsigned long long p[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) p[u] = j + u < N ? pr[j + u] : ~0ull;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    go = go && j + u < N && id_of(p[u]) == id;
-                    smaller += go && p[u] < mine[e];
-                }
-            }
-            pos = first + smaller;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
         }
-        pos_out[(size_t)seg * N + pos] = (int)(unsigned int)mine[e];
+        if (lane == 63) wsum_s[w] = incl;
+        __syncthreads();
+        unsigned int run = incl - tot;
+#pragma unroll
+        for (int ww = 0; ww < BKT_WAVES; ++ww)
+            if (ww < w) run += wsum_s[ww];
+#pragma unroll
+        for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) {
+            bin_s[BKT_BINS_PER_THREAD * tid + u] = run;
+            run += c[u];
+        }
     }
-#undef WIN
+    __syncthreads();
+    // (separate LDS / global code paths: one pointer for both would compile to slow FLAT accesses)
+    auto rank_all = [&](const unsigned long long* grouped) {
+        for (int i = tid; i < nb; i += BKT_THREADS) {
+            const unsigned long long p = grouped[i];
+            const unsigned int d = lo_of(p);
+            const int g0 = (int)cur_s[d], g1 = (int)cur_s[d + 1];  // = bin_s[d - 1], bin_s[d]
+            int smaller = 0;
+            for (int j = g0; j < g1; j += 4) {  // 4 independent reads per round trip
+                unsigned long long q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = grouped[min(j + u, g1 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) smaller += (j + u < g1) && (q[u] < p);
+            }
+            out[g0 + smaller] = (int)(unsigned int)p;
+        }
+    };
+    if (in_lds) {
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u)
+            if (u * BKT_THREADS + tid < nb) tile_s[atomicAdd(&bin_s[lo_of(mine[u])], 1u)] = mine[u];
+        __syncthreads();
+        rank_all(tile_s);
+    } else {
+        unsigned long long* g = scratch + (size_t)seg * N + start;
+        for (int i = tid; i < nb; i += BKT_THREADS) {
+            const unsigned long long p = src[i];
+            g[atomicAdd(&bin_s[lo_of(p)], 1u)] = p;
+        }
+        __threadfence_block();
+        __syncthreads();
+        rank_all(g);
+    }
 }
 
 // src variant: per (table, head) upper bound of the shift in units of span: max_n (phi * cfac + eta), written into
@@ -496,18 +489,19 @@ __global__ __launch_bounds__(SORT_THREADS) void raw_keygen_hist_kernel(const flo
         if (n < L) {
             const unsigned int u = ordered_bits(keys[(size_t)seg * L + n]);
             keys0[(size_t)seg * L + n] = u;
-            atomicAdd(&h_s[id16_of(u, rg.kmin, rg.scale) & 0xFF], 1u);
+            atomicAdd(&h_s[id16_of(u, rg.kmin, rg.scale) >> TOP_SHIFT], 1u);
         }
     }
     __syncthreads();
     hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
 }
 
-// the passes shared by hept_sort_tables and hept_segmented_argsort: keys0 + hist(low byte) + params -> pos
+// the passes shared by hept_sort_tables and hept_segmented_argsort: keys0 + hist(top bits) + params -> pos
 struct SortBuffers {
     unsigned int* keys0;
     unsigned long long *pa, *pb;
     unsigned int* hist;
+    unsigned int* bstart;  // [segs][RADIX] first position of every top-level bucket
     SegParams* params;
 };
 SortBuffers carve_sort(void* sort_ws, int segs, int N) {
@@ -523,19 +517,24 @@ SortBuffers carve_sort(void* sort_ws, int segs, int N) {
     ws += al((size_t)segs * N * 8);
     b.hist = reinterpret_cast<unsigned int*>(ws);
     ws += al((size_t)segs * n_chunks * RADIX * 4);
+    b.bstart = reinterpret_cast<unsigned int*>(ws);
+    ws += al((size_t)segs * RADIX * 4);
     b.params = reinterpret_cast<SegParams*>(ws);
     return b;
 }
+constexpr int BKT_CAP_SMALL = HEPT_BKT_CAP;  // LDS tile: the average bucket is N/NTOP
+constexpr int BKT_CAP_LARGE = 3 * HEPT_BKT_CAP;  // for longer segments
 void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const dim3 grid(n_chunks, segs), block(SORT_THREADS);
-    hipLaunchKernelGGL(scan_kernel, dim3(segs), dim3(RADIX), 0, st, b.hist, n_chunks);
-    hipLaunchKernelGGL(scatter_kernel<false>, grid, block, 0, st, b.keys0, nullptr, b.params, b.hist, N, n_chunks, b.pa);
-    hipLaunchKernelGGL(hist_hi_kernel, grid, block, 0, st, b.pa, b.params, N, b.hist, n_chunks);
-    hipLaunchKernelGGL(scan_kernel, dim3(segs), dim3(RADIX), 0, st, b.hist, n_chunks);
-    hipLaunchKernelGGL(scatter_kernel<true>, grid, block, 0, st, nullptr, b.pa, b.params, b.hist, N, n_chunks, b.pb);
-    const dim3 grid7((N + RANK_SPAN - 1) / RANK_SPAN, segs);
-    hipLaunchKernelGGL(neighbour_rank_kernel, grid7, block, 0, st, b.pb, b.params, N, pos);
+    hipLaunchKernelGGL(scatter_kernel, grid, block, 0, st, b.keys0, b.params, b.hist, N, n_chunks, b.bstart, b.pa);
+    const dim3 grid4(NTOP, segs);
+    if ((size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2))
+        hipLaunchKernelGGL(bucket_sort_kernel<BKT_CAP_SMALL>, grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
+                           b.bstart, N, pos);
+    else
+        hipLaunchKernelGGL(bucket_sort_kernel<BKT_CAP_LARGE>, grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
+                           b.bstart, N, pos);
 }
 
 }  // namespace
@@ -545,7 +544,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t sort_bytes(size_t segs, size_t N) {
     const size_t n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     return align256(segs * N * 4) + 2 * align256(segs * N * 8) + align256(segs * n_chunks * RADIX * 4) +
-           align256(segs * sizeof(SegParams));
+           align256(segs * RADIX * 4) + align256(segs * sizeof(SegParams));
 }
 
 extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) { return sort_bytes((size_t)2 * Tl * H, N); }
