@@ -53,6 +53,25 @@ def test_segmented_argsort_is_stable_and_handles_padding(gpu_device):
     assert torch.equal(ops.segmented_argsort(one.to(gpu_device)).long().cpu(), torch.sort(one, dim=-1, stable=True).indices)
 
 
+def test_segmented_argsort_skewed_and_long_segments(gpu_device):
+    """The sort's slow paths: a bucket larger than the LDS tile (streamed through global scratch), one id group
+    holding most of a segment, and segments long enough for the large-tile kernel."""
+    g = torch.Generator().manual_seed(6)
+    keys = torch.randn(5, 20000, generator=g)
+    keys[0, :18000] = keys[0, :18000] * 1e-4 + 3.0          # 90 % of the keys inside 1/1000 of the range
+    keys[1, 2000:] = 7.5                                     # one id group of 18 000 equal keys (ties by index)
+    keys[2] = torch.randint(0, 50, (20000,), generator=g).float()            # 50 distinct values, huge tie groups
+    keys[3, ::2] = float("inf")                              # half the segment is padding
+    keys[3, 1] = float("-inf")
+    keys[4] = torch.linspace(1.0, 1.0 + 1e-3, 20000).flip(0)  # descending, all keys nearly equal
+    pos = ops.segmented_argsort(keys.to(gpu_device)).long().cpu()
+    assert torch.equal(pos, torch.sort(keys, dim=-1, stable=True).indices)
+    long_keys = torch.randn(2, 300000, generator=g)
+    long_keys[1] = (long_keys[1] * 4).round() / 4           # quantised: ~100 distinct values
+    pos = ops.segmented_argsort(long_keys.to(gpu_device)).long().cpu()
+    assert torch.equal(pos, torch.sort(long_keys, dim=-1, stable=True).indices)
+
+
 def test_prepare_then_attention_pipeline(gpu_device):
     """prepare_input (HIP) -> HEPTAttention (HIP) end to end on GPU tensors only, against the CPU pipeline."""
     import hept_oracle as ho
