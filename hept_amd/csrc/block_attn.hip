@@ -34,8 +34,13 @@ namespace {
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
+// Register budget: a workgroup lives ~10 us, most of it waiting for its gathered rows, so throughput is set by how
+// many workgroups a CU holds.  16-bit tiles: 8 waves per SIMD (<= 64 VGPRs, no spills; 87 -> 80 us at tracking-60k);
+// f32 tiles carry twice the fragments: 6 waves per SIMD; the ragged-tile variants keep their masks in registers
+// and get a looser target (no spills anywhere).
 template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL>
-__global__ __launch_bounds__(64 * NKT) void block_attn_kernel(const char* __restrict__ qhat,
+__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(FULL ? (BF16 ? 8 : 6) : (BF16 ? 6 : 4), FULL ? (BF16 ? 8 : 6) : (BF16 ? 6 : 4))))
+void block_attn_kernel(const char* __restrict__ qhat,
                                                               const char* __restrict__ kvhat,
                                                               const int* __restrict__ qpos,
                                                               const int* __restrict__ kpos,
