@@ -6,8 +6,9 @@ attention -> combine + out_linear) over one synthetic tracking-60k cloud whose i
 resident in HBM.  N = 1: BASELINE config 3 (N_raw 60000 -> 60032 padded, block 128, n_hashes 3,
 bf16 MFMA tiles).  N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling
 over hash tables — every GPU keeps 3 tables (n_hashes = 3·N in total), inputs replicated, ONE
-exchange step (reduce-scatter of the per-table partial sums + all-gather of the output).
+exchange step (all-to-all of the packed per-rank table sums + all-gather of the output).
 ``value`` = points/s normalised to 3 table passes per point: N_gpus · N_raw / step time.
+``--tables-per-gpu 1`` is BASELINE config 4 (n_hashes = #GPUs, one table per GPU).
 
 Prints ONE JSON line on rank 0; see DESIGN.md §6 for every field.
 """
@@ -82,6 +83,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--tables-per-gpu", type=int, default=TABLES_PER_GPU,
+                    help="hash tables per GPU (default 3 = BASELINE config 3 at N=1; 1 = config 4: n_hashes = #GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage HIP-event breakdown to stderr")
     args = ap.parse_args()
@@ -104,7 +107,8 @@ def main():
     from hept_amd import HEPTAttention, ops
     from hept_amd.synthetic import workload_inputs
 
-    n_tables = TABLES_PER_GPU * world
+    tables_per_gpu = args.tables_per_gpu
+    n_tables = tables_per_gpu * world
     inp = workload_inputs(WORKLOAD, seed=0, n_hashes=n_tables)
     B, H, D = 128, 8, 24
     C = inp["coords"].shape[1]
@@ -163,10 +167,10 @@ def main():
         tile_bytes = 2 if args.precision == "bf16" else 4
         attn_ms = stage_ms["block_attn"] / max(n_rec, 1)
         if args.precision == "bf16":
-            ach = algorithmic_bytes(n, H, D, C, TABLES_PER_GPU, tile_bytes) / (attn_ms * 1e-3) / 1e9
+            ach = algorithmic_bytes(n, H, D, C, tables_per_gpu, tile_bytes) / (attn_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
         else:
-            ach = algorithmic_flops(n, H, D, C, TABLES_PER_GPU, B) / (attn_ms * 1e-3) / 1e12
+            ach = algorithmic_flops(n, H, D, C, tables_per_gpu, B) / (attn_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF}
         roof["kernel"] = "block_attn_kernel"
         roof["kernel_ms"] = attn_ms
@@ -183,10 +187,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{WORKLOAD}: N_raw={n_raw} padded N={n}, block_size={B}, n_hashes={TABLES_PER_GPU}/GPU "
+            "config": {"workload": f"{WORKLOAD}: N_raw={n_raw} padded N={n}, block_size={B}, n_hashes={tables_per_gpu}/GPU "
                                    f"({n_tables} total), H={H}, D={D}, C={C}, tiles {args.precision}",
-                       "parallelism": f"tables sharded {TABLES_PER_GPU}/GPU over {world} GPU(s)",
-                       "hbm_algorithmic_GBps_block_attn": algorithmic_bytes(n, H, D, C, TABLES_PER_GPU, tile_bytes) / (attn_ms * 1e-3) / 1e9},
+                       "parallelism": f"tables sharded {tables_per_gpu}/GPU over {world} GPU(s)",
+                       "hbm_algorithmic_GBps_block_attn": algorithmic_bytes(n, H, D, C, tables_per_gpu, tile_bytes) / (attn_ms * 1e-3) / 1e9},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
