@@ -302,9 +302,9 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
 // range [start, end) and only the order inside it is left.  Histogram of the LOW id byte -> exclusive prefix
 // -> scatter (any order): the pairs are now grouped by their full 16-bit id, group g = [first[g], first[g+1]), and
 //        final position(i) = start + first[g] + #{ j in group g : pair_j < pair_i }        (pairs are unique u64)
-// Groups are ~1-5 pairs at tracking-60k.  A bucket larger than the LDS tile takes the same three steps through a
-// global scratch copy (streaming; slower, never wrong); adversarial inputs (all keys inside 1/65536 of the key
-// range) cost O(group^2) compares.
+// Groups are 1-3 pairs at tracking-60k.  A bucket larger than the LDS tile takes the same three steps through a
+// global scratch copy, grouped by a monotone id of the pair over the bucket's own pair range (streaming; slower,
+// never wrong); a tile-sized bucket of equal keys costs at most CAP^2 compares.
 // The whole bucket is loaded into registers with every load in flight at once; only the grouped copy lives in LDS.
 // One bins array serves as histogram, exclusive prefix and scatter cursor: after the scatter cur[d] is one past the
 // last slot of group d, i.e. group d = [cur[d-1], cur[d]).
@@ -331,10 +331,42 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     const unsigned long long* src = pairs + (size_t)seg * N + start;
     int* out = pos_out + (size_t)seg * N + start;
     const SegParams rg = seg_params[seg];
-    auto lo_of = [&](unsigned long long p) {
-        return id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
-    };
     const bool in_lds = nb <= CAP;
+    // Grouping key inside the bucket.  LDS path: the low bits of the global id.  Streaming path (a bucket that does
+    // not fit the tile holds a pile of equal or nearly equal keys, which those bits cannot separate): a monotone id of
+    // the u64 PAIR over the bucket's own pair range -- pairs are unique, so e.g. 60 000 equal keys spread evenly by
+    // index over the bins and the quadratic group count stays small.
+    unsigned long long pmin = 0ull;
+    double pscale = 0.0;
+    if (!in_lds) {
+        __shared__ unsigned long long red_s[2][BKT_WAVES];
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for (int i = tid; i < nb; i += BKT_THREADS) {
+            const unsigned long long p = src[i];
+            lo = p < lo ? p : lo;
+            hi = p > hi ? p : hi;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if (lane == 0) { red_s[0][w] = lo; red_s[1][w] = hi; }
+        __syncthreads();
+#pragma unroll
+        for (int ww = 0; ww < BKT_WAVES; ++ww) {
+            lo = red_s[0][ww] < lo ? red_s[0][ww] : lo;
+            hi = red_s[1][ww] > hi ? red_s[1][ww] : hi;
+        }
+        pmin = lo;
+        pscale = (double)LOBINS / ((double)(hi - lo) + 1.0);
+    }
+    auto lo_of = [&](unsigned long long p) -> unsigned int {
+        if (in_lds) return id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
+        const unsigned int b = (unsigned int)((double)(p - pmin) * pscale);  // monotone in p
+        return b < (unsigned int)LOBINS ? b : (unsigned int)(LOBINS - 1);
+    };
     unsigned int* bin_s = cur_s + 1;
 #pragma unroll
     for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) bin_s[u * BKT_THREADS + tid] = 0;

@@ -72,6 +72,28 @@ def test_segmented_argsort_skewed_and_long_segments(gpu_device):
     assert torch.equal(pos, torch.sort(long_keys, dim=-1, stable=True).indices)
 
 
+def test_degenerate_segments_stay_fast(gpu_device):
+    """All keys equal (zero-initialised features hash to 0 everywhere) used to cost O(N^2) compares per segment --
+    minutes at tracking-60k.  Oversize buckets are now regrouped by a monotone id of the (key, index) pair."""
+    import time
+
+    n = 60032
+    keys = torch.zeros(48, n)
+    keys[1] = 3.25
+    keys[2, n // 2:] = 1.0                       # two piles
+    keys[3] = torch.arange(n).float() // 5000     # 13 piles of 5000
+    keys[4, -200:] = float("inf")                # src-variant padding behind a pile
+    dev_keys = keys.to(gpu_device)
+    ops.segmented_argsort(dev_keys[:1, :4096].contiguous())  # warm-up (library load, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pos = ops.segmented_argsort(dev_keys)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.equal(pos.long().cpu(), torch.sort(keys, dim=-1, stable=True).indices)
+    assert dt < 0.5, f"degenerate sort took {dt:.3f} s"
+
+
 def test_prepare_then_attention_pipeline(gpu_device):
     """prepare_input (HIP) -> HEPTAttention (HIP) end to end on GPU tensors only, against the CPU pipeline."""
     import hept_oracle as ho
