@@ -78,9 +78,12 @@ struct FfnIn {
 };
 constexpr int FFN_D = 24, FFN_PITCH = 25, FFN_WFLOATS = 2 * FFN_D * FFN_D + 4 * FFN_D;
 
-template <bool P16, bool FFN = false>
+// DT = compile-time head dimension (0: use the runtime value).  With a runtime D the `u < D` guards of the MFMA loop
+// became one branch + one fully exposed LDS round trip per step (ds_read, s_waitcnt lgkmcnt(0), v_mfma, 96 times
+// per wave); with DT the loop is straight-line code.
+template <bool P16, bool FFN = false, int DT = 0>
 __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
-                                                                  int H, int D, int n0, int n_count,
+                                                                  int H, int D_rt, int n0, int n_count,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out, FfnIn ffn = FfnIn{}) {
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     constexpr int TMAX = HEPT_MAX_TABLES;
     extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H (even-padded)][28 (d)][32 (c, zero padded)]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
+    const int D = DT ? DT : D_rt;
     const int HD = H * D, HP = (H + 1) & ~1;
     // W is (D, H*D) row-major: read it coalesced and transpose while writing LDS (a transposed gather from global
     // cost 6.6 us per launch); the zero padding is a disjoint set of slots, so no barrier sits between the two loops
@@ -135,6 +139,14 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 if (more && t < tpre) nxt[t].load(row_of(hp + 2) + (size_t)t * tstride);
+            // this head's weight column, requested before the rows are unpacked (LDS latency hides under the VALU work)
+            float wv[28];
+            {
+                const float* wrow = wt_s + (size_t)(hp + hh) * 28 * 32 + li;
+#pragma unroll
+                for (int u = 0; u < 28; ++u)
+                    if (u < D) wv[u] = wrow[u * 32];
+            }
             float s[28];
 #pragma unroll
             for (int u = 0; u < 28; ++u) s[u] = 0.f;
@@ -148,11 +160,9 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                 den += extra.add_to(s, D);
             }
             const float inv = 1.0f / den;
-            const int head = hp + hh;
-            const float* wrow = wt_s + (size_t)head * 28 * 32 + li;
 #pragma unroll
             for (int u = 0; u < 28; ++u)
-                if (u < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[u] * inv, wrow[u * 32], acc, 0, 0, 0);
+                if (u < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[u] * inv, wv[u], acc, 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 3; ++t) cur[t] = nxt[t];
         }
@@ -341,11 +351,18 @@ extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, i
     hipStream_t st = (hipStream_t)stream;
     if (part_precision == HEPT_PREC_BF16) {
         if (D != 24) return HEPT_ERR_SHAPE;  // packed rows keep the denominator at widened column 24
-        hipLaunchKernelGGL((combine_out_kernel<true, false>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
-                           n0, n_count, out_weight, out_bias, out, FfnIn{});
+        hipLaunchKernelGGL((combine_out_kernel<true, false, 24>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H,
+                           D, n0, n_count, out_weight, out_bias, out, FfnIn{});
     } else if (part_precision == HEPT_PREC_F32) {
-        hipLaunchKernelGGL((combine_out_kernel<false, false>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
-                           n0, n_count, out_weight, out_bias, out, FfnIn{});
+        if (D == 24)
+            hipLaunchKernelGGL((combine_out_kernel<false, false, 24>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N,
+                               H, D, n0, n_count, out_weight, out_bias, out, FfnIn{});
+        else if (D == 16)
+            hipLaunchKernelGGL((combine_out_kernel<false, false, 16>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N,
+                               H, D, n0, n_count, out_weight, out_bias, out, FfnIn{});
+        else
+            hipLaunchKernelGGL((combine_out_kernel<false, false, 0>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N,
+                               H, D, n0, n_count, out_weight, out_bias, out, FfnIn{});
     } else {
         return HEPT_ERR_SHAPE;
     }
@@ -368,10 +385,10 @@ extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, i
     hipStream_t st = (hipStream_t)stream;
     const FfnIn ffn{x, norm_w, norm_b, ff1_w, ff1_b, ff2_w, ff2_b, eps};
     if (part_precision == HEPT_PREC_BF16)
-        hipLaunchKernelGGL((combine_out_kernel<true, true>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
+        hipLaunchKernelGGL((combine_out_kernel<true, true, 24>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
                            n0, n_count, out_weight, out_bias, y, ffn);
     else if (part_precision == HEPT_PREC_F32)
-        hipLaunchKernelGGL((combine_out_kernel<false, true>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
+        hipLaunchKernelGGL((combine_out_kernel<false, true, 24>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
                            n0, n_count, out_weight, out_bias, y, ffn);
     else
         return HEPT_ERR_SHAPE;
