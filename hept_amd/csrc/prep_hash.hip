@@ -23,6 +23,9 @@ constexpr int PREP_THREADS = 256;
 // 8 chunks + one pad slot per head
 constexpr int PREP_WAVE_SLOTS = 64 * 8 + 8;
 constexpr int PREP_POINTS = 8;   // points per wave iteration; lane = (point = lane >> 3, head = lane & 7)
+// LDS pitch (floats) of one head's alpha slab [e][HEPT_MAX_TABLES]: = 4 (mod 32), so that the 8 heads of a wave read
+// 8 disjoint bank groups (a plain E * 8 pitch put them on two groups: 4-way conflicts, 60 % of the LDS cycles)
+constexpr int alpha_pitch(int E) { return ((E * HEPT_MAX_TABLES + 27) / 32) * 32 + 4; }
 
 // sqrt_w[h][c] = sqrt(2 * sum_k exp(min(sum_d w[h*D+d][r*K+k], 50))), column 0 duplicated (eta, phi share dR).
 // One thread per (h, r, k) term (coalesced over k), then a K-term sum per (h, r).
@@ -206,7 +209,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
             if (t < Tl) {
                 float acc = 0.f;
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc = fmaf(a[e], alpha_s[(h * E + e) * HEPT_MAX_TABLES + t], acc);
+                for (int e = 0; e < E; ++e) acc = fmaf(a[e], alpha_s[h * alpha_pitch(E) + e * HEPT_MAX_TABLES + t], acc);
                 if (live) {
                     proj[((size_t)t * H + h) * N + n] = is_pad ? INFINITY : acc;
                     mn[t] = fminf(mn[t], acc);
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
     constexpr int H = 8, E = D + C;
     static_assert(D % 4 == 0 && E <= 30 && D <= 28, "row packing needs D%4==0, E<=30");
-    __shared__ float alpha_s[H * E * HEPT_MAX_TABLES];
+    __shared__ float alpha_s[H * alpha_pitch(E)];
     __shared__ float sw_s[H * C];
     __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * HEPT_MAX_TABLES * H * 4];
     __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * PREP_WAVE_SLOTS];
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     if (role != 2) {
         for (int i = threadIdx.x; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
             const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
-            alpha_s[i] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
+            alpha_s[(he / E) * alpha_pitch(E) + (he % E) * HEPT_MAX_TABLES + t] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
         }
         for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
         __syncthreads();
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
     const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
     void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
     constexpr int D = 24, H = 8, E = D + C;
-    __shared__ float alpha_s[H * E * HEPT_MAX_TABLES];
+    __shared__ float alpha_s[H * alpha_pitch(E)];
     __shared__ float sw_s[H * C];
     __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * HEPT_MAX_TABLES * H * 4];
     __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * PREP_WAVE_SLOTS];
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
     if (role != 2) {
         for (int i = threadIdx.x; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
             const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
-            alpha_s[i] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
+            alpha_s[(he / E) * alpha_pitch(E) + (he % E) * HEPT_MAX_TABLES + t] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
         }
         for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
     }
