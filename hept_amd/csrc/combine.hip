@@ -17,6 +17,8 @@ namespace {
 
 constexpr int CMB_THREADS = 256;
 constexpr int CMB_WAVES = CMB_THREADS / HEPT_WAVE;
+constexpr int WT_PITCH = 33;  // LDS pitch of one (head, d) weight row: odd, so the transposing writes of the staging
+                              // loop (consecutive d) land on consecutive banks (pitch 32: 32-way conflicts)
 
 // Raw 16-B pieces of one (table, point, head) partial row kept in registers until they are needed
 // (P16: 4 pieces = 64 B; f32: 7 pieces = the 28 leading floats, which hold numer 0..D-1 and the denominator).
@@ -95,16 +97,16 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     const int HD = H * D, HP = (H + 1) & ~1;
     // W is (D, H*D) row-major: read it coalesced and transpose while writing LDS (a transposed gather from global
     // cost 6.6 us per launch); the zero padding is a disjoint set of slots, so no barrier sits between the two loops
-    for (int i = tid; i < HP * 28 * 32; i += CMB_THREADS) {
-        const int c = i & 31, d = (i >> 5) % 28, h = i / (28 * 32);
+    for (int i = tid; i < HP * 28 * WT_PITCH; i += CMB_THREADS) {
+        const int c = i % WT_PITCH, d = (i / WT_PITCH) % 28, h = i / (28 * WT_PITCH);
         if (!(c < D && d < D && h < H)) wt_s[i] = 0.f;
     }
     for (int i = tid; i < D * HD; i += CMB_THREADS) {
         const int c = i / HD, h = (i % HD) / D, d = i % D;
-        wt_s[(h * 28 + d) * 32 + c] = W[i];
+        wt_s[(h * 28 + d) * WT_PITCH + c] = W[i];
     }
     const float bia = (li < D && bias) ? bias[li] : 0.f;
-    float* ffn_s = wt_s + HP * 28 * 32;                        // [w1 | w2 | b1 | b2 | ln_w | ln_b]
+    float* ffn_s = wt_s + HP * 28 * WT_PITCH;                     // [w1 | w2 | b1 | b2 | ln_w | ln_b]
     float* stage_s = ffn_s + FFN_WFLOATS + w * 32 * FFN_PITCH;  // this wave's 32 x D tile
     if constexpr (FFN) {
         for (int i = tid; i < FFN_D * FFN_D; i += CMB_THREADS) {
@@ -142,10 +144,10 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             // this head's weight column, requested before the rows are unpacked (LDS latency hides under the VALU work)
             float wv[28];
             {
-                const float* wrow = wt_s + (size_t)(hp + hh) * 28 * 32 + li;
+                const float* wrow = wt_s + (size_t)(hp + hh) * 28 * WT_PITCH + li;
 #pragma unroll
                 for (int u = 0; u < 28; ++u)
-                    if (u < D) wv[u] = wrow[u * 32];
+                    if (u < D) wv[u] = wrow[u * WT_PITCH];
             }
             float s[28];
 #pragma unroll
@@ -344,7 +346,7 @@ extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, i
     if (Tl < 1 || N < 1 || H < 1 || H > 15 || D < 1 || D > 28 || n0 < 0 || n_count < 0 || n0 + n_count > N)
         return HEPT_ERR_SHAPE;
     if (n_count == 0) return HEPT_OK;
-    const size_t lds = sizeof(float) * (size_t)((H + 1) & ~1) * 28 * 32;
+    const size_t lds = sizeof(float) * (size_t)((H + 1) & ~1) * 28 * WT_PITCH;
     const int n_tiles = (n_count + 31) / 32;
     const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
     const int grid = wgs < 2048 ? wgs : 2048;
@@ -378,7 +380,7 @@ extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, i
     if (Tl < 1 || N < 1 || H < 1 || H > 15 || D != FFN_D || n0 < 0 || n_count < 0 || n0 + n_count > N)
         return HEPT_ERR_SHAPE;
     if (n_count == 0) return HEPT_OK;
-    const size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * 32 + FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH);
+    const size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * WT_PITCH + FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH);
     const int n_tiles = (n_count + 31) / 32;
     const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
     const int grid = wgs < 2048 ? wgs : 2048;
