@@ -83,7 +83,10 @@ constexpr int FFN_D = 24, FFN_PITCH = 25, FFN_WFLOATS = 2 * FFN_D * FFN_D + 4 * 
 // DT = compile-time head dimension (0: use the runtime value).  With a runtime D the `u < D` guards of the MFMA loop
 // became one branch + one fully exposed LDS round trip per step (ds_read, s_waitcnt lgkmcnt(0), v_mfma, 96 times
 // per wave); with DT the loop is straight-line code.
-template <bool P16, bool FFN = false, int DT = 0>
+// SPLIT (few tiles: a 6k cloud, or the N/G points a table-sharded rank finishes): the four waves of a workgroup
+// share ONE tile, each reduces every fourth head pair, and the partial 32 x D products meet in LDS -- a quarter of
+// the serial chain per wave when there are not enough tiles to fill the machine anyway.
+template <bool P16, bool FFN = false, int DT = 0, bool SPLIT = false>
 __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
                                                                   int H, int D_rt, int n0, int n_count,
                                                                   const float* __restrict__ W,
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     const float bia = (li < D && bias) ? bias[li] : 0.f;
     float* ffn_s = wt_s + HP * 28 * WT_PITCH;                     // [w1 | w2 | b1 | b2 | ln_w | ln_b]
     float* stage_s = ffn_s + FFN_WFLOATS + w * 32 * FFN_PITCH;  // this wave's 32 x D tile
+    float* stage_s_end = ffn_s + (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0);
     if constexpr (FFN) {
         for (int i = tid; i < FFN_D * FFN_D; i += CMB_THREADS) {
             ffn_s[i] = ffn.w1[i];
@@ -123,7 +127,10 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     __syncthreads();
     const size_t tstride = (size_t)N * H * ROWF;
     const int n_tiles = (n_count + 31) / 32;
-    for (int tile = blockIdx.x * CMB_WAVES + w; tile < n_tiles; tile += gridDim.x * CMB_WAVES) {
+    const int hp0 = SPLIT ? 2 * w : 0, hstep = SPLIT ? 2 * CMB_WAVES : 2;
+    float* red_s = stage_s_end;  // SPLIT: [CMB_WAVES - 1][16][64] partial accumulators of waves 1..
+    for (int tile = SPLIT ? blockIdx.x : blockIdx.x * CMB_WAVES + w; tile < n_tiles;
+         tile += SPLIT ? gridDim.x : gridDim.x * CMB_WAVES) {
         const int i = tile * 32 + li;
         const int n = n0 + (i < n_count ? i : n_count - 1);
         const float* prow = part + (size_t)n * H * ROWF;
@@ -135,12 +142,12 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         const int tpre = Tl < 3 ? Tl : 3;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-            if (t < tpre) cur[t].load(row_of(0) + (size_t)t * tstride);
-        for (int hp = 0; hp < HP; hp += 2) {
-            const bool more = hp + 2 < HP;
+            if (t < tpre && hp0 < HP) cur[t].load(row_of(hp0) + (size_t)t * tstride);
+        for (int hp = hp0; hp < HP; hp += hstep) {
+            const bool more = hp + hstep < HP;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
-                if (more && t < tpre) nxt[t].load(row_of(hp + 2) + (size_t)t * tstride);
+                if (more && t < tpre) nxt[t].load(row_of(hp + hstep) + (size_t)t * tstride);
             // this head's weight column, requested before the rows are unpacked (LDS latency hides under the VALU work)
             float wv[28];
             {
@@ -167,6 +174,24 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                 if (u < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[u] * inv, wv[u], acc, 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 3; ++t) cur[t] = nxt[t];
+        }
+        if constexpr (SPLIT) {
+            if (w != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red_s[((w - 1) * 16 + r) * 64 + lane] = acc[r];
+            }
+            __syncthreads();
+            if (w != 0) {
+                __syncthreads();  // pairs with the barrier after wave 0's epilogue (red_s is reused by the next tile)
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float tot = acc[r];
+#pragma unroll
+                for (int ww = 1; ww < CMB_WAVES; ++ww) tot += red_s[((ww - 1) * 16 + r) * 64 + lane];
+                acc[r] = tot;
+            }
         }
         if constexpr (FFN) {
 #pragma unroll
@@ -243,6 +268,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                 if (i2 < n_count && li < D) out[(size_t)i2 * D + li] = acc[r] + bia;
             }
         }
+        if constexpr (SPLIT) __syncthreads();
     }
 }
 
@@ -339,6 +365,28 @@ extern "C" int hept_reduce_tables(const float* part, int part_precision, int Tl,
     return hept_launch_status();
 }
 
+// few tiles: one tile per workgroup, head pairs split over its waves (SPLIT); else one tile per wave
+constexpr int CMB_SPLIT_BELOW = 1024;  // tiles; 1024 tiles = one wave per SIMD on 256 CUs
+
+template <bool P16, bool FFN, int DT>
+int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int D, int n0, int n_count, const float* W,
+                   const float* b, float* out, const FfnIn& ffn) {
+    const int n_tiles = (n_count + 31) / 32;
+    const bool split = n_tiles < CMB_SPLIT_BELOW;
+    const size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * WT_PITCH +
+                                        (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0) +
+                                        (split ? (CMB_WAVES - 1) * 16 * 64 : 0));
+    if (split) {
+        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true>), dim3(n_tiles), dim3(CMB_THREADS), lds, st, part, Tl, N,
+                           H, D, n0, n_count, W, b, out, ffn);
+    } else {
+        const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
+        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, false>), dim3(wgs < 2048 ? wgs : 2048), dim3(CMB_THREADS), lds,
+                           st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn);
+    }
+    return hept_launch_status();
+}
+
 extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
                                 int n_count, const float* out_weight, const float* out_bias, float* out,
                                 void* stream) {
@@ -346,29 +394,16 @@ extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, i
     if (Tl < 1 || N < 1 || H < 1 || H > 15 || D < 1 || D > 28 || n0 < 0 || n_count < 0 || n0 + n_count > N)
         return HEPT_ERR_SHAPE;
     if (n_count == 0) return HEPT_OK;
-    const size_t lds = sizeof(float) * (size_t)((H + 1) & ~1) * 28 * WT_PITCH;
-    const int n_tiles = (n_count + 31) / 32;
-    const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
-    const int grid = wgs < 2048 ? wgs : 2048;
     hipStream_t st = (hipStream_t)stream;
+    const FfnIn none{};
     if (part_precision == HEPT_PREC_BF16) {
         if (D != 24) return HEPT_ERR_SHAPE;  // packed rows keep the denominator at widened column 24
-        hipLaunchKernelGGL((combine_out_kernel<true, false, 24>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H,
-                           D, n0, n_count, out_weight, out_bias, out, FfnIn{});
-    } else if (part_precision == HEPT_PREC_F32) {
-        if (D == 24)
-            hipLaunchKernelGGL((combine_out_kernel<false, false, 24>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N,
-                               H, D, n0, n_count, out_weight, out_bias, out, FfnIn{});
-        else if (D == 16)
-            hipLaunchKernelGGL((combine_out_kernel<false, false, 16>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N,
-                               H, D, n0, n_count, out_weight, out_bias, out, FfnIn{});
-        else
-            hipLaunchKernelGGL((combine_out_kernel<false, false, 0>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N,
-                               H, D, n0, n_count, out_weight, out_bias, out, FfnIn{});
-    } else {
-        return HEPT_ERR_SHAPE;
+        return combine_launch<true, false, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none);
     }
-    return hept_launch_status();
+    if (part_precision != HEPT_PREC_F32) return HEPT_ERR_SHAPE;
+    if (D == 24) return combine_launch<false, false, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none);
+    if (D == 16) return combine_launch<false, false, 16>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none);
+    return combine_launch<false, false, 0>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none);
 }
 
 extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
@@ -380,19 +415,11 @@ extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, i
     if (Tl < 1 || N < 1 || H < 1 || H > 15 || D != FFN_D || n0 < 0 || n_count < 0 || n0 + n_count > N)
         return HEPT_ERR_SHAPE;
     if (n_count == 0) return HEPT_OK;
-    const size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * WT_PITCH + FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH);
-    const int n_tiles = (n_count + 31) / 32;
-    const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
-    const int grid = wgs < 2048 ? wgs : 2048;
     hipStream_t st = (hipStream_t)stream;
     const FfnIn ffn{x, norm_w, norm_b, ff1_w, ff1_b, ff2_w, ff2_b, eps};
     if (part_precision == HEPT_PREC_BF16)
-        hipLaunchKernelGGL((combine_out_kernel<true, true, 24>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
-                           n0, n_count, out_weight, out_bias, y, ffn);
-    else if (part_precision == HEPT_PREC_F32)
-        hipLaunchKernelGGL((combine_out_kernel<false, true, 24>), dim3(grid), dim3(CMB_THREADS), lds, st, part, Tl, N, H, D,
-                           n0, n_count, out_weight, out_bias, y, ffn);
-    else
-        return HEPT_ERR_SHAPE;
-    return hept_launch_status();
+        return combine_launch<true, true, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, y, ffn);
+    if (part_precision == HEPT_PREC_F32)
+        return combine_launch<false, true, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, y, ffn);
+    return HEPT_ERR_SHAPE;
 }
