@@ -99,15 +99,15 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     const int D = DT ? DT : D_rt;
     const int HD = H * D, HP = (H + 1) & ~1;
     // W is (D, H*D) row-major: read it coalesced and transpose while writing LDS (a transposed gather from global
-    // cost 6.6 us per launch); the zero padding is a disjoint set of slots, so no barrier sits between the two loops
-    for (int i = tid; i < HP * 28 * WT_PITCH; i += CMB_THREADS) {
-        const int c = i % WT_PITCH, d = (i / WT_PITCH) % 28, h = i / (28 * WT_PITCH);
-        if (!(c < D && d < D && h < H)) wt_s[i] = 0.f;
-    }
+    // cost 6.6 us per launch).  Slab of head h: [d][c] at pitch WT_PITCH, only the D x D entries that are read are
+    // written (lanes >= D read column D-1: their MFMA output columns are never stored); the pad head of an odd H is 0.
     for (int i = tid; i < D * HD; i += CMB_THREADS) {
         const int c = i / HD, h = (i % HD) / D, d = i % D;
         wt_s[(h * 28 + d) * WT_PITCH + c] = W[i];
     }
+    if (HP > H)
+        for (int i = tid; i < 28 * WT_PITCH; i += CMB_THREADS) wt_s[H * 28 * WT_PITCH + i] = 0.f;
+    const int lc = li < D ? li : D - 1;
     const float bia = (li < D && bias) ? bias[li] : 0.f;
     float* ffn_s = wt_s + HP * 28 * WT_PITCH;                     // [w1 | w2 | b1 | b2 | ln_w | ln_b]
     float* stage_s = ffn_s + FFN_WFLOATS + w * 32 * FFN_PITCH;  // this wave's 32 x D tile
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             // this head's weight column, requested before the rows are unpacked (LDS latency hides under the VALU work)
             float wv[28];
             {
-                const float* wrow = wt_s + (size_t)(hp + hh) * 28 * WT_PITCH + li;
+                const float* wrow = wt_s + (size_t)(hp + hh) * 28 * WT_PITCH + lc;
 #pragma unroll
                 for (int u = 0; u < 28; ++u)
                     if (u < D) wv[u] = wrow[u * WT_PITCH];
