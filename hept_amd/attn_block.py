@@ -60,6 +60,17 @@ class Attn(nn.Module):
             ff_output = self.ff(self.norm2(x))
             return x + self.dropout(ff_output)
         a = self.attn
+        if torch.compiler.is_compiling():
+            # one opaque graph node (hept_amd/library.py) instead of a ctypes call Dynamo cannot trace
+            from .library import attn_block_op
+
+            y = attn_block_op(x.float(), kwargs["coords"].float(), kwargs["combined_shifts"], self.norm1.weight,
+                              self.norm1.bias, self.w_q.weight, self.w_k.weight, self.w_v.weight, self.w_rpe.weight,
+                              a.e2lsh.alpha, a.out_linear.weight, a.out_linear.bias, self.norm2.weight,
+                              self.norm2.bias, self.ff[0].weight, self.ff[0].bias, self.ff[2].weight,
+                              self.ff[2].bias, self.num_heads, a.block_size, a.num_w_per_dist, self.norm1.eps,
+                              self.norm2.eps, a.precision)
+            return y.to(x.dtype)
         n = x.shape[0]
         c = kwargs["coords"].shape[1]
         need = ops.workspace_bytes(n, self.num_heads, self.dim_per_head, c, a.n_hashes, a.block_size, a.precision)

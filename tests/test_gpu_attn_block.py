@@ -116,3 +116,21 @@ def test_attn_block_module_vs_reference(name, precision, gpu_device):
         y2 = blk(inp["x"].to(dev), kwargs).detach().cpu()
         ok = ((y2 - y).abs() <= ATOL[name] + 1e-4 * y.abs()).all(-1).float().mean()
         assert float(ok) >= 0.97
+
+
+def test_attn_block_under_torch_compile_is_one_graph(gpu_device):
+    """The fused block is registered with torch.library too: fullgraph capture, same result as eager."""
+    import torch._dynamo
+
+    inp, _ = cases.load_case_attn("a2_attn_rand")
+    blk = Attn(inp["coords"].shape[1], h_dim=24, num_heads=8, block_size=inp["block_size"], n_hashes=3,
+               num_w_per_dist=10)
+    blk.load_state_dict(inp["params"], strict=True)
+    blk = blk.to(gpu_device).eval()
+    kwargs = {"coords": inp["coords"].to(gpu_device), "combined_shifts": inp["combined_shifts"].to(gpu_device)}
+    x = inp["x"].to(gpu_device)
+    with torch.no_grad():
+        eager = blk(x, kwargs)
+        torch._dynamo.reset()
+        out = torch.compile(blk, backend="aot_eager", fullgraph=True)(x, kwargs)
+    assert torch.equal(out, eager)
