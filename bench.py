@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 WORKLOAD = "tracking-60k"
-EVENT_STRIDE = 8
+EVENT_STRIDE = 16
 TABLES_PER_GPU = 3
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # dense f32-input MFMA
@@ -137,7 +137,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # HIP events around block_attn on the launch stream, inside the timed region; every 8th step only: an
+    # HIP events around block_attn on the launch stream, inside the timed region; every 16th step only: an
     # event pair costs ~12 us of stream time per step, sampling keeps `value` within 0.5 % of un-instrumented
     ops.profile_enable(1, args.steps, stride=EVENT_STRIDE)
     fence()

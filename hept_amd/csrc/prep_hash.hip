@@ -69,7 +69,7 @@ __global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict
 struct FusedIn {
     const float* ln_w;   // norm1.weight (D)
     const float* ln_b;   // norm1.bias (D)
-    const float* w_s;    // LDS: this role's projection weight, [h][d][j] at head pitch FUSED_WPITCH
+    const float* w_s;    // LDS: this role's projection weight, [h][j][d] (transposed) at head pitch FUSED_WPITCH
     float eps;
 };
 constexpr int FUSED_WPITCH = 24 * 24 + 4;  // head pitch = 4 (mod 32) dwords: the 8 heads' 16-B reads hit 8 distinct bank groups
@@ -130,19 +130,18 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
             const float rstd = 1.0f / sqrtf(var * (1.0f / D) + fin.eps);
 #pragma unroll
             for (int j = 0; j < D; ++j) xv[j] = (xv[j] - mean) * rstd * fin.ln_w[j] + fin.ln_b[j];
+            // out[d] = sum_j W[d][j] xn[j] with the slab stored [j][d]: one 16-B read brings W[d..d+3][j], and the four
+            // outputs advance with two packed fp32 FMAs (v_pk_fma_f32) instead of four scalar ones
             const float* wrow = fin.w_s + h * FUSED_WPITCH;
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                float acc = 0.f;
+            for (int g = 0; g < D4; ++g) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < D4; ++j) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + d * D + 4 * j);
-                    acc = fmaf(wv[0], xv[4 * j], acc);
-                    acc = fmaf(wv[1], xv[4 * j + 1], acc);
-                    acc = fmaf(wv[2], xv[4 * j + 2], acc);
-                    acc = fmaf(wv[3], xv[4 * j + 3], acc);
+                for (int j = 0; j < D; ++j) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + j * D + 4 * g);
+                    acc = __builtin_elementwise_fma(wv, f32x4{xv[j], xv[j], xv[j], xv[j]}, acc);
                 }
-                xr[d / 4][d % 4] = acc;
+                xr[g] = acc;
                 // keep the 144 weight reads from being hoisted in front of the fma chains (they would need ~600 VGPRs)
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -340,7 +339,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
     __shared__ __attribute__((aligned(16))) float w_s[H * FUSED_WPITCH];
     const int role = blockIdx.y;
     const float* wsrc = role == 0 ? wq : (role == 1 ? wk : wv);
-    for (int i = threadIdx.x; i < H * D * D; i += PREP_THREADS) w_s[(i / (D * D)) * FUSED_WPITCH + i % (D * D)] = wsrc[i];
+    for (int i = threadIdx.x; i < H * D * D; i += PREP_THREADS) {  // W row (h, d), column j  ->  slab h, [j][d]
+        const int hd = i / D, j = i % D;
+        w_s[(hd / D) * FUSED_WPITCH + j * D + hd % D] = wsrc[i];
+    }
     if (role != 2) {
         for (int i = threadIdx.x; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
             const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
