@@ -61,8 +61,8 @@ __device__ __forceinline__ unsigned int ordered_bits(float key) {
 __device__ __forceinline__ float from_ordered(unsigned int u) {
     return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
-// monotone 16-bit bucket id; scale = 65536 / (kmax - kmin), 0 when all keys are equal
-__device__ __forceinline__ unsigned int id16_of(unsigned int u, float kmin, float scale) {
+// monotone HEPT_ID_BITS-bit bucket id; scale = 2^bits / (kmax - kmin), 0 when all keys are equal
+__device__ __forceinline__ unsigned int bucket_id(unsigned int u, float kmin, float scale) {
     // the float clamp keeps +inf keys (the src variant's padding rows) and inf * 0 = NaN in the last bucket
     const float x = fminf((from_ordered(u) - kmin) * scale, (float)(ID_BUCKETS - 1));
     const int b = (int)x;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
     hi = fmaxf(fmaxf(red_s[1][0], red_s[1][1]), fmaxf(red_s[1][2], red_s[1][3]));
     cmax = fmaxf(fmaxf(red_s[2][0], red_s[2][1]), fmaxf(red_s[2][2], red_s[2][3]));
     const float span = hi - lo;
-    // keys lie in [lo, hi + cmax*span] (codes >= 0); any key outside is clamped by id16_of (still monotone)
+    // keys lie in [lo, hi + cmax*span] (codes >= 0); any key outside is clamped by bucket_id (still monotone)
     const float width = (hi + cmax * span) - lo;
     float scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
     if (!(scale < 3.0e38f)) scale = 0.f;  // inf/nan guard for denormal widths: one bucket, still exact
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
                 asm volatile("" : "+v"(t3));
                 const unsigned int u = ordered_bits(proj[n] + t3);
                 kout[n] = u;
-                atomicAdd(&h_s[id16_of(u, lo, scale) >> TOP_SHIFT], 1u);
+                atomicAdd(&h_s[bucket_id(u, lo, scale) >> TOP_SHIFT], 1u);
             }
         }
         __syncthreads();
@@ -178,13 +178,13 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
             u[3] = make_key(pj[3], c23[1]);
             *reinterpret_cast<u32x4*>(kout + n) = u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&h_s[id16_of(u[e], lo, scale) >> TOP_SHIFT], 1u);
+            for (int e = 0; e < 4; ++e) atomicAdd(&h_s[bucket_id(u[e], lo, scale) >> TOP_SHIFT], 1u);
         } else {
             for (int e = 0; e < 4; ++e)
                 if (n + e < N) {
                     const unsigned int u = make_key(proj[n + e], code[n + e]);
                     kout[n + e] = u;
-                    atomicAdd(&h_s[id16_of(u, lo, scale) >> TOP_SHIFT], 1u);
+                    atomicAdd(&h_s[bucket_id(u, lo, scale) >> TOP_SHIFT], 1u);
                 }
         }
     }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int n = base + r * SORT_THREADS + tid;
-        const unsigned int dg = id16_of(key[r], rg.kmin, rg.scale) >> TOP_SHIFT;
+        const unsigned int dg = bucket_id(key[r], rg.kmin, rg.scale) >> TOP_SHIFT;
         dig[r] = (unsigned char)dg;
         rank[r] = n < N ? (unsigned short)atomicAdd(&cnt_s[dg], 1u) : (unsigned short)0;
     }
@@ -291,16 +291,16 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
         const int lp = r * SORT_THREADS + tid;
         if (lp < n_valid) {
             const unsigned long long p = stage_s[lp];
-            const unsigned int dg = id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale) >> TOP_SHIFT;
+            const unsigned int dg = bucket_id((unsigned int)(p >> 32), rg.kmin, rg.scale) >> TOP_SHIFT;
             dst_pairs[seg_off + goff_s[dg] + (lp - start_s[dg])] = p;
         }
     }
 }
 
-// K4: every (segment, high-byte bucket) is finished by one workgroup.  A bucket holds the pairs whose id shares the
-// high byte, contiguous after K3; id is monotone in the key, so the bucket's final positions are exactly its own
-// range [start, end) and only the order inside it is left.  Histogram of the LOW id byte -> exclusive prefix
-// -> scatter (any order): the pairs are now grouped by their full 16-bit id, group g = [first[g], first[g+1]), and
+// K4: every (segment, top-bits bucket) is finished by one workgroup.  A bucket holds the pairs whose id shares the
+// top bits, contiguous after K3; id is monotone in the key, so the bucket's final positions are exactly its own
+// range [start, end) and only the order inside it is left.  Histogram of the LOW id bits -> exclusive prefix
+// -> scatter (any order): the pairs are now grouped by their full id, group g = [first[g], first[g+1]), and
 //        final position(i) = start + first[g] + #{ j in group g : pair_j < pair_i }        (pairs are unique u64)
 // Groups are 1-3 pairs at tracking-60k.  A bucket larger than the LDS tile takes the same three steps through a
 // global scratch copy, grouped by a monotone id of the pair over the bucket's own pair range (streaming; slower,
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         pscale = (double)LOBINS / ((double)(hi - lo) + 1.0);
     }
     auto lo_of = [&](unsigned long long p) -> unsigned int {
-        if (in_lds) return id16_of((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
+        if (in_lds) return bucket_id((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
         const unsigned int b = (unsigned int)((double)(p - pmin) * pscale);  // monotone in p
         return b < (unsigned int)LOBINS ? b : (unsigned int)(LOBINS - 1);
     };
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(SORT_THREADS) void raw_keygen_hist_kernel(const flo
         if (n < L) {
             const unsigned int u = ordered_bits(keys[(size_t)seg * L + n]);
             keys0[(size_t)seg * L + n] = u;
-            atomicAdd(&h_s[id16_of(u, rg.kmin, rg.scale) >> TOP_SHIFT], 1u);
+            atomicAdd(&h_s[bucket_id(u, rg.kmin, rg.scale) >> TOP_SHIFT], 1u);
         }
     }
     __syncthreads();
