@@ -24,7 +24,6 @@ __device__ __forceinline__ unsigned int hept_pack_bf16(float lo, float hi) {
     const hept_f32x2 v = {lo, hi};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hept_bf16x2));
 }
-__device__ __forceinline__ float hept_bf16_round(float x) { return (float)(__bf16)x; }
 // the two bf16 halves of a packed dword, widened back to fp32
 __device__ __forceinline__ float hept_bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hept_bf16_hi(unsigned int w) { return __uint_as_float(w & 0xFFFF0000u); }

@@ -15,7 +15,9 @@ from ._lib import PREC_BF16, PREC_F32, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
-    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part", "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args", "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward",
+    "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part",
+    "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args",
+    "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward",
 ]
 
 
