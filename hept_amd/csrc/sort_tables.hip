@@ -555,7 +555,7 @@ SortBuffers carve_sort(void* sort_ws, int segs, int N) {
     return b;
 }
 constexpr int BKT_CAP_SMALL = HEPT_BKT_CAP;  // LDS tile: the average bucket is N/NTOP
-constexpr int BKT_CAP_LARGE = 3 * HEPT_BKT_CAP;  // for longer segments
+constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segments (average bucket up to ~3000 pairs)
 void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const dim3 grid(n_chunks, segs), block(SORT_THREADS);

@@ -66,7 +66,7 @@ def test_segmented_argsort_skewed_and_long_segments(gpu_device):
     keys[4] = torch.linspace(1.0, 1.0 + 1e-3, 20000).flip(0)  # descending, all keys nearly equal
     pos = ops.segmented_argsort(keys.to(gpu_device)).long().cpu()
     assert torch.equal(pos, torch.sort(keys, dim=-1, stable=True).indices)
-    long_keys = torch.randn(2, 300000, generator=g)
+    long_keys = torch.randn(2, 700000, generator=g)          # average bucket 2734 pairs: the large-tile kernel
     long_keys[1] = (long_keys[1] * 4).round() / 4           # quantised: ~100 distinct values
     pos = ops.segmented_argsort(long_keys.to(gpu_device)).long().cpu()
     assert torch.equal(pos, torch.sort(long_keys, dim=-1, stable=True).indices)
