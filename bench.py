@@ -135,6 +135,15 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    if world > 1:
+        # first sharded step: if this RCCL build rejects the all-to-all of packed rows, fall back to the reduce-scatter
+        # exchange (f32 rows) rather than lose the measurement; the mode used is reported in config.parallelism
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[rank {rank}] all_to_all exchange failed ({exc!r}); using reduce_scatter", file=sys.stderr)
+            attn.sharding.mode = "reduce_scatter"
     for _ in range(args.warmup):
         step()
     # HIP events around block_attn on the launch stream, inside the timed region; every 16th step only: an
@@ -189,7 +198,8 @@ def main():
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"{WORKLOAD}: N_raw={n_raw} padded N={n}, block_size={B}, n_hashes={tables_per_gpu}/GPU "
                                    f"({n_tables} total), H={H}, D={D}, C={C}, tiles {args.precision}",
-                       "parallelism": f"tables sharded {tables_per_gpu}/GPU over {world} GPU(s)",
+                       "parallelism": f"tables sharded {tables_per_gpu}/GPU over {world} GPU(s)" +
+                                      (f", exchange {attn.sharding.mode}" if world > 1 else ""),
                        "hbm_algorithmic_GBps_block_attn": algorithmic_bytes(n, H, D, C, tables_per_gpu, tile_bytes) / (attn_ms * 1e-3) / 1e9},
             "roofline": roof,
         }
