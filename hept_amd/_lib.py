@@ -46,6 +46,7 @@ SIGNATURES = {
     "hept_prep_hash_fused": (c_int, [_P] * 3 + [c_float] + [_P] * 7 + [c_int] * 9 + [_P] * 6),
     "hept_combine_ffn": (c_int, [_P] + [c_int] * 7 + [_P] * 5 + [c_float] + [_P] * 6),
     "hept_attn_block_forward": (c_int, [_P] * 4 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
+    "hept_combine_bwd": (c_int, [_P] * 3 + [c_int] * 3 + [_P] * 4),
     "hept_forward_src": (c_int, [_P] * 7 + [c_int] + [_P] * 4 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_partial_src": (c_int, [_P] * 7 + [c_int] + [_P] * 2 + [c_int] * 11 + [_P, c_size_t, _P, _P]),
     "hept_block_attn_bwd": (c_int, [_P] * 5 + [c_int] * 5 + [_P] * 3),

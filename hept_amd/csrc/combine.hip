@@ -339,6 +339,96 @@ __global__ __launch_bounds__(256) void reduce_tables_kernel(const float* __restr
     }
 }
 
+// ---- backward of combine_out (training path): out = bias + W . (numer / den) -----------------------
+// Two kernels.  Rows: lane (point, head) recomputes per_head = numer / den, pulls g_out back through its head's
+// D x D weight slab (LDS, packed fp32 FMAs) and writes the gradient of the partial row [d numer | d den | 0].
+// Weight: one lane per output column (h, j) walks a slice of points and keeps the D partial sums of
+// dW[:, h*D + j] in registers; slices are merged with atomics (dW, db are zeroed by the entry point).
+constexpr int CB_D = 24, CB_PITCH = CB_D * CB_D + 4;  // head pitch = 4 (mod 32): conflict-free 16-B reads for 8 heads
+
+__global__ __launch_bounds__(256) void combine_bwd_rows_kernel(const float* __restrict__ acc,
+                                                               const float* __restrict__ g_out,
+                                                               const float* __restrict__ W, int N, int H,
+                                                               float* __restrict__ gacc) {
+    __shared__ __attribute__((aligned(16))) float wt_s[8 * CB_PITCH];  // [h][c][j]
+    const int tid = threadIdx.x, HD = H * CB_D;
+    for (int i = tid; i < CB_D * HD; i += 256) {  // W (D, H*D) row-major: coalesced read
+        const int c = i / HD, h = (i % HD) / CB_D, j = i % CB_D;
+        wt_s[h * CB_PITCH + c * CB_D + j] = W[i];
+    }
+    __syncthreads();
+    const size_t n_rows = (size_t)N * H;
+    for (size_t row = (size_t)blockIdx.x * 256 + tid; row < n_rows; row += (size_t)gridDim.x * 256) {
+        const int h = (int)(row % H);
+        const size_t n = row / H;
+        float g[CB_D], a[28];
+        const f32x4* gs = reinterpret_cast<const f32x4*>(g_out + n * CB_D);
+        const f32x4* as = reinterpret_cast<const f32x4*>(acc + row * 32);
+#pragma unroll
+        for (int i = 0; i < CB_D / 4; ++i) {
+            const f32x4 v = gs[i];
+            g[4 * i] = v[0]; g[4 * i + 1] = v[1]; g[4 * i + 2] = v[2]; g[4 * i + 3] = v[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const f32x4 v = as[i];
+            a[4 * i] = v[0]; a[4 * i + 1] = v[1]; a[4 * i + 2] = v[2]; a[4 * i + 3] = v[3];
+        }
+        const float inv = 1.0f / a[CB_D];
+        const float* wh = wt_s + h * CB_PITCH;
+        f32x4 dph[CB_D / 4];
+#pragma unroll
+        for (int jg = 0; jg < CB_D / 4; ++jg) {
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < CB_D; ++c) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wh + c * CB_D + 4 * jg);
+                s4 = __builtin_elementwise_fma(w4, f32x4{g[c], g[c], g[c], g[c]}, s4);
+            }
+            dph[jg] = s4;
+            __builtin_amdgcn_sched_barrier(0);  // keep the 144 weight reads from being hoisted (register pressure)
+        }
+        // d numer[j] = dph[j] / den;   d den = - sum_j dph[j] * numer[j] / den^2
+        float dot = 0.f;
+        f32x4* out = reinterpret_cast<f32x4*>(gacc + row * 32);
+#pragma unroll
+        for (int jg = 0; jg < CB_D / 4; ++jg) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dot = fmaf(dph[jg][u], a[4 * jg + u], dot);
+            out[jg] = f32x4{dph[jg][0] * inv, dph[jg][1] * inv, dph[jg][2] * inv, dph[jg][3] * inv};
+        }
+        out[6] = f32x4{-dot * inv * inv, 0.f, 0.f, 0.f};
+        out[7] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+constexpr int CBW_POINTS = 128;  // points per workgroup of the weight-gradient kernel
+__global__ __launch_bounds__(192) void combine_bwd_weight_kernel(const float* __restrict__ acc,
+                                                                 const float* __restrict__ g_out, int N, int H,
+                                                                 float* __restrict__ d_weight,
+                                                                 float* __restrict__ d_bias) {
+    const int col = threadIdx.x;            // h * D + j
+    const int HD = H * CB_D;
+    if (col >= HD) return;
+    const int h = col / CB_D, j = col % CB_D;
+    const int n_begin = blockIdx.x * CBW_POINTS, n_end = min(N, n_begin + CBW_POINTS);
+    float s[CB_D];
+#pragma unroll
+    for (int c = 0; c < CB_D; ++c) s[c] = 0.f;
+    float sb = 0.f;  // lanes < D also sum g_out[:, lane] for the bias gradient
+    for (int n = n_begin; n < n_end; ++n) {
+        const float* arow = acc + ((size_t)n * H + h) * 32;
+        const float ph = arow[j] / arow[CB_D];
+        const float* gr = g_out + (size_t)n * CB_D;  // uniform across the workgroup: scalar loads
+#pragma unroll
+        for (int c = 0; c < CB_D; ++c) s[c] = fmaf(gr[c], ph, s[c]);
+        if (col < CB_D) sb += gr[col];
+    }
+#pragma unroll
+    for (int c = 0; c < CB_D; ++c) atomicAdd(d_weight + (size_t)c * HD + col, s[c]);
+    if (col < CB_D && d_bias) atomicAdd(d_bias + col, sb);
+}
+
 }  // namespace
 
 extern "C" int hept_reduce_tables(const float* part, int part_precision, int Tl, int N, int H, int D, float* acc,
@@ -422,4 +512,20 @@ extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, i
     if (part_precision == HEPT_PREC_F32)
         return combine_launch<false, true, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, y, ffn);
     return HEPT_ERR_SHAPE;
+}
+
+extern "C" int hept_combine_bwd(const float* acc, const float* g_out, const float* out_weight, int N, int H, int D,
+                                float* gacc, float* d_weight, float* d_bias, void* stream) {
+    if (!acc || !g_out || !out_weight || !gacc || !d_weight) return HEPT_ERR_ARG;
+    if (N < 1 || H < 1 || H > 8 || D != CB_D) return HEPT_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(d_weight, 0, sizeof(float) * D * H * D, st) != hipSuccess) return HEPT_ERR_LAUNCH;
+    if (d_bias && hipMemsetAsync(d_bias, 0, sizeof(float) * D, st) != hipSuccess) return HEPT_ERR_LAUNCH;
+    const size_t n_rows = (size_t)N * H;
+    const size_t blocks = (n_rows + 255) / 256;
+    hipLaunchKernelGGL(combine_bwd_rows_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, acc,
+                       g_out, out_weight, N, H, gacc);
+    hipLaunchKernelGGL(combine_bwd_weight_kernel, dim3((N + CBW_POINTS - 1) / CBW_POINTS), dim3(192), 0, st, acc, g_out, N,
+                       H, d_weight, d_bias);
+    return hept_launch_status();
 }

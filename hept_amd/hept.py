@@ -165,6 +165,11 @@ class HEPTAttention(nn.Module):
         acc = HeptPartialSums.apply(query.reshape(n, h * d).float(), key.reshape(n, h * d).float(),
                                     value.reshape(n, h * d).float(), coords, sqrt_w, self.e2lsh.alpha.detach(),
                                     kwargs.get("combined_shifts"), self.block_size, geo)
-        per_head = acc[..., :d] / acc[..., d:d + 1]                      # example/hept.py:79
-        out = self.out_linear(per_head.reshape(n, h * d))                # example/hept.py:80
+        if d == 24:
+            from .autograd import HeptCombine
+
+            out = HeptCombine.apply(acc, self.out_linear.weight, self.out_linear.bias)   # example/hept.py:79-80
+        else:
+            per_head = acc[..., :d] / acc[..., d:d + 1]                  # example/hept.py:79
+            out = self.out_linear(per_head.reshape(n, h * d))            # example/hept.py:80
         return out.to(query.dtype)

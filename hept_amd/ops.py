@@ -17,7 +17,7 @@ __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
     "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part",
     "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args",
-    "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward",
+    "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward", "combine_bwd",
 ]
 
 
@@ -226,6 +226,23 @@ def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int
     _lib.check(lib.hept_bwd_reduce(dq_part.data_ptr(), dkv_part.data_ptr(), tl, n, h, head_dim, coords_dim,
                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dcs.data_ptr(), st), "hept_bwd_reduce")
     return dq, dk, dv, dcs
+
+
+def combine_bwd(acc: torch.Tensor, g_out: torch.Tensor, out_weight: torch.Tensor, need_bias: bool = True):
+    """Backward of ``combine_out`` on table-summed f32 rows: returns (gacc (N,H,32), d_weight (D,H*D), d_bias (D))."""
+    lib = _lib.load()
+    acc = _f32c(acc, "acc")
+    g_out = _f32c(g_out, "grad of the output")
+    w = _f32c(out_weight, "out_linear.weight")
+    n, h, _ = acc.shape
+    d = g_out.shape[1]
+    gacc = torch.empty_like(acc)
+    dw = torch.empty_like(w)
+    db = torch.empty(d, device=acc.device, dtype=torch.float32) if need_bias else None
+    _lib.check(lib.hept_combine_bwd(acc.data_ptr(), g_out.data_ptr(), w.data_ptr(), n, h, d, gacc.data_ptr(),
+                                    dw.data_ptr(), db.data_ptr() if db is not None else None, _stream(acc)),
+               "hept_combine_bwd")
+    return gacc, dw, db
 
 
 def geo_args(region_indices, regions_h, n_tables: int, n_heads: int, n: int):

@@ -206,6 +206,11 @@ int hept_block_attn_bwd(const float* qhat, const float* kvhat, const int32_t* qp
                         float* dkv_part, void* stream);
 int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
                     float* dq, float* dk, float* dv, float* dcs, void* stream);
+/* backward of hept_combine_out on table-summed f32 rows acc (N, H, 32) (example/hept.py:79-80 under autograd):
+ * given g_out (N, D) writes gacc (N, H, 32) = gradient of acc, d_weight (D, H*D) and d_bias (D, may be NULL).
+ * D == 24, H <= 8. */
+int hept_combine_bwd(const float* acc, const float* g_out, const float* out_weight, int N, int H, int D,
+                     float* gacc, float* d_weight, float* d_bias, void* stream);
 
 /* SURVEY.md §8 f-1 — replaces prepare_input (example/transformer.py:35-63: per-cloud argsorts of eta / phi,
  * quantile_partition example/hept_utils.py:6-14, bit_shift x2 :10-13, pad_and_unpad :16-32 and the gathers by

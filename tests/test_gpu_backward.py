@@ -100,3 +100,28 @@ def test_module_trains_like_the_reference(name, gpu_device):
     # (sqrt_w comes from torch in the training path and from rpe_scale_kernel in the fused one: last-bit
     #  differences, amplified by the logit cancellation of the trained-weight case)
     torch.testing.assert_close(out2, out.detach(), rtol=1e-3, atol=1e-3 if name == "g3_ckpt6k" else 1e-5)
+
+
+def test_combine_backward_kernel_vs_autograd(gpu_device):
+    """hept_combine_bwd (divide + out_linear backward in HIP) against torch autograd of the same expression."""
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    n, h, d = 1000, 8, 24
+    acc = torch.zeros(n, h, 32)
+    acc[..., :d] = torch.randn(n, h, d, generator=g)
+    acc[..., d] = torch.rand(n, h, generator=g) * 3 + 0.05
+    w = torch.randn(d, h * d, generator=g) * 0.1
+    b = torch.randn(d, generator=g)
+    g_out = torch.randn(n, d, generator=g)
+    acc_r, w_r, b_r = (t.clone().to(dev).requires_grad_(True) for t in (acc, w, b))
+    ref = torch.nn.functional.linear((acc_r[..., :d] / acc_r[..., d:d + 1]).reshape(n, h * d), w_r, b_r)
+    ref.backward(g_out.to(dev))
+    from hept_amd.autograd import HeptCombine
+    acc_t, w_t, b_t = (t.clone().to(dev).requires_grad_(True) for t in (acc, w, b))
+    out = HeptCombine.apply(acc_t, w_t, b_t)
+    torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-5)
+    out.backward(g_out.to(dev))
+    torch.testing.assert_close(acc_t.grad[..., :d + 1], acc_r.grad[..., :d + 1], rtol=1e-4, atol=1e-5)
+    assert float(acc_t.grad[..., d + 1:].abs().max()) == 0.0
+    assert _close(w_t.grad.cpu(), w_r.grad.cpu(), rel=1e-4)   # summed with atomics: order-dependent round-off
+    assert _close(b_t.grad.cpu(), b_r.grad.cpu(), rel=1e-5)
