@@ -91,3 +91,30 @@ def test_module_under_torch_compile_is_one_graph(variant, gpu_device):
     compiled = torch.compile(m, backend="aot_eager", fullgraph=True)
     out = run(compiled)
     assert torch.equal(out, eager)
+
+
+def test_forward_is_hip_graph_capturable(gpu_device):
+    """The C call launches on the caller's stream without allocating or synchronising, so the whole forward can be
+    captured into a HIP graph (torch.cuda.CUDAGraph) and replayed: same result, ~7 launches collapse into one."""
+    inp, _ = cases.load_case("g1_rand512")
+    m, w_rpe = _module(inp, gpu_device, precision="bf16")
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+    with torch.no_grad():
+        eager = m(g["q"], g["k"], g["v"], **kw)          # warm-up: library, workspace, kernel attributes
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(g["q"], g["k"], g["v"], **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = m(g["q"], g["k"], g["v"], **kw)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        g["v"].mul_(2.0)                                   # replay reads the live input buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out, m(g["q"], g["k"], g["v"], **kw), rtol=0, atol=0)
