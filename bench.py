@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0; see DESIGN.md §6 for every field.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -77,6 +78,26 @@ def cpu_baseline(inp, block_size, min_seconds=10.0):
     }
 
 
+@contextlib.contextmanager
+def c_stdout_to_stderr():
+    """RCCL prints a version banner with C stdio on stdout when a communicator is created; the contract is ONE JSON
+    line on stdout.  Route file descriptor 1 to stderr (flushing C stdio on both sides) while RCCL initialises."""
+    import ctypes
+
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +107,8 @@ def main():
     ap.add_argument("--tables-per-gpu", type=int, default=TABLES_PER_GPU,
                     help="hash tables per GPU (default 3 = BASELINE config 3 at N=1; 1 = config 4: n_hashes = #GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (process group, exchange step, barriers) even with one rank: a self-check")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage HIP-event breakdown to stderr")
     args = ap.parse_args()
 
@@ -97,11 +120,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        with c_stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            dist.barrier()  # creates the communicator (and prints RCCL's banner) now
+            torch.cuda.synchronize()
         group = dist.group.WORLD
 
     from hept_amd import HEPTAttention, ops
@@ -120,6 +148,8 @@ def main():
     attn.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
                           "e2lsh.alpha": inp["alpha"]}, strict=True)
     attn = attn.to(dev).eval()
+    if args.force_dist and world == 1:
+        attn.sharding.always_exchange = True
     w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(dev)
     with torch.no_grad():
         w_rpe.weight.copy_(g["w_rpe_weight"])
@@ -131,11 +161,11 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    if world > 1:
+    if multi:
         # first sharded step: if this RCCL build rejects the all-to-all of packed rows, fall back to the reduce-scatter
         # exchange (f32 rows) rather than lose the measurement; the mode used is reported in config.parallelism
         try:
@@ -157,7 +187,7 @@ def main():
     elapsed = time.perf_counter() - t0
     stage_ms, n_rec = ops.profile_read()
     ops.profile_enable(0)
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
@@ -199,15 +229,16 @@ def main():
             "config": {"workload": f"{WORKLOAD}: N_raw={n_raw} padded N={n}, block_size={B}, n_hashes={tables_per_gpu}/GPU "
                                    f"({n_tables} total), H={H}, D={D}, C={C}, tiles {args.precision}",
                        "parallelism": f"tables sharded {tables_per_gpu}/GPU over {world} GPU(s)" +
-                                      (f", exchange {attn.sharding.mode}" if world > 1 else ""),
+                                      (f", exchange {attn.sharding.mode}" if multi else ""),
                        "hbm_algorithmic_GBps_block_attn": algorithmic_bytes(n, H, D, C, tables_per_gpu, tile_bytes) / (attn_ms * 1e-3) / 1e9},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(inp, B)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    if multi:
+        with c_stdout_to_stderr():
+            torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
