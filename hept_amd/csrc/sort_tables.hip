@@ -528,6 +528,176 @@ __global__ __launch_bounds__(SORT_THREADS) void raw_keygen_hist_kernel(const flo
     hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
 }
 
+// ---- short segments (N <= SMALL_CAP: the 4k / 6k clouds): the whole sort of a segment in ONE workgroup ----------------
+// Three dependent kernels of ~5-10 us each are a fixed ~23 us at these sizes; here a 1024-thread workgroup keeps the
+// segment's (key, index) pairs in registers, groups them by a 12-bit monotone id in LDS (histogram / prefix / scatter on
+// one bins array, as in K4) and ranks every pair inside its id group.  Same exact result.
+constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_WAVES = SMALL_THREADS / HEPT_WAVE;
+constexpr int SMALL_CAP = 6144;
+constexpr int SMALL_ITEMS = SMALL_CAP / SMALL_THREADS;
+constexpr int SMALL_BINS = 4096;
+constexpr size_t SMALL_LDS = (size_t)SMALL_CAP * 8 + (SMALL_BINS + 1) * 4;
+
+// MODE 0: key = proj + float(code) * span;  MODE 1: src variant (get_geo_shift);  MODE 2: raw keys (S segments of L)
+template <int MODE>
+__global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
+    const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
+    const float* __restrict__ eta_idx, const float* __restrict__ phi_idx, const float* __restrict__ cfac,
+    const float* __restrict__ minmax, int N, int H, int t0, int Tl, int* __restrict__ pos_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long small_tile_s[];  // [SMALL_CAP] pairs, then bins
+    __shared__ float red_s[3][SMALL_WAVES];
+    __shared__ unsigned int wsum_s[SMALL_WAVES];
+    unsigned int* cur_s = reinterpret_cast<unsigned int*>(small_tile_s + SMALL_CAP);  // [0] stays 0; bin d at [d + 1]
+    unsigned int* bin_s = cur_s + 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, seg = blockIdx.x;
+    for (int i = tid; i < SMALL_BINS + 1; i += SMALL_THREADS) cur_s[i] = 0;
+
+    // ---- key range of the segment
+    float lo = INFINITY, hi = -INFINITY, cmax = 0.f;
+    const float* proj;
+    size_t row_off = 0;
+    if (MODE == 2) {
+        proj = qproj + (size_t)seg * N;  // raw keys
+        for (int i = tid; i < N; i += SMALL_THREADS) {
+            const float x = proj[i];
+            if (x < INFINITY && x > -INFINITY) { lo = fminf(lo, x); hi = fmaxf(hi, x); }
+        }
+    } else {
+        const int th = seg % (Tl * H), t = th / H, h = th % H;
+        proj = (seg >= Tl * H ? kproj : qproj) + (size_t)th * N;
+        row_off = ((size_t)(t0 + t) * H + h) * N;
+        for (int i = tid; i < HEPT_PREP_GRID; i += SMALL_THREADS) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(minmax + (((size_t)t * H + h) * HEPT_PREP_GRID + i) * 4);
+            lo = fminf(lo, m[0]); hi = fmaxf(hi, m[1]); cmax = fmaxf(cmax, m[2]);
+        }
+        if (MODE == 1) {  // src variant: bound of the shift in units of span (what src_bound_kernel computes)
+            const float cf = cfac[(size_t)(t0 + t) * H + h];
+            float m = 0.f;
+            for (int i = tid; i < N; i += SMALL_THREADS) {
+                const float e = eta_idx[row_off + i], p = phi_idx[row_off + i];
+                if (e < INFINITY && p < INFINITY) m = fmaxf(m, fmaf(p, cf, e));
+            }
+            cmax = m * 1.0001f + 1.f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+    }
+    if (lane == 0) { red_s[0][w] = lo; red_s[1][w] = hi; red_s[2][w] = cmax; }
+    __syncthreads();
+    lo = red_s[0][0]; hi = red_s[1][0]; cmax = red_s[2][0];
+#pragma unroll
+    for (int ww = 1; ww < SMALL_WAVES; ++ww) {
+        lo = fminf(lo, red_s[0][ww]); hi = fmaxf(hi, red_s[1][ww]); cmax = fmaxf(cmax, red_s[2][ww]);
+    }
+    if (lo > hi) { lo = 0.f; hi = 0.f; }  // no finite key at all
+    const float span = hi - lo;
+    const float width = MODE == 2 ? span : (hi + cmax * span) - lo;
+    float scale = width > 0.f ? (float)SMALL_BINS / width : 0.f;
+    if (!(scale < 3.0e38f)) scale = 0.f;
+    auto bin_of = [&](unsigned int u) -> unsigned int {
+        const float x = fminf((from_ordered(u) - lo) * scale, (float)(SMALL_BINS - 1));
+        const int b = (int)x;
+        return (unsigned int)(b < 0 ? 0 : b);
+    };
+
+    // ---- keys -> pairs in registers, histogram of the id
+    unsigned long long mine[SMALL_ITEMS];
+    float cf = 0.f;
+    if (MODE == 1) { const int th = seg % (Tl * H); cf = cfac[(size_t)(t0 + th / H) * H + th % H]; }
+#pragma unroll
+    for (int u = 0; u < SMALL_ITEMS; ++u) {
+        const int n = u * SMALL_THREADS + tid;
+        mine[u] = ~0ull;
+        if (n < N) {
+            float key;
+            if (MODE == 0) {
+                float off = (float)codes[row_off + n] * span;   // two separately rounded ops, as in K1
+                asm volatile("" : "+v"(off));
+                key = proj[n] + off;
+            } else if (MODE == 1) {
+                float t1 = eta_idx[row_off + n] * span;
+                asm volatile("" : "+v"(t1));
+                float t2 = phi_idx[row_off + n] * span;
+                asm volatile("" : "+v"(t2));
+                t2 = t2 * cf;
+                asm volatile("" : "+v"(t2));
+                float t3 = t2 + t1;
+                asm volatile("" : "+v"(t3));
+                key = proj[n] + t3;
+            } else {
+                key = proj[n];
+            }
+            const unsigned int ub = ordered_bits(key);
+            mine[u] = ((unsigned long long)ub << 32) | (unsigned int)n;
+            atomicAdd(&bin_s[bin_of(ub)], 1u);
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix over the bins: thread owns 4 consecutive bins
+        constexpr int BPT = SMALL_BINS / SMALL_THREADS;
+        unsigned int c[BPT], tot = 0;
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { c[u] = bin_s[BPT * tid + u]; tot += c[u]; }
+        unsigned int incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) wsum_s[w] = incl;
+        __syncthreads();
+        unsigned int run = incl - tot;
+        for (int ww = 0; ww < w; ++ww) run += wsum_s[ww];
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            bin_s[BPT * tid + u] = run;
+            run += c[u];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SMALL_ITEMS; ++u)
+        if (u * SMALL_THREADS + tid < N)
+            small_tile_s[atomicAdd(&bin_s[bin_of((unsigned int)(mine[u] >> 32))], 1u)] = mine[u];
+    __syncthreads();
+    int* out = pos_out + (size_t)seg * N;
+    for (int i = tid; i < N; i += SMALL_THREADS) {
+        const unsigned long long p = small_tile_s[i];
+        const unsigned int d = bin_of((unsigned int)(p >> 32));
+        const int g0 = (int)cur_s[d], g1 = (int)cur_s[d + 1];
+        int smaller = 0;
+        for (int j = g0; j < g1; j += 4) {
+            unsigned long long q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = small_tile_s[min(j + u, g1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) smaller += (j + u < g1) && (q[u] < p);
+        }
+        out[g0 + smaller] = (int)(unsigned int)p;
+    }
+}
+
+template <int MODE>
+int launch_small_sort(int segs, hipStream_t st, const float* qproj, const float* kproj, const int64_t* codes,
+                      const float* eta, const float* phi, const float* cfac, const float* minmax, int N, int H, int t0,
+                      int Tl, int* pos) {
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_sort_kernel<MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS) != hipSuccess)
+            return HEPT_ERR_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL(small_sort_kernel<MODE>, dim3(segs), dim3(SMALL_THREADS), SMALL_LDS, st, qproj, kproj, codes, eta,
+                       phi, cfac, minmax, N, H, t0, Tl, pos);
+    return hept_launch_status();
+}
+
 // the passes shared by hept_sort_tables and hept_segmented_argsort: keys0 + hist(top bits) + params -> pos
 struct SortBuffers {
     unsigned int* keys0;
@@ -589,6 +759,8 @@ extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const in
     if (kpos != qpos + (size_t)Tl * H * N) return HEPT_ERR_ARG;  // one (2,Tl,H,N) array: q then k
     hipStream_t st = (hipStream_t)stream;
     const int segs = 2 * Tl * H;
+    if (N <= SMALL_CAP)
+        return launch_small_sort<0>(segs, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, N, H, t0, Tl, qpos);
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(sort_ws, segs, N);
     hipLaunchKernelGGL(keygen_hist_kernel<false>, dim3(n_chunks, segs), dim3(SORT_THREADS), 0, st, qproj, kproj, codes,
@@ -606,6 +778,8 @@ extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, cons
     if (kpos != qpos + (size_t)Tl * H * N) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int segs = 2 * Tl * H;
+    if (N <= SMALL_CAP)
+        return launch_small_sort<1>(segs, st, qproj, kproj, nullptr, eta_idx, phi_idx, cfac, minmax, N, H, t0, Tl, qpos);
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(sort_ws, segs, N);
     hipLaunchKernelGGL(src_bound_kernel, dim3(Tl * H), dim3(SORT_THREADS), 0, st, eta_idx, phi_idx, cfac, N, H, t0,
@@ -622,6 +796,8 @@ extern "C" int hept_segmented_argsort(const float* keys, int S, int L, void* ws,
     if (!keys || !ws || !pos) return HEPT_ERR_ARG;
     if (S < 1 || L < 1) return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (L <= SMALL_CAP)
+        return launch_small_sort<2>(S, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, L, 1, 0, 1, pos);
     const int n_chunks = (L + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(ws, S, L);
     hipLaunchKernelGGL(raw_range_kernel, dim3(S), dim3(SORT_THREADS), 0, st, keys, L, b.params);
