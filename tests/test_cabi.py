@@ -114,3 +114,13 @@ def test_custom_ops_trace_with_fake_tensors():
         torch.ops.hept_amd.forward(torch.zeros(128, 192), torch.zeros(128, 192), torch.zeros(128, 192),
                                    torch.zeros(128, 6), torch.zeros(3, 8, 128, dtype=torch.int64), torch.zeros(192, 50),
                                    torch.zeros(8, 30, 3), torch.zeros(24, 192), None, 128, 10, "fp32")
+
+
+def test_header_is_plain_c():
+    """include/hept_hip.h is the drop-in boundary for any FFI: it has to compile as C99 and as C++ on its own."""
+    import os
+    import subprocess
+
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hept_hip.h")
+    subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], check=True)
+    subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-Wall", "-Werror", hdr], check=True)
