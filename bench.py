@@ -213,6 +213,16 @@ def main():
             roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF}
         roof["kernel"] = "block_attn_kernel"
         roof["kernel_ms"] = attn_ms
+        # what an event pair around NOTHING reads on this stream: the bracket's own cost is inside kernel_ms (the
+        # rocprofv3 kernel trace in profiles/ shows the kernel itself shorter by about this much)
+        gaps = []
+        for _ in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            torch.cuda.synchronize()
+            gaps.append(e0.elapsed_time(e1))
+        roof["event_pair_overhead_ms"] = sorted(gaps)[len(gaps) // 2]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
         if os.path.exists(tpath):
