@@ -119,11 +119,12 @@ def _worker(rank, world, port, mode, name, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,name", [("all_reduce", "g6_block100"), ("reduce_scatter", "g6_block100"),
-                                       ("all_reduce", "g1_rand512"), ("all_to_all", "g6_block100"),
-                                       ("all_to_all_packed", "g6_block100")])
-def test_two_rank_table_sharding_matches_single_process(mode, name):
-    world = 2
+@pytest.mark.parametrize("mode,name,world", [
+    ("all_reduce", "g6_block100", 2), ("reduce_scatter", "g6_block100", 2), ("all_reduce", "g1_rand512", 2),
+    ("all_to_all", "g6_block100", 2), ("all_to_all_packed", "g6_block100", 2),
+    # three ranks, one table each, and a point count (4096) that does not divide: the last slice is padded
+    ("all_to_all", "g4_pileup", 3), ("all_to_all_packed", "g4_pileup", 3), ("reduce_scatter", "g4_pileup", 3)])
+def test_table_sharding_matches_single_process(mode, name, world):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), mode, name, ret), nprocs=world, join=True)
