@@ -116,3 +116,15 @@ def test_prepare_then_attention_pipeline(gpu_device):
     err = (out.cpu() - ref).abs()
     assert ((err <= 1e-5 + 1e-4 * ref.abs()).all(-1)).float().mean() >= 0.995
     assert out[mask].shape[0] == n_raw
+
+
+def test_segmented_argsort_randomised(gpu_device):
+    """Random sizes / segment counts / key distributions (tools/sort_stress.py runs 400 of these): exact every time."""
+    import subprocess
+    import sys
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "sort_stress.py"), "60"], capture_output=True,
+                         text=True)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
