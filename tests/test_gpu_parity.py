@@ -286,3 +286,15 @@ def test_edge_cases(gpu_device):
     with pytest.raises(RuntimeError, match="HEPT_ERR_SHAPE"):
         ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
                     g["out_weight"], g["out_bias"], block_size=512, w_per_dist=10)
+
+
+def test_random_shapes_against_the_oracle(gpu_device):
+    """tools/op_stress.py: random block sizes (8..256, mostly not multiples of 32), 1..8 tables, every supported
+    (head_dim, coords_dim) pair, 1..3 clouds; fp32 and bf16 tiles against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "op_stress.py"), "18"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]

@@ -1,0 +1,48 @@
+"""Randomised shapes of the whole operator against the oracle (fp32 tiles): block sizes that are not multiples of 32,
+1..8 tables, every supported (head_dim, coords_dim) pair, one or several clouds.  python tools/op_stress.py [iters]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import hept_oracle as ho  # noqa: E402  (checker only)
+from hept_amd import ops  # noqa: E402
+from hept_amd.synthetic import make_inputs  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+g = torch.Generator().manual_seed(99)
+dev = torch.device("cuda", 0)
+pairs = [(24, 6), (24, 4), (24, 2), (16, 6), (16, 4), (8, 4)]
+bad = 0
+for it in range(iters):
+    d, c = pairs[it % len(pairs)]
+    b = int(torch.randint(8, 257, (1,), generator=g))
+    t = int(torch.randint(1, 9, (1,), generator=g))
+    n_clouds = int(torch.randint(1, 4, (1,), generator=g))
+    sizes = [int(torch.randint(b, 4 * b + 40, (1,), generator=g)) for _ in range(n_clouds)]
+    inp = make_inputs(sizes, block_size=b, n_hashes=t, coords_dim=c, h_dim=d, seed=1000 + it)
+    scale = 0.3
+    inp["q"], inp["k"] = inp["q"] * scale, inp["k"] * scale
+    inp["coords"] = inp["coords"] * 0.2
+    for prec, kw, tol in (("fp32", {}, 2e-5), ("bf16", dict(tile_dtype=torch.bfloat16), None)):
+        if prec == "bf16" and d != 24 and it % 2:
+            continue
+        want = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
+                          inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=b, w_per_dist=10, keep=False,
+                          **kw)["out"]
+        gd = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+        got = ops.forward(gd["q"], gd["k"], gd["v"], gd["coords"], gd["combined_shifts"], gd["w_rpe_weight"], gd["alpha"],
+                          gd["out_weight"], gd["out_bias"], block_size=b, w_per_dist=10, precision=prec).cpu()
+        err = (got - want).abs().amax(-1)
+        if tol is not None:
+            ok = float((err <= tol + 2e-4 * want.abs().amax(-1)).float().mean())
+        else:  # against the oracle's model of the bf16 arithmetic
+            ok = float((err <= 8e-3 * (want.abs().amax(-1) + 1e-2)).float().mean())
+        if not (ok >= 0.97 and bool(torch.isfinite(got).all())):
+            bad += 1
+            print(f"MISMATCH it={it} D={d} C={c} B={b} T={t} sizes={sizes} {prec}: rows ok {ok:.4f}", flush=True)
+print(f"{iters} shapes, {bad} mismatches")
+sys.exit(1 if bad else 0)
