@@ -1,5 +1,6 @@
 """Randomised shapes of the whole operator against the oracle (fp32 tiles): block sizes that are not multiples of 32,
-1..8 tables, every supported (head_dim, coords_dim) pair, one or several clouds.  python tools/op_stress.py [iters]"""
+1..8 tables, every supported (head_dim, coords_dim) pair, one or several clouds.  python tests/op_stress.py [iters]
+(test infrastructure: it is the only stress script that uses the oracle, hence it lives under tests/)."""
 import os
 import sys
 

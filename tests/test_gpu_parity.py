@@ -70,7 +70,7 @@ def _rows_scaled_ok(out, ref, rel):
 
 
 # stated tolerances of the 16-bit modes against the fp32 REFERENCE (measured 99th percentiles: bf16 <= 1.9e-2,
-# mixed16 <= 0.85e-2 of the row scale on every golden case, tools/tol_probe.py)
+# mixed16 <= 0.85e-2 of the row scale on every golden case, tests/diag_tol_probe.py)
 REL16 = {"bf16": 2.5e-2, "mixed16": 1.0e-2}
 
 
@@ -289,12 +289,12 @@ def test_edge_cases(gpu_device):
 
 
 def test_random_shapes_against_the_oracle(gpu_device):
-    """tools/op_stress.py: random block sizes (8..256, mostly not multiples of 32), 1..8 tables, every supported
+    """tests/op_stress.py: random block sizes (8..256, mostly not multiples of 32), 1..8 tables, every supported
     (head_dim, coords_dim) pair, 1..3 clouds; fp32 and bf16 tiles against the oracle."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = subprocess.run([sys.executable, os.path.join(root, "tools", "op_stress.py"), "18"], capture_output=True, text=True)
+    run = subprocess.run([sys.executable, os.path.join(root, "tests", "op_stress.py"), "18"], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
