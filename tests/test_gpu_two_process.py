@@ -1,0 +1,61 @@
+"""Two processes sharing ONE GPU (-m gpu): rank-dependent table slices computed by the HIP kernels in separate
+processes and summed through torch.distributed.  RCCL refuses two ranks on one device, so the group is gloo
+(all-reduce of the device tensors, staged through the host by gloo) -- the RCCL collectives themselves are covered
+by tests/test_gpu_dist.py on a 1-rank group and the exchange logic by tests/test_sharding_gloo.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, name, precision, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hept_amd import HEPTAttention
+
+        dev = torch.device("cuda", 0)
+        inp, _ = cases.load_case(name)
+        g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+        h, e, t = inp["alpha"].shape
+        m = HEPTAttention(e, h_dim=24, num_heads=h, block_size=inp["block_size"], n_hashes=t, num_w_per_dist=10,
+                          precision=precision, process_group=dist.group.WORLD)
+        assert m.sharding.mode == "all_reduce" and m.sharding.local_tables()[1] in (1, 2)
+        m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
+                           "e2lsh.alpha": inp["alpha"]})
+        m = m.to(dev).eval()
+        w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(dev)
+        with torch.no_grad():
+            w_rpe.weight.copy_(g["w_rpe_weight"])
+            out = m(g["q"], g["k"], g["v"], w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+        ret[rank] = out.cpu()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_processes_one_gpu(precision, gpu_device):
+    name = "g6_block100"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, name, precision, ret), nprocs=2, join=True)
+    assert torch.equal(ret[0], ret[1])
+    from hept_amd import ops
+
+    inp, _ = cases.load_case(name)
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    plain = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
+                        g["out_weight"], g["out_bias"], block_size=inp["block_size"], w_per_dist=10,
+                        precision=precision).cpu()
+    torch.testing.assert_close(ret[0], plain, rtol=1e-5, atol=1e-6)
