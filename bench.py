@@ -117,8 +117,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # self-check hooks (never set by the driver): HEPT_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL refuses
+    # that), HEPT_BENCH_EXCHANGE forces an exchange mode -- together they run the whole N>1 code path on a 1-GPU box
+    backend = os.environ.get("HEPT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     group = None
     multi = world > 1 or args.force_dist
     if multi:
@@ -127,7 +131,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         with c_stdout_to_stderr():
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
             dist.barrier()  # creates the communicator (and prints RCCL's banner) now
             torch.cuda.synchronize()
         group = dist.group.WORLD
@@ -150,6 +157,8 @@ def main():
     attn = attn.to(dev).eval()
     if args.force_dist and world == 1:
         attn.sharding.always_exchange = True
+    if multi and os.environ.get("HEPT_BENCH_EXCHANGE"):
+        attn.sharding.mode = os.environ["HEPT_BENCH_EXCHANGE"]
     w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(dev)
     with torch.no_grad():
         w_rpe.weight.copy_(g["w_rpe_weight"])
