@@ -1,3 +1,5 @@
+"""Forward latency at tracking-60k for several block sizes (64, 96, 100 = the reference's yaml, 128), both tile
+precisions, with the block_attn share from the HIP-event stage timer."""
 import sys, os, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from hept_amd import HEPTAttention, ops

@@ -1,3 +1,4 @@
+"""Host time to ISSUE one forward (Python + ctypes + 7 kernel launches) vs end-to-end time, for small clouds."""
 import sys, os, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from hept_amd import HEPTAttention, ops

@@ -1,3 +1,4 @@
+"""Sanity run far above the benchmark size (480k and 1.92M points in one cloud): finishes, finite, memory use."""
 import sys, os, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from hept_amd import HEPTAttention
