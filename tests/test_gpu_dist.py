@@ -85,3 +85,33 @@ def test_single_table_packed_partial_is_written_directly(nccl_group, gpu_device)
     one = ops.forward_partial(*args, t0=1, tl=1, packed=True, **common)
     wide = ops.forward_partial(*args, t0=1, tl=1, **common)
     assert torch.equal(ops.unpack_part(one), wide)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_sharded_src_variant_equals_plain(precision, nccl_group, gpu_device):
+    """Table sharding of the src variant (raw_size / region_indices kwargs) through the all-to-all exchange."""
+    inp, _ = cases.load_case_src("s1_src1000")
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    h, e, t = inp["alpha"].shape
+    kw = dict(variant="src", h_dim=24, num_heads=h, block_size=inp["block_size"], n_hashes=t, num_w_per_dist=10,
+              precision=precision)
+    sd = {"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"], "e2lsh.alpha": inp["alpha"],
+          "e2lsh.beta": torch.zeros(1, t)}
+    plain = HEPTAttention(e, **kw)
+    shard = HEPTAttention(e, process_group=nccl_group, **kw)
+    shard.sharding = TableSharding(t, nccl_group, mode="all_to_all", always_exchange=True)
+    for m in (plain, shard):
+        m.load_state_dict(sd, strict=True)
+        m.to(gpu_device).eval()
+    w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(gpu_device)
+    with torch.no_grad():
+        w_rpe.weight.copy_(g["w_rpe_weight"])
+        kwargs = dict(w_rpe=w_rpe, coords=g["coords"], raw_size=inp["raw_size"], regions_h=g["regions_h"],
+                      region_indices=[g["eta_idx"], g["phi_idx"]])
+        a = plain(g["q"], g["k"], g["v"], **kwargs)
+        b = shard(g["q"], g["k"], g["v"], **kwargs)
+    if precision == "fp32":
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
+    else:
+        err = (b - a).abs().amax(-1)
+        assert bool((err <= 4e-3 * (a.abs().amax(-1) + 1e-2)).all())
