@@ -27,8 +27,9 @@
  *   part         (Tl, N, H, row)     per-table partial rows, two formats:
  *                                      HEPT_PREC_F32 : 32 f32 = [numer(0..D-1) | denom(D) | 0]        (128 B)
  *                                      HEPT_PREC_BF16: 16 dwords = [24 bf16 numer | f32 denom | 0]    ( 64 B),
- *                                      written by hept_block_attn iff precision is bf16 and D == 24
- *   acc          (N, H, 32) f32      sum over tables of part, always in the f32 row format
+ *                                      written by hept_block_attn iff the tiles are 16-bit and D == 24
+ *   acc          (N, H, row)         sum over tables of part: f32 rows (N, H, 32), or packed rows again when the
+ *                                      caller asks for acc_precision HEPT_PREC_BF16 (table-sharding exchange)
  *   out          (N, D)     f32
  * "tile" element type is f32 (precision 0) or 16-bit (precision 1: bf16; precision 2: fp16 for q^/k^ rows, bf16 for v rows).
  */
