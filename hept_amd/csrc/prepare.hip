@@ -63,23 +63,23 @@ __global__ __launch_bounds__(PT) void codes_kernel(const int* __restrict__ rank,
                                                    int H, int* __restrict__ row_max /* [2][T*H] */,
                                                    int64_t* __restrict__ codes_raw) {
     const int row = blockIdx.y, t = row / H, h = row % H;
-    const int n = blockIdx.x * PT + threadIdx.x;
     int val = 0;
-    if (n < n_raw) {
+    // grid-stride: the reduction phases run with few workgroups per row (one atomic each: hundreds of atomics on
+    // one address were the whole cost of these phases)
+    for (int n = blockIdx.x * PT + threadIdx.x; n < n_raw; n += gridDim.x * PT) {
         const int c = cloud_of(cloud_start, n_clouds, n);
         const int n_c = cloud_start[c + 1] - cloud_start[c];
         const int eta = region_of(rank[n], n_c, regions[((size_t)t * 2 + 0) * H + h]);
         if (PHASE == 0) {
-            val = eta;
+            val = max(val, eta);
         } else {
             const int phi = region_of(rank[(size_t)n_raw + n], n_c, regions[((size_t)t * 2 + 1) * H + h]);
             const int p1 = (phi << bit_length(row_max[row])) | eta;
             if (PHASE == 1) {
-                val = p1;
+                val = max(val, p1);
             } else {
                 codes_raw[(size_t)row * n_raw + n] =
                     ((int64_t)c << bit_length(row_max[(size_t)T * H + row])) | (int64_t)p1;
-                return;
             }
         }
     }
@@ -194,9 +194,10 @@ extern "C" int hept_prepare_input(const float* coords, int C, const int32_t* clo
     if (rc) return rc;
     hipLaunchKernelGGL(rank_scatter_kernel, gridL, dim3(PT), 0, st, pos, cloud_start, L, n_raw, rank);
     if (hipMemsetAsync(row_max, 0, (size_t)2 * rows * 4, st) != hipSuccess) return HEPT_ERR_LAUNCH;
-    hipLaunchKernelGGL(codes_kernel<0>, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
+    const dim3 gridR(gridN.x < 8 ? gridN.x : 8, rows);  // reduction phases: <= 8 atomics per row
+    hipLaunchKernelGGL(codes_kernel<0>, gridR, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
                        codes_raw);
-    hipLaunchKernelGGL(codes_kernel<1>, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
+    hipLaunchKernelGGL(codes_kernel<1>, gridR, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
                        codes_raw);
     hipLaunchKernelGGL(codes_kernel<2>, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
                        codes_raw);

@@ -303,8 +303,8 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
 // -> scatter (any order): the pairs are now grouped by their full id, group g = [first[g], first[g+1]), and
 //        final position(i) = start + first[g] + #{ j in group g : pair_j < pair_i }        (pairs are unique u64)
 // Groups are 1-3 pairs at tracking-60k.  A bucket larger than the LDS tile takes the same three steps through a
-// global scratch copy, grouped by a monotone id of the pair over the bucket's own pair range (streaming; slower,
-// never wrong); a tile-sized bucket of equal keys costs at most CAP^2 compares.
+// global scratch copy, grouped by sampled splitters instead of id bits (streaming; slower, never wrong); a
+// tile-sized bucket of equal keys costs at most CAP^2 compares.
 // The whole bucket is loaded into registers with every load in flight at once; only the grouped copy lives in LDS.
 // One bins array serves as histogram, exclusive prefix and scatter cursor: after the scatter cur[d] is one past the
 // last slot of group d, i.e. group d = [cur[d-1], cur[d]).
@@ -333,39 +333,35 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     const SegParams rg = seg_params[seg];
     const bool in_lds = nb <= CAP;
     // Grouping key inside the bucket.  LDS path: the low bits of the global id.  Streaming path (a bucket that does
-    // not fit the tile holds a pile of equal or nearly equal keys, which those bits cannot separate): a monotone id of
-    // the u64 PAIR over the bucket's own pair range -- pairs are unique, so e.g. 60 000 equal keys spread evenly by
-    // index over the bins and the quadratic group count stays small.
-    unsigned long long pmin = 0ull;
-    double pscale = 0.0;
+    // not fit the tile holds a pile of equal or nearly equal keys, possibly next to a few spread ones, which neither
+    // those bits nor any linear map of the key range can separate): SPLITTERS -- LOBINS pairs sampled at regular
+    // positions of the bucket and sorted in LDS; a pair's bin is the number of splitters <= it (binary search).
+    // Pairs are unique u64, so even 60 000 equal keys spread over the bins by their index.
+    __shared__ unsigned long long spl_s[LOBINS];
     if (!in_lds) {
-        __shared__ unsigned long long red_s[2][BKT_WAVES];
-        unsigned long long lo = ~0ull, hi = 0ull;
-        for (int i = tid; i < nb; i += BKT_THREADS) {
-            const unsigned long long p = src[i];
-            lo = p < lo ? p : lo;
-            hi = p > hi ? p : hi;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned long long l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
-            lo = l2 < lo ? l2 : lo;
-            hi = h2 > hi ? h2 : hi;
-        }
-        if (lane == 0) { red_s[0][w] = lo; red_s[1][w] = hi; }
+        for (int i = tid; i < LOBINS; i += BKT_THREADS) spl_s[i] = src[(size_t)i * nb / LOBINS];
         __syncthreads();
-#pragma unroll
-        for (int ww = 0; ww < BKT_WAVES; ++ww) {
-            lo = red_s[0][ww] < lo ? red_s[0][ww] : lo;
-            hi = red_s[1][ww] > hi ? red_s[1][ww] : hi;
-        }
-        pmin = lo;
-        pscale = (double)LOBINS / ((double)(hi - lo) + 1.0);
+        for (int k = 2; k <= LOBINS; k <<= 1)          // bitonic sort, ascending
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < LOBINS; i += BKT_THREADS) {
+                    const int partner = i ^ j;
+                    if (partner > i) {
+                        const unsigned long long a = spl_s[i], b = spl_s[partner];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { spl_s[i] = b; spl_s[partner] = a; }
+                    }
+                }
+                __syncthreads();
+            }
     }
     auto lo_of = [&](unsigned long long p) -> unsigned int {
         if (in_lds) return bucket_id((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
-        const unsigned int b = (unsigned int)((double)(p - pmin) * pscale);  // monotone in p
-        return b < (unsigned int)LOBINS ? b : (unsigned int)(LOBINS - 1);
+        int lo = 0, hi = LOBINS;  // number of splitters <= p
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (spl_s[mid] <= p) lo = mid + 1; else hi = mid;
+        }
+        return (unsigned int)(lo > 0 ? lo - 1 : 0);
     };
     unsigned int* bin_s = cur_s + 1;
 #pragma unroll
@@ -473,45 +469,61 @@ __global__ __launch_bounds__(SORT_THREADS) void src_bound_kernel(const float* __
 }
 
 // ---- generic front end (hept_segmented_argsort): S segments of L raw fp32 keys, +inf allowed as padding ----
-// finite min/max of one segment -> id map parameters
+// finite min / max of every segment: one workgroup per 4096-key chunk folds into two ordered-uint words per segment
+// with one atomicMin each (word 0: min, word 1: complement of the max; both start at 0xFFFFFFFF)
 __global__ __launch_bounds__(SORT_THREADS) void raw_range_kernel(const float* __restrict__ keys, int L,
-                                                                 SegParams* __restrict__ seg_params) {
-    __shared__ float red_s[2][SORT_WAVES];
-    const int tid = threadIdx.x, seg = blockIdx.x;
+                                                                 unsigned int* __restrict__ range_bits) {
+    __shared__ unsigned int red_s[2][SORT_WAVES];
+    const int tid = threadIdx.x, seg = blockIdx.y;
     const float* k = keys + (size_t)seg * L;
-    float lo = INFINITY, hi = -INFINITY;
-    for (int i = tid; i < L; i += SORT_THREADS) {
-        const float x = k[i];
-        if (x < INFINITY && x > -INFINITY) {
-            lo = fminf(lo, x);
-            hi = fmaxf(hi, x);
+    unsigned int lo = 0xFFFFFFFFu, nhi = 0xFFFFFFFFu;
+    const int base = blockIdx.x * SORT_CHUNK;
+#pragma unroll 4
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int n = base + i * SORT_THREADS + tid;
+        if (n < L) {
+            const float x = k[n];
+            if (x < INFINITY && x > -INFINITY) {
+                const unsigned int u = ordered_bits(x);
+                lo = min(lo, u);
+                nhi = min(nhi, ~u);
+            }
         }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, off));
-        hi = fmaxf(hi, __shfl_xor(hi, off));
+        lo = min(lo, (unsigned int)__shfl_xor((int)lo, off));
+        nhi = min(nhi, (unsigned int)__shfl_xor((int)nhi, off));
     }
-    if ((tid & 63) == 0) { red_s[0][tid >> 6] = lo; red_s[1][tid >> 6] = hi; }
+    if ((tid & 63) == 0) { red_s[0][tid >> 6] = lo; red_s[1][tid >> 6] = nhi; }
     __syncthreads();
     if (tid == 0) {
-        lo = fminf(fminf(red_s[0][0], red_s[0][1]), fminf(red_s[0][2], red_s[0][3]));
-        hi = fmaxf(fmaxf(red_s[1][0], red_s[1][1]), fmaxf(red_s[1][2], red_s[1][3]));
-        const float width = hi - lo;
-        float scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
-        if (!(scale < 3.0e38f)) scale = 0.f;
-        seg_params[seg] = SegParams{lo > hi ? 0.f : lo, scale};
+#pragma unroll
+        for (int ww = 1; ww < SORT_WAVES; ++ww) { lo = min(lo, red_s[0][ww]); nhi = min(nhi, red_s[1][ww]); }
+        if (lo != 0xFFFFFFFFu) atomicMin(range_bits + 2 * seg, lo);
+        if (nhi != 0xFFFFFFFFu) atomicMin(range_bits + 2 * seg + 1, nhi);
     }
 }
 
 // keys0 = ordered bits of the raw keys + per-chunk histogram of the low id byte
 __global__ __launch_bounds__(SORT_THREADS) void raw_keygen_hist_kernel(const float* __restrict__ keys, int L,
-                                                                       const SegParams* __restrict__ seg_params,
+                                                                       const unsigned int* __restrict__ range_bits,
+                                                                       SegParams* __restrict__ seg_params,
                                                                        unsigned int* __restrict__ keys0,
                                                                        unsigned int* __restrict__ hist, int n_chunks) {
     __shared__ unsigned int h_s[RADIX];
     const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
-    const SegParams rg = seg_params[seg];
+    SegParams rg;
+    {
+        const unsigned int lo_b = range_bits[2 * seg], nhi_b = range_bits[2 * seg + 1];
+        const bool none = lo_b == 0xFFFFFFFFu && nhi_b == 0xFFFFFFFFu;  // no finite key in the segment
+        const float lo = none ? 0.f : from_ordered(lo_b), hi = none ? 0.f : from_ordered(~nhi_b);
+        const float width = hi - lo;
+        float scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
+        if (!(scale < 3.0e38f)) scale = 0.f;
+        rg = SegParams{lo, scale};
+        if (chunk == 0 && tid == 0) seg_params[seg] = rg;
+    }
     h_s[tid] = 0;
     __syncthreads();
     const int base = chunk * SORT_CHUNK;
@@ -704,6 +716,7 @@ struct SortBuffers {
     unsigned long long *pa, *pb;
     unsigned int* hist;
     unsigned int* bstart;  // [segs][RADIX] first position of every top-level bucket
+    unsigned int* range;   // [segs][2] ordered-uint finite min / ~max of raw keys (hept_segmented_argsort)
     SegParams* params;
 };
 SortBuffers carve_sort(void* sort_ws, int segs, int N) {
@@ -721,6 +734,8 @@ SortBuffers carve_sort(void* sort_ws, int segs, int N) {
     ws += al((size_t)segs * n_chunks * RADIX * 4);
     b.bstart = reinterpret_cast<unsigned int*>(ws);
     ws += al((size_t)segs * RADIX * 4);
+    b.range = reinterpret_cast<unsigned int*>(ws);
+    ws += al((size_t)segs * 8);
     b.params = reinterpret_cast<SegParams*>(ws);
     return b;
 }
@@ -746,7 +761,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t sort_bytes(size_t segs, size_t N) {
     const size_t n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     return align256(segs * N * 4) + 2 * align256(segs * N * 8) + align256(segs * n_chunks * RADIX * 4) +
-           align256(segs * RADIX * 4) + align256(segs * sizeof(SegParams));
+           align256(segs * RADIX * 4) + align256(segs * 8) + align256(segs * sizeof(SegParams));
 }
 
 extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) { return sort_bytes((size_t)2 * Tl * H, N); }
@@ -800,9 +815,10 @@ extern "C" int hept_segmented_argsort(const float* keys, int S, int L, void* ws,
         return launch_small_sort<2>(S, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, L, 1, 0, 1, pos);
     const int n_chunks = (L + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(ws, S, L);
-    hipLaunchKernelGGL(raw_range_kernel, dim3(S), dim3(SORT_THREADS), 0, st, keys, L, b.params);
-    hipLaunchKernelGGL(raw_keygen_hist_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, b.params, b.keys0,
-                       b.hist, n_chunks);
+    if (hipMemsetAsync(b.range, 0xFF, (size_t)S * 8, st) != hipSuccess) return HEPT_ERR_LAUNCH;
+    hipLaunchKernelGGL(raw_range_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, b.range);
+    hipLaunchKernelGGL(raw_keygen_hist_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, b.range, b.params,
+                       b.keys0, b.hist, n_chunks);
     run_passes(b, S, L, pos, st);
     return hept_launch_status();
 }
