@@ -36,6 +36,7 @@ SIGNATURES = {
     "hept_sort_tables": (c_int, [_P] * 4 + [c_int] * 5 + [_P] * 4),
     "hept_sort_tables_src": (c_int, [_P] * 6 + [c_int] * 5 + [_P] * 4),
     "hept_argsort_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "hept_segmented_argsort_ragged": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "hept_segmented_argsort": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "hept_block_attn": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P]),
     "hept_part_precision": (c_int, [c_int, c_int]),

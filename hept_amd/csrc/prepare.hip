@@ -18,15 +18,16 @@ constexpr int PT = 256;
 
 __device__ __forceinline__ int bit_length(int m) { return m <= 0 ? 0 : 32 - __clz(m); }
 
-// keys[(c*2 + a)][j] = coordinate a of the j-th point of cloud c, +inf beyond the cloud
+// keys[(c*2 + a)][j] = coordinate a of the j-th point of cloud c (row pitch L, only the first n_c entries are
+// written and sorted: seg_len[c*2 + a] = n_c)
 __global__ __launch_bounds__(PT) void coord_keys_kernel(const float* __restrict__ coords, int C,
                                                         const int* __restrict__ cloud_start, int L,
-                                                        float* __restrict__ keys) {
+                                                        float* __restrict__ keys, int* __restrict__ seg_len) {
     const int seg = blockIdx.y, c = seg >> 1, a = seg & 1;
     const int j = blockIdx.x * PT + threadIdx.x;
-    if (j >= L) return;
     const int s = cloud_start[c], n_c = cloud_start[c + 1] - s;
-    keys[(size_t)seg * L + j] = j < n_c ? coords[(size_t)(s + j) * C + a] : INFINITY;
+    if (j == 0) seg_len[seg] = n_c;
+    if (j < n_c) keys[(size_t)seg * L + j] = coords[(size_t)(s + j) * C + a];
 }
 
 // rank[a][point] = position of the point in its cloud's ascending order of coordinate a
@@ -149,6 +150,7 @@ extern "C" size_t hept_prepare_workspace_bytes(int n_raw, int n_clouds, int max_
     size_t b = 0;
     b += al256(S * sortL * 4);                                         // coordinate key matrix
     b += al256(S * sortL * 4);                                         // its argsort
+    b += al256(S * 4);                                                 // points per (cloud, axis) segment
     b += al256((size_t)2 * n_raw * 4);                                 // ranks
     b += al256((size_t)2 * T * H * 4);                                 // row maxima
     b += al256((size_t)T * H * n_raw * 8);                             // raw codes
@@ -181,6 +183,7 @@ extern "C" int hept_prepare_input(const float* coords, int C, const int32_t* clo
     };
     float* keys = reinterpret_cast<float*>(take((size_t)S * L * 4));
     int* pos = reinterpret_cast<int*>(take((size_t)S * L * 4));
+    int* seg_len = reinterpret_cast<int*>(take((size_t)S * 4));
     int* rank = reinterpret_cast<int*>(take((size_t)2 * n_raw * 4));
     int* row_max = reinterpret_cast<int*>(take((size_t)2 * rows * 4));
     int64_t* codes_raw = reinterpret_cast<int64_t*>(take((size_t)rows * n_raw * 8));
@@ -189,8 +192,8 @@ extern "C" int hept_prepare_input(const float* coords, int C, const int32_t* clo
     void* sort_ws = ws;
 
     const dim3 gridL((L + PT - 1) / PT, S), gridN((n_raw + PT - 1) / PT, rows);
-    hipLaunchKernelGGL(coord_keys_kernel, gridL, dim3(PT), 0, st, coords, C, cloud_start, L, keys);
-    int rc = hept_segmented_argsort(keys, S, L, sort_ws, pos, stream);
+    hipLaunchKernelGGL(coord_keys_kernel, gridL, dim3(PT), 0, st, coords, C, cloud_start, L, keys, seg_len);
+    int rc = hept_segmented_argsort_ragged(keys, S, L, seg_len, sort_ws, pos, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(rank_scatter_kernel, gridL, dim3(PT), 0, st, pos, cloud_start, L, n_raw, rank);
     if (hipMemsetAsync(row_max, 0, (size_t)2 * rows * 4, st) != hipSuccess) return HEPT_ERR_LAUNCH;

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
                                                                const SegParams* __restrict__ seg_params,
                                                                const unsigned int* __restrict__ hist, int N,
                                                                int n_chunks, unsigned int* __restrict__ bstart,
-                                                               unsigned long long* __restrict__ dst_pairs) {
+                                                               unsigned long long* __restrict__ dst_pairs,
+                                                               const int* __restrict__ seg_len) {
     __shared__ unsigned long long stage_s[SORT_CHUNK];   // the chunk, digit-sorted (32 KiB)
     __shared__ unsigned int cnt_s[RADIX];                // keys of the chunk per digit
     __shared__ unsigned int start_s[RADIX];              // first local position of a digit
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int seg = blockIdx.y, chunk = blockIdx.x;
     const SegParams rg = seg_params[seg];
-    const size_t seg_off = (size_t)seg * N;
+    const size_t seg_off = (size_t)seg * N;        // N = segment stride; len = keys that take part (ragged argsort)
+    const int len = seg_len ? seg_len[seg] : N;
     cnt_s[tid] = 0;
     // global offset of digit `tid` for this chunk = (keys of the segment with a smaller digit) + (same digit in
     // earlier chunks): every workgroup reduces the segment's chunk histograms itself (a few KiB from L2) instead
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int n = base + r * SORT_THREADS + tid;
-        key[r] = n < N ? keys0[seg_off + n] : 0u;
+        key[r] = n < len ? keys0[seg_off + n] : 0u;
     }
     {
         unsigned int incl = tot;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
         const int n = base + r * SORT_THREADS + tid;
         const unsigned int dg = bucket_id(key[r], rg.kmin, rg.scale) >> TOP_SHIFT;
         dig[r] = (unsigned char)dg;
-        rank[r] = n < N ? (unsigned short)atomicAdd(&cnt_s[dg], 1u) : (unsigned short)0;
+        rank[r] = n < len ? (unsigned short)atomicAdd(&cnt_s[dg], 1u) : (unsigned short)0;
     }
     __syncthreads();
     // digit `tid`: exclusive prefix over the digits -> first local position of the digit
@@ -281,11 +283,11 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int n = base + r * SORT_THREADS + tid;
-        if (n < N) stage_s[start_s[dig[r]] + rank[r]] = ((unsigned long long)key[r] << 32) | (unsigned int)n;
+        if (n < len) stage_s[start_s[dig[r]] + rank[r]] = ((unsigned long long)key[r] << 32) | (unsigned int)n;
     }
     __syncthreads();
     // write out: consecutive local positions of one digit are consecutive global positions
-    const int n_valid = min(SORT_CHUNK, N - base);
+    const int n_valid = min(SORT_CHUNK, len - base);
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int lp = r * SORT_THREADS + tid;
@@ -317,7 +319,8 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
                                                                   unsigned long long* __restrict__ scratch,
                                                                   const SegParams* __restrict__ seg_params,
                                                                   const unsigned int* __restrict__ bstart, int N,
-                                                                  int* __restrict__ pos_out) {
+                                                                  int* __restrict__ pos_out,
+                                                                  const int* __restrict__ seg_len) {
     __shared__ unsigned long long tile_s[CAP];
     __shared__ unsigned int cur_s[LOBINS + 1];  // [0] stays 0; bin d lives at [d + 1]
     __shared__ unsigned int wsum_s[BKT_WAVES];
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     const int seg = blockIdx.y, bucket = blockIdx.x;
     const unsigned int* o = bstart + (size_t)seg * RADIX;  // keys of the segment with a smaller digit (written by K3)
     const int start = (int)o[bucket];
-    const int end = bucket == NTOP - 1 ? N : (int)o[bucket + 1];
+    const int end = bucket == NTOP - 1 ? (seg_len ? seg_len[seg] : N) : (int)o[bucket + 1];
     const int nb = end - start;
     if (nb <= 0) return;
     const unsigned long long* src = pairs + (size_t)seg * N + start;
@@ -472,16 +475,18 @@ __global__ __launch_bounds__(SORT_THREADS) void src_bound_kernel(const float* __
 // finite min / max of every segment: one workgroup per 4096-key chunk folds into two ordered-uint words per segment
 // with one atomicMin each (word 0: min, word 1: complement of the max; both start at 0xFFFFFFFF)
 __global__ __launch_bounds__(SORT_THREADS) void raw_range_kernel(const float* __restrict__ keys, int L,
+                                                                 const int* __restrict__ seg_len,
                                                                  unsigned int* __restrict__ range_bits) {
     __shared__ unsigned int red_s[2][SORT_WAVES];
     const int tid = threadIdx.x, seg = blockIdx.y;
     const float* k = keys + (size_t)seg * L;
+    const int len = seg_len ? seg_len[seg] : L;
     unsigned int lo = 0xFFFFFFFFu, nhi = 0xFFFFFFFFu;
     const int base = blockIdx.x * SORT_CHUNK;
 #pragma unroll 4
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const int n = base + i * SORT_THREADS + tid;
-        if (n < L) {
+        if (n < len) {
             const float x = k[n];
             if (x < INFINITY && x > -INFINITY) {
                 const unsigned int u = ordered_bits(x);
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(SORT_THREADS) void raw_range_kernel(const float* __
 
 // keys0 = ordered bits of the raw keys + per-chunk histogram of the low id byte
 __global__ __launch_bounds__(SORT_THREADS) void raw_keygen_hist_kernel(const float* __restrict__ keys, int L,
+                                                                       const int* __restrict__ seg_len,
                                                                        const unsigned int* __restrict__ range_bits,
                                                                        SegParams* __restrict__ seg_params,
                                                                        unsigned int* __restrict__ keys0,
@@ -527,10 +533,11 @@ __global__ __launch_bounds__(SORT_THREADS) void raw_keygen_hist_kernel(const flo
     h_s[tid] = 0;
     __syncthreads();
     const int base = chunk * SORT_CHUNK;
+    const int len = seg_len ? seg_len[seg] : L;
 #pragma unroll 4
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const int n = base + i * SORT_THREADS + tid;
-        if (n < L) {
+        if (n < len) {
             const unsigned int u = ordered_bits(keys[(size_t)seg * L + n]);
             keys0[(size_t)seg * L + n] = u;
             atomicAdd(&h_s[bucket_id(u, rg.kmin, rg.scale) >> TOP_SHIFT], 1u);
@@ -556,13 +563,15 @@ template <int MODE>
 __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
     const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
     const float* __restrict__ eta_idx, const float* __restrict__ phi_idx, const float* __restrict__ cfac,
-    const float* __restrict__ minmax, int N, int H, int t0, int Tl, int* __restrict__ pos_out) {
+    const float* __restrict__ minmax, int N_stride, int H, int t0, int Tl, int* __restrict__ pos_out,
+    const int* __restrict__ seg_len) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long small_tile_s[];  // [SMALL_CAP] pairs, then bins
     __shared__ float red_s[3][SMALL_WAVES];
     __shared__ unsigned int wsum_s[SMALL_WAVES];
     unsigned int* cur_s = reinterpret_cast<unsigned int*>(small_tile_s + SMALL_CAP);  // [0] stays 0; bin d at [d + 1]
     unsigned int* bin_s = cur_s + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, seg = blockIdx.x;
+    const int N = seg_len ? seg_len[seg] : N_stride;  // keys that take part (ragged argsort); N_stride = segment pitch
     for (int i = tid; i < SMALL_BINS + 1; i += SMALL_THREADS) cur_s[i] = 0;
 
     // ---- key range of the segment
@@ -570,15 +579,15 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
     const float* proj;
     size_t row_off = 0;
     if (MODE == 2) {
-        proj = qproj + (size_t)seg * N;  // raw keys
+        proj = qproj + (size_t)seg * N_stride;  // raw keys
         for (int i = tid; i < N; i += SMALL_THREADS) {
             const float x = proj[i];
             if (x < INFINITY && x > -INFINITY) { lo = fminf(lo, x); hi = fmaxf(hi, x); }
         }
     } else {
         const int th = seg % (Tl * H), t = th / H, h = th % H;
-        proj = (seg >= Tl * H ? kproj : qproj) + (size_t)th * N;
-        row_off = ((size_t)(t0 + t) * H + h) * N;
+        proj = (seg >= Tl * H ? kproj : qproj) + (size_t)th * N_stride;
+        row_off = ((size_t)(t0 + t) * H + h) * N_stride;
         for (int i = tid; i < HEPT_PREP_GRID; i += SMALL_THREADS) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(minmax + (((size_t)t * H + h) * HEPT_PREP_GRID + i) * 4);
             lo = fminf(lo, m[0]); hi = fmaxf(hi, m[1]); cmax = fmaxf(cmax, m[2]);
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
         if (u * SMALL_THREADS + tid < N)
             small_tile_s[atomicAdd(&bin_s[bin_of((unsigned int)(mine[u] >> 32))], 1u)] = mine[u];
     __syncthreads();
-    int* out = pos_out + (size_t)seg * N;
+    int* out = pos_out + (size_t)seg * N_stride;
     for (int i = tid; i < N; i += SMALL_THREADS) {
         const unsigned long long p = small_tile_s[i];
         const unsigned int d = bin_of((unsigned int)(p >> 32));
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
 template <int MODE>
 int launch_small_sort(int segs, hipStream_t st, const float* qproj, const float* kproj, const int64_t* codes,
                       const float* eta, const float* phi, const float* cfac, const float* minmax, int N, int H, int t0,
-                      int Tl, int* pos) {
+                      int Tl, int* pos, const int* seg_len = nullptr) {
     static bool raised = false;
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_sort_kernel<MODE>),
@@ -706,7 +715,7 @@ int launch_small_sort(int segs, hipStream_t st, const float* qproj, const float*
         raised = true;
     }
     hipLaunchKernelGGL(small_sort_kernel<MODE>, dim3(segs), dim3(SMALL_THREADS), SMALL_LDS, st, qproj, kproj, codes, eta,
-                       phi, cfac, minmax, N, H, t0, Tl, pos);
+                       phi, cfac, minmax, N, H, t0, Tl, pos, seg_len);
     return hept_launch_status();
 }
 
@@ -741,17 +750,17 @@ SortBuffers carve_sort(void* sort_ws, int segs, int N) {
 }
 constexpr int BKT_CAP_SMALL = HEPT_BKT_CAP;  // LDS tile: the average bucket is N/NTOP
 constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segments (average bucket up to ~3000 pairs)
-void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st) {
+void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const int* seg_len = nullptr) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const dim3 grid(n_chunks, segs), block(SORT_THREADS);
-    hipLaunchKernelGGL(scatter_kernel, grid, block, 0, st, b.keys0, b.params, b.hist, N, n_chunks, b.bstart, b.pa);
+    hipLaunchKernelGGL(scatter_kernel, grid, block, 0, st, b.keys0, b.params, b.hist, N, n_chunks, b.bstart, b.pa, seg_len);
     const dim3 grid4(NTOP, segs);
     if ((size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2))
         hipLaunchKernelGGL(bucket_sort_kernel<BKT_CAP_SMALL>, grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
-                           b.bstart, N, pos);
+                           b.bstart, N, pos, seg_len);
     else
         hipLaunchKernelGGL(bucket_sort_kernel<BKT_CAP_LARGE>, grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
-                           b.bstart, N, pos);
+                           b.bstart, N, pos, seg_len);
 }
 
 }  // namespace
@@ -807,18 +816,31 @@ extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, cons
 
 extern "C" size_t hept_argsort_workspace_bytes(int S, int L) { return sort_bytes((size_t)S, (size_t)L); }
 
-extern "C" int hept_segmented_argsort(const float* keys, int S, int L, void* ws, int32_t* pos, void* stream) {
+namespace {
+int segmented_argsort_impl(const float* keys, int S, int L, const int* seg_len, void* ws, int32_t* pos, void* stream) {
     if (!keys || !ws || !pos) return HEPT_ERR_ARG;
     if (S < 1 || L < 1) return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (L <= SMALL_CAP)
-        return launch_small_sort<2>(S, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, L, 1, 0, 1, pos);
+        return launch_small_sort<2>(S, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, L, 1, 0, 1, pos,
+                                    seg_len);
     const int n_chunks = (L + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(ws, S, L);
     if (hipMemsetAsync(b.range, 0xFF, (size_t)S * 8, st) != hipSuccess) return HEPT_ERR_LAUNCH;
-    hipLaunchKernelGGL(raw_range_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, b.range);
-    hipLaunchKernelGGL(raw_keygen_hist_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, b.range, b.params,
-                       b.keys0, b.hist, n_chunks);
-    run_passes(b, S, L, pos, st);
+    hipLaunchKernelGGL(raw_range_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, seg_len, b.range);
+    hipLaunchKernelGGL(raw_keygen_hist_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, seg_len, b.range,
+                       b.params, b.keys0, b.hist, n_chunks);
+    run_passes(b, S, L, pos, st, seg_len);
     return hept_launch_status();
+}
+}  // namespace
+
+extern "C" int hept_segmented_argsort(const float* keys, int S, int L, void* ws, int32_t* pos, void* stream) {
+    return segmented_argsort_impl(keys, S, L, nullptr, ws, pos, stream);
+}
+
+extern "C" int hept_segmented_argsort_ragged(const float* keys, int S, int L, const int32_t* seg_len, void* ws,
+                                             int32_t* pos, void* stream) {
+    if (!seg_len) return HEPT_ERR_ARG;
+    return segmented_argsort_impl(keys, S, L, seg_len, ws, pos, stream);
 }

@@ -129,15 +129,25 @@ def sort_tables_src(qproj, kproj, eta_idx, phi_idx, cfac, minmax, t0: int = 0) -
     return pos[0], pos[1]
 
 
-def segmented_argsort(keys: torch.Tensor) -> torch.Tensor:
-    """Stable ascending argsort of every row of a float32 (S, L) GPU tensor (+inf pads sort last); int32 (S, L)."""
+def segmented_argsort(keys: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Stable ascending argsort of every row of a float32 (S, L) GPU tensor (+inf pads sort last); int32 (S, L).
+
+    With ``lens`` (int32 (S,), on the GPU) only the first ``lens[s]`` keys of row s take part and only
+    ``pos[s, :lens[s]]`` is defined (the ragged form ``prepare_input`` uses for clouds of unequal size)."""
     lib = _lib.load()
     keys = _f32c(keys, "keys")
     s_, l_ = keys.shape
     ws = torch.empty(int(lib.hept_argsort_workspace_bytes(s_, l_)), device=keys.device, dtype=torch.uint8)
     pos = torch.empty(s_, l_, device=keys.device, dtype=torch.int32)
-    _lib.check(lib.hept_segmented_argsort(keys.data_ptr(), s_, l_, ws.data_ptr(), pos.data_ptr(), _stream(keys)),
-               "hept_segmented_argsort")
+    if lens is None:
+        rc = lib.hept_segmented_argsort(keys.data_ptr(), s_, l_, ws.data_ptr(), pos.data_ptr(), _stream(keys))
+    else:
+        if lens.dtype != torch.int32 or lens.shape != (s_,) or lens.device != keys.device:
+            raise ValueError("lens must be an int32 (S,) tensor on the keys' device")
+        lens = lens.contiguous()
+        rc = lib.hept_segmented_argsort_ragged(keys.data_ptr(), s_, l_, lens.data_ptr(), ws.data_ptr(), pos.data_ptr(),
+                                               _stream(keys))
+    _lib.check(rc, "hept_segmented_argsort")
     return pos
 
 

@@ -103,6 +103,11 @@ int hept_sort_tables_src(const float* qproj, const float* kproj, const float* et
  * hept_prepare_input; equals torch.sort(stable=True).indices. */
 size_t hept_argsort_workspace_bytes(int S, int L);
 int hept_segmented_argsort(const float* keys, int S, int L, void* ws, int32_t* pos, void* stream);
+/* Ragged form: only the first seg_len[s] (device i32, 0 <= seg_len[s] <= L) keys of segment s take part; pos[s][0 ..
+ * seg_len[s]) is their stable ascending permutation, the rest of the row is left untouched.  (Per-cloud sorts of a
+ * batch of clouds of different sizes: padding every segment with +inf keys would sort the padding too.) */
+int hept_segmented_argsort_ragged(const float* keys, int S, int L, const int32_t* seg_len, void* ws,
+                                  int32_t* pos, void* stream);
 
 /* replaces sort_to_buckets x3 (example/hept.py:70-72), qkv_res (:7-18), invert_permutation and
  * unsort_from_buckets x2 (:76-78): gather -> block-local RBF attention on MFMA -> scatter. */

@@ -128,3 +128,25 @@ def test_segmented_argsort_randomised(gpu_device):
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "sort_stress.py"), "60"], capture_output=True,
                          text=True)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+def test_segmented_argsort_ragged(gpu_device):
+    """Ragged segments: only the first lens[s] keys of a row take part (whatever lies behind them, NaN included);
+    pos[s, :lens[s]] equals the stable sort of that prefix.  Covers the one-workgroup path (short rows), the
+    bucket path (long rows) and rows of length 0 / 1."""
+    g = torch.Generator().manual_seed(31)
+    for s_, l_ in [(6, 700), (5, 9000), (3, 70000), (40, 33)]:
+        keys = torch.randn(s_, l_, generator=g)
+        if l_ == 9000:
+            keys = keys.round()  # heavy ties: stability matters
+        lens = torch.randint(0, l_ + 1, (s_,), generator=g, dtype=torch.int32)
+        lens[0], lens[-1] = l_, min(1, l_)
+        if s_ > 2:
+            lens[1] = 0
+        poisoned = keys.clone()
+        for s in range(s_):
+            poisoned[s, int(lens[s]):] = float("nan") if s % 2 else -1e30
+        pos = ops.segmented_argsort(poisoned.to(gpu_device), lens.to(gpu_device)).long().cpu()
+        for s in range(s_):
+            n = int(lens[s])
+            assert torch.equal(pos[s, :n], torch.sort(keys[s, :n], stable=True).indices), (s_, l_, s, n)
