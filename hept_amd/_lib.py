@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 from .build import LIB_PATH
 
 ABI_VERSION = 7
-PREC_F32, PREC_BF16, PREC_MIXED16 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
 MAX_BLOCK = 256

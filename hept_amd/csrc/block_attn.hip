@@ -220,6 +220,239 @@ void block_attn_kernel(const char* __restrict__ qhat,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// f32 tiles on the bf16 matrix pipe ("split" kernel, the default for HEPT_PREC_F32).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate, and the f32-tile kernel above is bound by it (49 % MFMA
+// busy at 300 us).  A product of two f32 values is recovered to f32 accuracy from bf16 pieces: a = ah + am + al
+// with ah = bf16(a), am = bf16(a - ah), al = bf16(a - ah - am) (each residual is exact in f32), and
+//     a.b = ah.bh + (ah.bm + am.bh) + (am.bm + ah.bl + al.bh) + O(2^-26 |a||b|)
+// -- six bf16 MFMAs with f32 accumulation instead of eight f32 MFMAs of 1/16 the rate each (3/8 of the issue
+// slots, 1/16 of the cycles per slot).  Both products use all six terms (VP = 3 planes for V and three pieces of
+// P): measured against the CPU oracle the output error is then that of the f32 MFMA kernel (1.4e-8 vs 2.0e-8 mean
+// on the pileup case); with two pieces for P.V (VP = 2, relative error 2^-17) it is 7x larger.  K^ and V are split
+// once per workgroup while they are staged (3 + VP bf16 planes in LDS, 384 B per key instead of 256), the wave's
+// Q^ rows once into registers, P in registers after the exp.  The norms -|q|^2/2, -|k|^2/2 ride in the product
+// through the two spare columns (30, 31) against a 1.0 on the other side.
+// Inputs, outputs and the (t, block, head) -> workgroup map are those of the f32-tile kernel.
+__device__ __forceinline__ void split3_bf16(const float (&a)[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int hp = hept_pack_bf16(a[2 * j], a[2 * j + 1]);
+        const float r0 = a[2 * j] - hept_bf16_lo(hp), r1 = a[2 * j + 1] - hept_bf16_hi(hp);
+        const unsigned int mp = hept_pack_bf16(r0, r1);
+        const float s0 = r0 - hept_bf16_lo(mp), s1 = r1 - hept_bf16_hi(mp);
+        h[j] = hp;
+        m[j] = mp;
+        l[j] = hept_pack_bf16(s0, s1);
+    }
+}
+__device__ __forceinline__ void split2_bf16(const float (&a)[8], u32x4& h, u32x4& m) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int hp = hept_pack_bf16(a[2 * j], a[2 * j + 1]);
+        h[j] = hp;
+        m[j] = hept_pack_bf16(a[2 * j] - hept_bf16_lo(hp), a[2 * j + 1] - hept_bf16_hi(hp));
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+}
+
+template <int NKT, bool FULL, int VP>
+__global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float* __restrict__ qhat,
+                                                                    const float* __restrict__ kvhat,
+                                                                    const int* __restrict__ qpos,
+                                                                    const int* __restrict__ kpos,
+                                                                    float* __restrict__ part, int N, int H, int D,
+                                                                    int B, int nb) {
+    constexpr int NT = 64 * NKT;
+    constexpr int KEYS = 32 * NKT;
+    constexpr int PROW = 64;  // bytes of one 32-column bf16 plane row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_s = smem;                         // 3 planes [KEYS][32 bf16], 16-B chunks XOR-swizzled
+    char* v_s = smem + 3 * KEYS * PROW;       // VP planes [KEYS][32 bf16], read transposed
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
+    const int bid = blockIdx.x;
+    const int h = bid % H;
+    const int rest = bid / H;
+    const int b = rest % nb, t = rest / nb;
+    const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
+    const int* __restrict__ kp = kpos + seg;
+    const int* __restrict__ qp = qpos + seg;
+    const float* __restrict__ qbase = qhat + (size_t)h * N * 32;
+    const float* __restrict__ kvbase = kvhat + (size_t)h * N * 64;
+
+    // ---- this wave's 32 query rows -> three bf16 planes in registers (B-operand layout: lane-half hh of step s
+    //      holds columns 16 s + 8 hh .. + 8)
+    const int qi = w * 32 + li;
+    const bool qvalid = FULL || qi < B;
+    const int qsrc = qp[qvalid ? qi : 0];
+    const float* qrow = qbase + (size_t)qsrc * 32;
+    u32x4 qh[2], qm[2], ql[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hh);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hh + 4);
+        float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (s == 1 && hh == 1) {  // the norms ride in the product: q^[30] = -|q|^2/2 meets k^[30] = 1, q^[31] = 1
+            a[6] = a[7];          // meets k^[31] = -|k|^2/2 (columns E..30 of the stored rows are zero, E <= 30)
+            a[7] = 1.f;
+        }
+        split3_bf16(a, qh[s], qm[s], ql[s]);
+    }
+
+    // ---- stage K^ (3 planes) and V (2 planes): one item = 8 consecutive columns of a gathered kvhat row
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ci = it * NT + tid;
+        const int key = ci >> 3, c = ci & 7;  // c < 4: K^ columns 8c..; c >= 4: V columns 8(c-4)..
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (FULL || key < B) {
+            const float* src = kvbase + (size_t)kp[key] * 64 + c * 8;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
+            a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
+            a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+        }
+        if (c < 4) {
+            if (c == 3 && (FULL || key < B)) a[6] = 1.f;
+            u32x4 ph, pm, pl;
+            split3_bf16(a, ph, pm, pl);
+            const int off = key * PROW + ((c ^ ((key >> 2) & 3)) * 16);
+            *reinterpret_cast<u32x4*>(k_s + off) = ph;
+            *reinterpret_cast<u32x4*>(k_s + KEYS * PROW + off) = pm;
+            *reinterpret_cast<u32x4*>(k_s + 2 * KEYS * PROW + off) = pl;
+        } else {
+            u32x4 ph, pm, pl;
+            if constexpr (VP == 3) split3_bf16(a, ph, pm, pl);
+            else split2_bf16(a, ph, pm);
+            const int off = key * PROW + (c - 4) * 16;
+            *reinterpret_cast<u32x4*>(v_s + off) = ph;
+            *reinterpret_cast<u32x4*>(v_s + KEYS * PROW + off) = pm;
+            if constexpr (VP == 3) *reinterpret_cast<u32x4*>(v_s + 2 * KEYS * PROW + off) = pl;
+        }
+    }
+    __syncthreads();
+
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (!FULL && kt * 32 >= B) break;  // uniform
+        const int key = kt * 32 + li;
+        f32x16 x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = key * PROW + (((2 * s + hh) ^ ((key >> 2) & 3)) * 16);
+            const u32x4 kh = *reinterpret_cast<const u32x4*>(k_s + off);
+            const u32x4 km = *reinterpret_cast<const u32x4*>(k_s + KEYS * PROW + off);
+            const u32x4 kl = *reinterpret_cast<const u32x4*>(k_s + 2 * KEYS * PROW + off);
+            x = mfma_bf16(kl, qh[s], x);
+            x = mfma_bf16(kh, ql[s], x);
+            x = mfma_bf16(km, qm[s], x);
+            x = mfma_bf16(km, qh[s], x);
+            x = mfma_bf16(kh, qm[s], x);
+            x = mfma_bf16(kh, qh[s], x);
+        }
+
+        float pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = fminf(__expf(x[r]), 1.f);
+        if (!FULL && (kt + 1) * 32 > B) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt * 32 + hept_acc_row(r, hh) >= B) pr[r] = 0.f;
+        }
+
+        const int g = lane >> 4, l16 = lane & 15;
+        const int vrow = kt * 32 + 4 * hh + (l16 >> 2);
+        const int vcol = 32 * (g & 1) + 8 * (l16 & 3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float pa[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] = pr[8 * s + j];
+            u32x4 ph, pm, pl3;
+            if constexpr (VP == 3) split3_bf16(pa, ph, pm, pl3);
+            else split2_bf16(pa, ph, pm);
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            u32x4 vpl[VP];
+#pragma unroll
+            for (int pl = 0; pl < VP; ++pl) {
+                const char* vb = v_s + pl * KEYS * PROW;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vb + (vrow + 16 * s) * PROW + vcol));
+                const s16x4 v1 =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vb + (vrow + 16 * s + 8) * PROW + vcol));
+                const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                vpl[pl] = __builtin_bit_cast(u32x4, vv);
+            }
+            if constexpr (VP == 3) {
+                z = mfma_bf16(pl3, vpl[0], z);
+                z = mfma_bf16(ph, vpl[2], z);
+                z = mfma_bf16(pm, vpl[1], z);
+            }
+            z = mfma_bf16(pm, vpl[0], z);
+            z = mfma_bf16(ph, vpl[1], z);
+            z = mfma_bf16(ph, vpl[0], z);
+        }
+    }
+
+    // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
+    float* __restrict__ pt = part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q2 = w * 32 + hept_acc_row(r, hh);
+        const int dst = __shfl(qsrc, hept_acc_row(r, hh));  // lane li holds the source row of query 32 w + li
+        if (FULL || q2 < B) {
+            float val = z[r];
+            if (li == D) val += 1e-20f;  // example/hept.py:14
+            pt[(size_t)dst * H * 32] = val;
+        }
+    }
+}
+
+template <bool FULL, int VP>
+int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, const float* kvhat, const int* qpos,
+                      const int* kpos, float* part, int N, int H, int D, int B, int nb) {
+#define HEPT_SPLIT_CASE(K)                                                                                       \
+    case K: {                                                                                                    \
+        constexpr size_t lds = (size_t)(3 + VP) * 32 * K * 64;                                                   \
+        if (lds > 65536) {                                                                                       \
+            static bool raised = false;                                                                          \
+            if (!raised) {                                                                                       \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_split_kernel<K, FULL, VP>),        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
+                    return HEPT_ERR_LAUNCH;                                                                      \
+                raised = true;                                                                                   \
+            }                                                                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL((block_attn_split_kernel<K, FULL, VP>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,   \
+                           kpos, part, N, H, D, B, nb);                                                          \
+        break;                                                                                                   \
+    }
+    switch (nkt) {
+        HEPT_SPLIT_CASE(1)
+        HEPT_SPLIT_CASE(2)
+        HEPT_SPLIT_CASE(3)
+        HEPT_SPLIT_CASE(4)
+        HEPT_SPLIT_CASE(5)
+        HEPT_SPLIT_CASE(6)
+        HEPT_SPLIT_CASE(7)
+        HEPT_SPLIT_CASE(8)
+        default:
+            return HEPT_ERR_SHAPE;
+    }
+#undef HEPT_SPLIT_CASE
+    return hept_launch_status();
+}
+
 template <bool BF16, bool P16, bool F16QK, bool FULL>
 int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
                 const int* kpos, float* part, int N, int H, int D, int B, int nb) {
@@ -285,7 +518,13 @@ extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_
         return launch_attn<true, true, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
     if (precision == HEPT_PREC_MIXED16)
         return launch_attn<true, false, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
-    if (precision == HEPT_PREC_F32)
+    if (precision == HEPT_PREC_F32) {
+        const float* qf = (const float*)qhat;
+        const float* kf = (const float*)kvhat;
+        if (B == 32 * nkt) return launch_attn_split<true, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb);
+        return launch_attn_split<false, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb);
+    }
+    if (precision == HEPT_PREC_F32_MFMA)
         return launch_attn<false, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
     return HEPT_ERR_SHAPE;
 }

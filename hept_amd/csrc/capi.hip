@@ -20,7 +20,7 @@ struct Workspace {
 };
 
 Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
-    const size_t esz = precision == HEPT_PREC_F32 ? 4 : 2;
+    const size_t esz = (precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA) ? 4 : 2;
     char* p = reinterpret_cast<char*>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -100,7 +100,7 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 extern "C" int hept_abi_version(void) { return 7; }
 
 extern "C" int hept_part_precision(int precision, int D) {
-    return (precision != HEPT_PREC_F32 && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
+    return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
 }
 
 extern "C" int hept_check_shape(int N, int H, int D, int C, int Tl, int B) {

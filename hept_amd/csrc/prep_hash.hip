@@ -414,6 +414,7 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
     if (!q || !k || !v || !coords || !sqrt_w || !alpha || !qhat || !kvhat || !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
     if (H != 8 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (precision == HEPT_PREC_F32_MFMA) precision = HEPT_PREC_F32;  // same f32 tile rows, another block_attn kernel
     if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16 && precision != HEPT_PREC_MIXED16)
         return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -441,6 +442,7 @@ extern "C" int hept_prep_hash_fused(const float* x, const float* norm_w, const f
         !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
     if (H != 8 || D != 24 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (precision == HEPT_PREC_F32_MFMA) precision = HEPT_PREC_F32;  // same f32 tile rows, another block_attn kernel
     if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16 && precision != HEPT_PREC_MIXED16)
         return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;

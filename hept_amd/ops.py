@@ -11,7 +11,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_F32, PREC_MIXED16
+from ._lib import PREC_BF16, PREC_F32, PREC_F32_MFMA, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
@@ -22,15 +22,17 @@ __all__ = [
 
 
 def precision_code(precision) -> int:
-    if isinstance(precision, int) and not isinstance(precision, bool) and precision in (PREC_F32, PREC_BF16, PREC_MIXED16):
+    if isinstance(precision, int) and not isinstance(precision, bool) and precision in (PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA):
         return precision
     if precision == "mixed16":
         return PREC_MIXED16
     if precision in ("fp32", "f32") or precision is torch.float32:
         return PREC_F32
+    if precision == "fp32_mfma":
+        return PREC_F32_MFMA
     if precision == "bf16" or precision is torch.bfloat16:
         return PREC_BF16
-    raise ValueError(f"precision must be 'fp32', 'bf16' or 'mixed16', got {precision!r}")
+    raise ValueError(f"precision must be 'fp32', 'bf16', 'mixed16' or 'fp32_mfma', got {precision!r}")
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -83,7 +85,8 @@ def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int =
     tl = t - t0 if tl is None else tl
     prec = precision_code(precision)
     # dtype tag of the row buffers: bf16 / f16 (mixed16: q^,k^ halves are fp16, the v half of kvhat is bf16) / f32
-    tile = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16}[prec]
+    tile = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16,
+            PREC_F32_MFMA: torch.float32}[prec]
     dev = q.device
     qhat = torch.empty(h, n, 32, device=dev, dtype=tile)
     kvhat = torch.empty(h, n, 64, device=dev, dtype=tile)
@@ -151,13 +154,16 @@ def segmented_argsort(keys: torch.Tensor, lens: Optional[torch.Tensor] = None) -
     return pos
 
 
-def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int) -> torch.Tensor:
+def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int, f32_mfma: bool = False) -> torch.Tensor:
     """Per-table partial rows (Tl, N, H, row).  fp32 tiles: row = 32 f32 (numer in [:D], denom (+1e-20) at [D]);
-    bf16 tiles with D == 24: packed row = 16 int32 dwords (24 bf16 numer | f32 denom | 0); see ``unpack_part``."""
+    bf16 tiles with D == 24: packed row = 16 int32 dwords (24 bf16 numer | f32 denom | 0); see ``unpack_part``.
+    ``f32_mfma`` runs f32 tiles on the native f32 MFMA instead of the split-bf16 products."""
     lib = _lib.load()
     h, n, _ = qhat.shape
     tl = qpos.shape[0]
     prec = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16, torch.float16: PREC_MIXED16}[qhat.dtype]
+    if f32_mfma and prec == PREC_F32:
+        prec = PREC_F32_MFMA
     packed = lib.hept_part_precision(prec, head_dim) == PREC_BF16
     qpos = qpos.to(torch.int32).contiguous()
     kpos = kpos.to(torch.int32).contiguous()
@@ -408,7 +414,8 @@ def prep_hash_fused(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha
     raw_size = n if raw_size is None else int(raw_size)
     tl = t - t0 if tl is None else tl
     prec = precision_code(precision)
-    dt = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16}[prec]
+    dt = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16,
+            PREC_F32_MFMA: torch.float32}[prec]
     dev = x.device
     qhat = torch.empty(h, n, 32, device=dev, dtype=dt)
     kvhat = torch.empty(h, n, 64, device=dev, dtype=dt)

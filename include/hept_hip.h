@@ -48,10 +48,15 @@ extern "C" {
 #define HEPT_ERR_LAUNCH 2  /* HIP reported a launch error */
 #define HEPT_ERR_ARG 3     /* null pointer / workspace too small */
 
-#define HEPT_PREC_F32 0      /* f32 tiles, f32 MFMA: the reference's numerics */
+#define HEPT_PREC_F32 0      /* f32 tiles: the reference's numerics.  The tile products run on the bf16 matrix pipe
+                                with every f32 factor split into bf16 pieces (6 products for the logits, 3 for
+                                P.V), which reproduces the f32 products to f32 accuracy at ~1/3 of the cycles */
 #define HEPT_PREC_BF16 1     /* bf16 tiles (q^, k^, v, weights P), bf16 MFMA, packed bf16 partial numerators */
 #define HEPT_PREC_MIXED16 2  /* as BF16 but q^/k^ tiles in fp16 (11-bit significand protects the logit
                                 q.k - |q|^2/2 - |k|^2/2; values are clamped to +-65504); P, v stay bf16 */
+
+#define HEPT_PREC_F32_MFMA 3 /* f32 tiles on v_mfma_f32_32x32x2_f32 (the exact f32 fma chain); same storage and row
+                                formats as HEPT_PREC_F32, ~2x slower -- kept as the in-library ground truth */
 
 #define HEPT_ROW 32          /* padded row width (elements) of qhat / k / v / part rows */
 #define HEPT_MAX_TABLES 8    /* tables per call */

@@ -298,3 +298,25 @@ def test_random_shapes_against_the_oracle(gpu_device):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, os.path.join(root, "tests", "op_stress.py"), "18"], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_split_bf16_products_match_the_f32_mfma_kernel(name, gpu_device):
+    """precision="fp32" runs the tile products as split-bf16 MFMAs (6 bf16 products per f32 product); the native
+    v_mfma_f32_32x32x2_f32 kernel (precision="fp32_mfma") is the in-library ground truth for it: same permutations,
+    same f32 rows in, partial rows equal to f32 round-off."""
+    inp, _ = cases.load_case(name)
+    g = _gpu(inp, gpu_device)
+    n, h, d, e, t = _dims(inp)
+    st = _staged(g, inp, "fp32")
+    ref = ops.block_attn(st["qhat"], st["kvhat"], st["qpos"], st["kpos"], d, inp["block_size"], f32_mfma=True)
+    got = st["part"]
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    err = (got - ref).abs()
+    tol = ATOL.get(name, 1e-5) + 1e-4 * ref.abs()
+    assert float((err <= tol).float().mean()) >= 0.995
+    assert float((got[..., d + 1:]).abs().max()) == 0.0
+    # the whole operator through the other kernel: both f32 modes agree on >= 99.5 % of rows
+    a = _forward(g, inp, "fp32").cpu()
+    b = _forward(g, inp, "fp32_mfma").cpu()
+    assert _rows_ok(a, b, ATOL.get(name, 1e-5), 1e-4) >= 0.995
