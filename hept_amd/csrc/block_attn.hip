@@ -32,7 +32,6 @@
 
 namespace {
 
-typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 // Register budget: a workgroup lives ~10 us, most of it waiting for its gathered rows, so throughput is set by how
 // many workgroups a CU holds.  16-bit tiles: 8 waves per SIMD (<= 64 VGPRs, no spills; 87 -> 80 us at tracking-60k);
@@ -235,31 +234,6 @@ void block_attn_kernel(const char* __restrict__ qhat,
 // Q^ rows once into registers, P in registers after the exp.  The norms -|q|^2/2, -|k|^2/2 ride in the product
 // through the two spare columns (30, 31) against a 1.0 on the other side.
 // Inputs, outputs and the (t, block, head) -> workgroup map are those of the f32-tile kernel.
-__device__ __forceinline__ void split3_bf16(const float (&a)[8], u32x4& h, u32x4& m, u32x4& l) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned int hp = hept_pack_bf16(a[2 * j], a[2 * j + 1]);
-        const float r0 = a[2 * j] - hept_bf16_lo(hp), r1 = a[2 * j + 1] - hept_bf16_hi(hp);
-        const unsigned int mp = hept_pack_bf16(r0, r1);
-        const float s0 = r0 - hept_bf16_lo(mp), s1 = r1 - hept_bf16_hi(mp);
-        h[j] = hp;
-        m[j] = mp;
-        l[j] = hept_pack_bf16(s0, s1);
-    }
-}
-__device__ __forceinline__ void split2_bf16(const float (&a)[8], u32x4& h, u32x4& m) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned int hp = hept_pack_bf16(a[2 * j], a[2 * j + 1]);
-        h[j] = hp;
-        m[j] = hept_pack_bf16(a[2 * j] - hept_bf16_lo(hp), a[2 * j + 1] - hept_bf16_hi(hp));
-    }
-}
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                   0, 0);
-}
-
 template <int NKT, bool FULL, int VP>
 __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float* __restrict__ qhat,
                                                                     const float* __restrict__ kvhat,

@@ -195,6 +195,259 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same backward on the bf16 matrix pipe (the default; the f32-MFMA kernel above is kept as ground truth).
+//
+// Every f32 factor is split into bf16 pieces (common.h) and each f32 product becomes 6 (or 5) bf16 MFMAs with f32
+// accumulation -- 74 bf16 MFMAs of 8 passes per 32x32 tile pair instead of 112 f32 MFMAs of 16 passes.  Which
+// products need all the pieces: the logits X (exponentiated), dP = G.V^T (dnumer.v + dden cancels where the
+// block's values agree with the output) and the sums dS.K^, dS.Q^ (they cancel against rowsum(dS).q^: the row sum
+// rides through the same MFMAs against a 1.0 column, so the error of the two-piece dS is common to both terms
+// and only the three-piece K^/Q^ matter).  One workgroup, 6 planes of LDS (48 KB at B = 128), two phases:
+//   stage K^ | V planes, own Q^ / G rows in registers         -> phase Q (d q^)
+//   own K^ / V rows from LDS to registers, then the waves write their Q^ / G rows over the planes -> phase K
+// Column 30 / 31 bookkeeping: q^ rows carry (-|q|^2/2, 1), k^ rows carry (1, -|k|^2/2) there, so the logit needs no
+// separate norm terms; rowsum(dS) comes out in column 30 of dS.K^ and in column 31 of dS^T.Q^.
+constexpr int BPROW = 64;  // bytes of one 32-column bf16 plane row
+__device__ __forceinline__ int plane_chunk(int row, int c) { return row * BPROW + ((c ^ ((row >> 2) & 3)) << 4); }
+
+// LDS addresses are lane-dependent bases (computed once) plus compile-time offsets: tile bases are multiples of 16
+// rows, so the swizzle term (row >> 2) & 3 of a fragment row depends on the lane and on "+8 rows" only.
+struct PlaneLanes {
+    int row[2];  // A-operand 16-B chunk of row li, step s:      + tile * 32 * BPROW
+    int tr[2];   // transposed 8-B reads, rows +0..3 / +8..11:   + (tile * 32 + 16 s) * BPROW
+};
+__device__ __forceinline__ PlaneLanes plane_lanes(int lane) {
+    const int li = lane & 31, hh = lane >> 5, l16 = lane & 15, g = lane >> 4;
+    PlaneLanes p;
+    p.row[0] = plane_chunk(li, hh);
+    p.row[1] = plane_chunk(li, 2 + hh);
+    const int r = 4 * hh + (l16 >> 2), colb = 32 * (g & 1) + 8 * (l16 & 3);
+    p.tr[0] = plane_chunk(r, colb >> 4) + (colb & 15);
+    p.tr[1] = plane_chunk(r + 8, colb >> 4) + (colb & 15);
+    return p;
+}
+
+// B-operand fragment (k = the 16 rows starting at byte offset base, n = column li) by transposing reads
+__device__ __forceinline__ u32x4 plane_tr_frag(const char* plane, const PlaneLanes& pl, int base) {
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + base + pl.tr[0]));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + base + pl.tr[1]));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(u32x4, vv);
+}
+
+// x += a.b with a (three planes in LDS, A operand rows) and b (three pieces in registers): the six leading terms
+__device__ __forceinline__ f32x16 mfma6(const char* planes, int plane_bytes, int off, const u32x4 (&b)[3], f32x16 x) {
+    const u32x4 ah = *reinterpret_cast<const u32x4*>(planes + off);
+    const u32x4 am = *reinterpret_cast<const u32x4*>(planes + plane_bytes + off);
+    const u32x4 al = *reinterpret_cast<const u32x4*>(planes + 2 * plane_bytes + off);
+    x = mfma_bf16(al, b[0], x);
+    x = mfma_bf16(ah, b[2], x);
+    x = mfma_bf16(am, b[1], x);
+    x = mfma_bf16(am, b[0], x);
+    x = mfma_bf16(ah, b[1], x);
+    x = mfma_bf16(ah, b[0], x);
+    return x;
+}
+// z += a.b with a (two pieces in registers, accumulator layout) and b (three planes, transposed reads): five terms
+__device__ __forceinline__ f32x16 mfma5_tr(const u32x4& ah, const u32x4& am, const char* planes, int plane_bytes,
+                                           const PlaneLanes& pl, int base, f32x16 z) {
+    const u32x4 bh = plane_tr_frag(planes, pl, base);
+    const u32x4 bm = plane_tr_frag(planes + plane_bytes, pl, base);
+    const u32x4 bl = plane_tr_frag(planes + 2 * plane_bytes, pl, base);
+    z = mfma_bf16(ah, bl, z);
+    z = mfma_bf16(am, bm, z);
+    z = mfma_bf16(am, bh, z);
+    z = mfma_bf16(ah, bm, z);
+    z = mfma_bf16(ah, bh, z);
+    return z;
+}
+
+template <int NKT, bool FULL>
+__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu((NKT <= 4 && FULL) ? 3 : 2, (NKT <= 4 && FULL) ? 3 : 2)))
+void block_attn_bwd_split_kernel(
+    const float* __restrict__ qhat, const float* __restrict__ kvhat, const int* __restrict__ qpos,
+    const int* __restrict__ kpos, const float* __restrict__ gacc, float* __restrict__ dq_part,
+    float* __restrict__ dkv_part, int N, int H, int D, int B, int nb) {
+    constexpr int NT = 64 * NKT, ROWS = 32 * NKT, PL = ROWS * BPROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_s = smem;           // phase Q: K^ planes (h, m, l)   phase K: Q^ planes
+    char* b_s = smem + 3 * PL;  // phase Q: V  planes             phase K: G  planes
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
+    const int bid = blockIdx.x;
+    const int h = bid % H, rest = bid / H, b = rest % nb, t = rest / nb;
+    const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
+    const int* __restrict__ qp = qpos + seg;
+    const int* __restrict__ kp = kpos + seg;
+    const float* __restrict__ qbase = qhat + (size_t)h * N * 32;
+    const float* __restrict__ kvbase = kvhat + (size_t)h * N * 64;
+
+    const int own = w * 32 + li;  // the query (phase Q) / key (phase K) of this lane
+    const bool own_ok = FULL || own < B;
+    const int qsrc = qp[own_ok ? own : 0], ksrc = kp[own_ok ? own : 0];
+    const PlaneLanes pl = plane_lanes(lane);
+
+    // ---- own Q^ and G rows -> bf16 pieces in registers (B-operand layout: step s, half hh = columns 16 s + 8 hh ..)
+    u32x4 q3[2][3], g3[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (own_ok) {
+            const float* qrow = qbase + (size_t)qsrc * 32 + 16 * s + 8 * hh;
+            const float* grow = gacc + ((size_t)qsrc * H + h) * 32 + 16 * s + 8 * hh;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(qrow), a1 = *reinterpret_cast<const f32x4*>(qrow + 4);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(grow), g1 = *reinterpret_cast<const f32x4*>(grow + 4);
+            a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+            gg[0] = g0[0]; gg[1] = g0[1]; gg[2] = g0[2]; gg[3] = g0[3];
+            gg[4] = g1[0]; gg[5] = g1[1]; gg[6] = g1[2]; gg[7] = g1[3];
+            if (s == 1 && hh == 1) {  // columns (30, 31) = (-|q|^2/2, 1)
+                a[6] = a[7];
+                a[7] = 1.f;
+            }
+        }
+        split3_bf16(a, q3[s][0], q3[s][1], q3[s][2]);
+        split3_bf16(gg, g3[s][0], g3[s][1], g3[s][2]);
+    }
+
+    // ---- stage K^ and V planes: one item = 8 consecutive columns of a gathered kvhat row
+    for (int ci = tid; ci < ROWS * 8; ci += NT) {
+        const int key = ci >> 3, c = ci & 7;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (FULL || key < B) {
+            const float* src = kvbase + (size_t)kp[key] * 64 + c * 8;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+            a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+            if (c == 3) a[6] = 1.f;  // columns (30, 31) = (1, -|k|^2/2)
+        }
+        u32x4 ph, pm, pl;
+        split3_bf16(a, ph, pm, pl);
+        char* dst = (c < 4 ? a_s : b_s) + plane_chunk(key, c & 3);
+        *reinterpret_cast<u32x4*>(dst) = ph;
+        *reinterpret_cast<u32x4*>(dst + PL) = pm;
+        *reinterpret_cast<u32x4*>(dst + 2 * PL) = pl;
+    }
+    __syncthreads();
+
+    // =========================== phase Q: d q^ ===========================
+    {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (!FULL && kt * 32 >= B) break;
+            f32x16 x, y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[r] = 0.f; y[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = kt * 32 * BPROW + pl.row[s];
+                x = mfma6(a_s, PL, off, q3[s], x);  // X^T = K^ . Q^T (+ both norms)
+                y = mfma6(b_s, PL, off, g3[s], y);  // Y^T = V . G^T
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ds[r] = x[r] <= 0.f ? __expf(x[r]) * y[r] : 0.f;  // exp(x) <= 1 wherever the clamp passes the gradient
+                if (!FULL && (kt * 32 + hept_acc_row(r, hh) >= B || !own_ok)) ds[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float pa[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pa[j] = ds[8 * s + j];
+                u32x4 dh, dm;
+                split2_bf16(pa, dh, dm);
+                z = mfma5_tr(dh, dm, a_s, PL, pl, (kt * 32 + 16 * s) * BPROW, z);  // Z += dS . K^ ; column 30 = rowsum(dS)
+            }
+        }
+        // d q^_i = sum_j dS_ij k^_j - (sum_j dS_ij) q^_i ;  lane = column, registers = queries
+        float* __restrict__ dst = dq_part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q2 = w * 32 + hept_acc_row(r, hh);
+            const int src = __shfl(qsrc, hept_acc_row(r, hh));
+            const float rs = __shfl(z[r], 30 + 32 * hh);
+            if (FULL || q2 < B) dst[(size_t)src * H * 32] = li < 30 ? z[r] - rs * qbase[(size_t)src * 32 + li] : 0.f;
+        }
+    }
+
+    // ---- own K^ / V rows: LDS -> registers; then the planes are re-used for Q^ / G
+    u32x4 k3[2][3], v3[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int off = w * 32 * BPROW + pl.row[s];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            k3[s][pc] = *reinterpret_cast<const u32x4*>(a_s + pc * PL + off);
+            v3[s][pc] = *reinterpret_cast<const u32x4*>(b_s + pc * PL + off);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int off = w * 32 * BPROW + pl.row[s];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            *reinterpret_cast<u32x4*>(a_s + pc * PL + off) = q3[s][pc];
+            *reinterpret_cast<u32x4*>(b_s + pc * PL + off) = g3[s][pc];
+        }
+    }
+    __syncthreads();
+
+    // =========================== phase K: d k^, d v ===========================
+    {
+        f32x16 zk, zv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { zk[r] = 0.f; zv[r] = 0.f; }
+#pragma unroll
+        for (int qt = 0; qt < NKT; ++qt) {
+            if (!FULL && qt * 32 >= B) break;
+            f32x16 x, y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[r] = 0.f; y[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = qt * 32 * BPROW + pl.row[s];
+                x = mfma6(a_s, PL, off, k3[s], x);  // X = Q^ . K^T (+ both norms)
+                y = mfma6(b_s, PL, off, v3[s], y);  // Y = G . V^T
+            }
+            float pr[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pr[r] = fminf(__expf(x[r]), 1.f);
+                if (!FULL && (qt * 32 + hept_acc_row(r, hh) >= B || !own_ok)) pr[r] = 0.f;
+                ds[r] = x[r] <= 0.f ? pr[r] * y[r] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float pa[8], da[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { pa[j] = pr[8 * s + j]; da[j] = ds[8 * s + j]; }
+                u32x4 ph, pm, dh, dm;
+                split2_bf16(pa, ph, pm);
+                split2_bf16(da, dh, dm);
+                zk = mfma5_tr(dh, dm, a_s, PL, pl, (qt * 32 + 16 * s) * BPROW, zk);  // ZK += dS^T . Q^ ; column 31 = colsum(dS)
+                zv = mfma5_tr(ph, pm, b_s, PL, pl, (qt * 32 + 16 * s) * BPROW, zv);  // ZV += P^T . G
+            }
+        }
+        float* __restrict__ dst = dkv_part + (size_t)t * N * H * 64 + (size_t)h * 64 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k2 = w * 32 + hept_acc_row(r, hh);
+            const int src = __shfl(ksrc, hept_acc_row(r, hh));
+            const float rs = __shfl(zk[r], 31 + 32 * hh);
+            if (FULL || k2 < B) {
+                float* row = dst + (size_t)src * H * 64;
+                row[0] = li < 30 ? zk[r] - rs * kvbase[(size_t)src * 64 + li] : 0.f;
+                row[32] = li < D ? zv[r] : 0.f;
+            }
+        }
+    }
+}
+
 // sum the per-table partial rows and undo the augmentation:
 //   dq,dk,dv (N, H*D);  dcs (N, H, C) = gradient of the scaled coordinates sqrt_w[h,c]*coords[n,c] (q^ and k^ share them)
 __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict__ dq_part,
@@ -255,19 +508,69 @@ int launch_bwd(int nkt, dim3 grid, hipStream_t st, const float* qhat, const floa
     return hept_launch_status();
 }
 
-}  // namespace
+template <bool FULL>
+int launch_bwd_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, const float* kvhat, const int* qpos,
+                     const int* kpos, const float* gacc, float* dq_part, float* dkv_part, int N, int H, int D, int B,
+                     int nb) {
+#define HEPT_BWDS_CASE(K)                                                                                        \
+    case K: {                                                                                                    \
+        constexpr size_t lds = (size_t)6 * 32 * K * BPROW;                                                       \
+        static bool raised = false;                                                                              \
+        if (lds > 65536 && !raised) {                                                                            \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_bwd_split_kernel<K, FULL>),        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)         \
+                return HEPT_ERR_LAUNCH;                                                                          \
+            raised = true;                                                                                       \
+        }                                                                                                        \
+        hipLaunchKernelGGL((block_attn_bwd_split_kernel<K, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat,     \
+                           qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);                                 \
+        break;                                                                                                   \
+    }
+    switch (nkt) {
+        HEPT_BWDS_CASE(1)
+        HEPT_BWDS_CASE(2)
+        HEPT_BWDS_CASE(3)
+        HEPT_BWDS_CASE(4)
+        HEPT_BWDS_CASE(5)
+        HEPT_BWDS_CASE(6)
+        HEPT_BWDS_CASE(7)
+        HEPT_BWDS_CASE(8)
+        default:
+            return HEPT_ERR_SHAPE;
+    }
+#undef HEPT_BWDS_CASE
+    return hept_launch_status();
+}
 
-extern "C" int hept_block_attn_bwd(const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
-                                   const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part,
-                                   float* dkv_part, void* stream) {
+int block_attn_bwd_impl(bool split, const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
+                        const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part, float* dkv_part,
+                        void* stream) {
     if (!qhat || !kvhat || !qpos || !kpos || !gacc || !dq_part || !dkv_part) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
         return HEPT_ERR_SHAPE;
     const int nb = N / B, nkt = (B + 31) / 32;
     const dim3 grid((unsigned)((size_t)Tl * nb * H));
     hipStream_t st = (hipStream_t)stream;
-    if (B == 32 * nkt) return launch_bwd<true>(nkt, grid, st, qhat, kvhat, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);
-    return launch_bwd<false>(nkt, grid, st, qhat, kvhat, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);
+    const bool full = B == 32 * nkt;
+    if (split)
+        return full ? launch_bwd_split<true>(nkt, grid, st, qhat, kvhat, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb)
+                    : launch_bwd_split<false>(nkt, grid, st, qhat, kvhat, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);
+    return full ? launch_bwd<true>(nkt, grid, st, qhat, kvhat, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb)
+                : launch_bwd<false>(nkt, grid, st, qhat, kvhat, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);
+}
+
+}  // namespace
+
+extern "C" int hept_block_attn_bwd(const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
+                                   const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part,
+                                   float* dkv_part, void* stream) {
+    return block_attn_bwd_impl(true, qhat, kvhat, qpos, kpos, gacc, N, H, D, Tl, B, dq_part, dkv_part, stream);
+}
+
+extern "C" int hept_block_attn_bwd_f32mfma(const float* qhat, const float* kvhat, const int32_t* qpos,
+                                           const int32_t* kpos, const float* gacc, int N, int H, int D, int Tl, int B,
+                                           float* dq_part, float* dkv_part, void* stream) {
+    return block_attn_bwd_impl(false, qhat, kvhat, qpos, kpos, gacc, N, H, D, Tl, B, dq_part, dkv_part, stream);
 }
 
 extern "C" int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,

@@ -41,3 +41,31 @@ __device__ __forceinline__ float hept_f16_hi(unsigned int w) { return (float)__b
 // Row of the 32x32 MFMA accumulator held in register r by lane-half hh
 // (C/D layout of v_mfma_f32_32x32x*: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
 __device__ __forceinline__ int hept_acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// ---- f32 products on the bf16 matrix pipe (block_attn.hip, block_attn_bwd.hip) ------------------------------------
+// a = ah + am + al with ah = bf16(a), am = bf16(a - ah), al = bf16(a - ah - am); every residual is exact in f32.
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+__device__ __forceinline__ void split3_bf16(const float (&a)[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int hp = hept_pack_bf16(a[2 * j], a[2 * j + 1]);
+        const float r0 = a[2 * j] - hept_bf16_lo(hp), r1 = a[2 * j + 1] - hept_bf16_hi(hp);
+        const unsigned int mp = hept_pack_bf16(r0, r1);
+        const float s0 = r0 - hept_bf16_lo(mp), s1 = r1 - hept_bf16_hi(mp);
+        h[j] = hp;
+        m[j] = mp;
+        l[j] = hept_pack_bf16(s0, s1);
+    }
+}
+__device__ __forceinline__ void split2_bf16(const float (&a)[8], u32x4& h, u32x4& m) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int hp = hept_pack_bf16(a[2 * j], a[2 * j + 1]);
+        h[j] = hp;
+        m[j] = hept_pack_bf16(a[2 * j] - hept_bf16_lo(hp), a[2 * j + 1] - hept_bf16_hi(hp));
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+}

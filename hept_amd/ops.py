@@ -220,9 +220,11 @@ def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int
     return out
 
 
-def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int, block_size: int):
+def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int, block_size: int,
+                   f32_mfma: bool = False):
     """Backward of block_attn + reduce_tables for f32 tiles: gradient rows gacc (N,H,32) -> dq, dk, dv (N, H*D)
-    and dcs (N, H, C), the gradient of the scaled coordinates shared by q^ and k^."""
+    and dcs (N, H, C), the gradient of the scaled coordinates shared by q^ and k^.  ``f32_mfma`` selects the
+    native f32 MFMA kernel instead of the split-bf16 products."""
     lib = _lib.load()
     if qhat.dtype != torch.float32:
         raise TypeError("the backward pass needs f32 tiles (precision='fp32')")
@@ -233,9 +235,9 @@ def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int
     dq_part = torch.empty(tl, n, h, 32, device=dev, dtype=torch.float32)
     dkv_part = torch.empty(tl, n, h, 64, device=dev, dtype=torch.float32)
     st = _stream(qhat)
-    _lib.check(lib.hept_block_attn_bwd(qhat.data_ptr(), kvhat.data_ptr(), qpos.data_ptr(), kpos.data_ptr(),
-                                       gacc.data_ptr(), n, h, head_dim, tl, block_size, dq_part.data_ptr(),
-                                       dkv_part.data_ptr(), st), "hept_block_attn_bwd")
+    fn = lib.hept_block_attn_bwd_f32mfma if f32_mfma else lib.hept_block_attn_bwd
+    _lib.check(fn(qhat.data_ptr(), kvhat.data_ptr(), qpos.data_ptr(), kpos.data_ptr(), gacc.data_ptr(), n, h, head_dim,
+                  tl, block_size, dq_part.data_ptr(), dkv_part.data_ptr(), st), "hept_block_attn_bwd")
     dq = torch.empty(n, h * head_dim, device=dev, dtype=torch.float32)
     dk, dv = torch.empty_like(dq), torch.empty_like(dq)
     dcs = torch.empty(n, h, coords_dim, device=dev, dtype=torch.float32)

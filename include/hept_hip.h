@@ -207,7 +207,8 @@ int hept_attn_block_forward(const float* x, const float* coords, const int64_t* 
                             int precision, void* workspace, size_t workspace_bytes, float* y, void* stream);
 
 /* SURVEY.md §8 f-2 — backward of the block attention (the reference trains through example/hept.py:55-80 with
- * plain autograd; there is no custom backward to mirror).  f32 tiles only.  gacc (N, H, 32) f32 is the
+ * plain autograd; there is no custom backward to mirror).  f32 tiles only; the tile products run as split-bf16
+ * MFMAs (6 or 5 bf16 products per f32 product, see HEPT_PREC_F32).  gacc (N, H, 32) f32 is the
  * gradient of the table-summed partial rows [d numer | d den | 0]; qhat/kvhat/qpos/kpos are the forward's.
  * dq_part (Tl, N, H, 32) receives d q^ rows, dkv_part (Tl, N, H, 64) receives [d k^ | d v] rows (point order,
  * one row per table).  hept_bwd_reduce sums the tables and undoes the augmentation: dq, dk, dv (N, H*D) and
@@ -215,6 +216,11 @@ int hept_attn_block_forward(const float* x, const float* coords, const int64_t* 
 int hept_block_attn_bwd(const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
                         const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part,
                         float* dkv_part, void* stream);
+/* the same on v_mfma_f32_32x32x2_f32 (exact f32 fma chains, ~2.5x slower): the in-library ground truth of the
+ * split-bf16 kernel behind hept_block_attn_bwd */
+int hept_block_attn_bwd_f32mfma(const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
+                                const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part,
+                                float* dkv_part, void* stream);
 int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
                     float* dq, float* dk, float* dv, float* dcs, void* stream);
 /* backward of hept_combine_out on table-summed f32 rows acc (N, H, 32) (example/hept.py:79-80 under autograd):

@@ -125,3 +125,27 @@ def test_combine_backward_kernel_vs_autograd(gpu_device):
     assert float(acc_t.grad[..., d + 1:].abs().max()) == 0.0
     assert _close(w_t.grad.cpu(), w_r.grad.cpu(), rel=1e-4)   # summed with atomics: order-dependent round-off
     assert _close(b_t.grad.cpu(), b_r.grad.cpu(), rel=1e-5)
+
+
+@pytest.mark.parametrize("name", ["g1_rand512", "g6_block100", "g4_pileup", "g3_ckpt6k"])
+def test_split_backward_matches_the_f32_mfma_kernel(name, gpu_device):
+    """hept_block_attn_bwd runs its tile products as split-bf16 MFMAs; hept_block_attn_bwd_f32mfma (native f32 MFMA)
+    is the in-library ground truth: same inputs, gradients equal to f32 round-off relative to their scale."""
+    inp, _ = cases.load_case(name)
+    dev = gpu_device
+    g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+    h, e, t = inp["alpha"].shape
+    d, c, b = 24, inp["coords"].shape[1], inp["block_size"]
+    sw = ops.rpe_scale(g["w_rpe_weight"], h, d, inp["w_per_dist"])
+    ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw, g["alpha"], g["combined_shifts"], "fp32")
+    qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], g["combined_shifts"], ph["minmax"])
+    part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, b)
+    acc = ops.reduce_tables(part, d).requires_grad_(True)
+    out = torch.nn.functional.linear((acc[..., :d] / acc[..., d:d + 1]).reshape(-1, h * d), g["out_weight"], g["out_bias"])
+    out.backward(torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev))
+    got = ops.block_attn_bwd(ph["qhat"], ph["kvhat"], qpos, kpos, acc.grad, d, c, b)
+    ref = ops.block_attn_bwd(ph["qhat"], ph["kvhat"], qpos, kpos, acc.grad, d, c, b, f32_mfma=True)
+    # g3 (trained checkpoint): logits of order 1e3 make exp() amplify the last f32 bit of either kernel
+    rel = 5e-4 if name == "g3_ckpt6k" else 1e-4
+    for a, r in zip(got, ref):
+        assert _close(a, r, rel=rel)
