@@ -314,17 +314,18 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     f32x16 z;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    // lane part of the K^ chunk addresses (tile bases are multiples of 32 rows: the swizzle term is the lane's)
+    const int krow[2] = {li * PROW + ((hh ^ ((li >> 2) & 3)) * 16), li * PROW + (((2 + hh) ^ ((li >> 2) & 3)) * 16)};
 
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         if (!FULL && kt * 32 >= B) break;  // uniform
-        const int key = kt * 32 + li;
         f32x16 x;
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int off = key * PROW + (((2 * s + hh) ^ ((key >> 2) & 3)) * 16);
+            const int off = kt * 32 * PROW + krow[s];
             const u32x4 kh = *reinterpret_cast<const u32x4*>(k_s + off);
             const u32x4 km = *reinterpret_cast<const u32x4*>(k_s + KEYS * PROW + off);
             const u32x4 kl = *reinterpret_cast<const u32x4*>(k_s + 2 * KEYS * PROW + off);

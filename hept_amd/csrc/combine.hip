@@ -403,30 +403,61 @@ __global__ __launch_bounds__(256) void combine_bwd_rows_kernel(const float* __re
 }
 
 constexpr int CBW_POINTS = 128;  // points per workgroup of the weight-gradient kernel
-__global__ __launch_bounds__(192) void combine_bwd_weight_kernel(const float* __restrict__ acc,
-                                                                 const float* __restrict__ g_out, int N, int H,
-                                                                 float* __restrict__ d_weight,
-                                                                 float* __restrict__ d_bias) {
-    const int col = threadIdx.x;            // h * D + j
+constexpr int CBW_GROUPS = 4;    // thread groups of H*D = 192 columns that share a workgroup's points
+// d_weight[c][h*D+j] = sum_n g_out[n][c] * numer[n][h][j] / denom[n][h]: thread = column (h, j) of one group, the
+// groups take every CBW_GROUPS-th point (4 points in flight per thread: the loop is bound by load latency, not by
+// its 24 fma per point), fold through LDS, and one group adds the workgroup's sums to the output with atomics.
+__global__ __launch_bounds__(192 * CBW_GROUPS) void combine_bwd_weight_kernel(const float* __restrict__ acc,
+                                                                              const float* __restrict__ g_out, int N,
+                                                                              int H, float* __restrict__ d_weight,
+                                                                              float* __restrict__ d_bias) {
+    __shared__ float red_s[CBW_GROUPS - 1][CB_D + 1][192];
+    const int col = threadIdx.x % 192, grp = threadIdx.x / 192;  // col = h * D + j; 192 = 3 waves, so grp is wave-uniform
     const int HD = H * CB_D;
-    if (col >= HD) return;
-    const int h = col / CB_D, j = col % CB_D;
+    const bool live = col < HD;
+    const int h = live ? col / CB_D : 0, j = col % CB_D;
     const int n_begin = blockIdx.x * CBW_POINTS, n_end = min(N, n_begin + CBW_POINTS);
     float s[CB_D];
 #pragma unroll
     for (int c = 0; c < CB_D; ++c) s[c] = 0.f;
     float sb = 0.f;  // lanes < D also sum g_out[:, lane] for the bias gradient
-    for (int n = n_begin; n < n_end; ++n) {
-        const float* arow = acc + ((size_t)n * H + h) * 32;
-        const float ph = arow[j] / arow[CB_D];
-        const float* gr = g_out + (size_t)n * CB_D;  // uniform across the workgroup: scalar loads
+    constexpr int UN = 4;
+    for (int n0 = n_begin + grp; n0 < n_end; n0 += CBW_GROUPS * UN) {
+        float ph[UN];
 #pragma unroll
-        for (int c = 0; c < CB_D; ++c) s[c] = fmaf(gr[c], ph, s[c]);
-        if (col < CB_D) sb += gr[col];
+        for (int u = 0; u < UN; ++u) {
+            const int n = n0 + u * CBW_GROUPS;
+            const float* arow = acc + ((size_t)(n < n_end ? n : n_begin) * H + h) * 32;
+            ph[u] = n < n_end ? arow[j] / arow[CB_D] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int n = n0 + u * CBW_GROUPS;
+            if (n < n_end) {                                 // wave-uniform
+                const float* gr = g_out + (size_t)n * CB_D;  // uniform across the wave: scalar loads
+#pragma unroll
+                for (int c = 0; c < CB_D; ++c) s[c] = fmaf(gr[c], ph[u], s[c]);
+                if (col < CB_D) sb += gr[col];
+            }
+        }
     }
+    if (grp > 0) {
 #pragma unroll
-    for (int c = 0; c < CB_D; ++c) atomicAdd(d_weight + (size_t)c * HD + col, s[c]);
-    if (col < CB_D && d_bias) atomicAdd(d_bias + col, sb);
+        for (int c = 0; c < CB_D; ++c) red_s[grp - 1][c][col] = s[c];
+        red_s[grp - 1][CB_D][col] = sb;
+    }
+    __syncthreads();
+    if (grp == 0 && live) {
+#pragma unroll
+        for (int g2 = 0; g2 < CBW_GROUPS - 1; ++g2) {
+#pragma unroll
+            for (int c = 0; c < CB_D; ++c) s[c] += red_s[g2][c][col];
+            sb += red_s[g2][CB_D][col];
+        }
+#pragma unroll
+        for (int c = 0; c < CB_D; ++c) atomicAdd(d_weight + (size_t)c * HD + col, s[c]);
+        if (col < CB_D && d_bias) atomicAdd(d_bias + col, sb);
+    }
 }
 
 }  // namespace
@@ -525,7 +556,7 @@ extern "C" int hept_combine_bwd(const float* acc, const float* g_out, const floa
     const size_t blocks = (n_rows + 255) / 256;
     hipLaunchKernelGGL(combine_bwd_rows_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, acc,
                        g_out, out_weight, N, H, gacc);
-    hipLaunchKernelGGL(combine_bwd_weight_kernel, dim3((N + CBW_POINTS - 1) / CBW_POINTS), dim3(192), 0, st, acc, g_out, N,
+    hipLaunchKernelGGL(combine_bwd_weight_kernel, dim3((N + CBW_POINTS - 1) / CBW_POINTS), dim3(192 * CBW_GROUPS), 0, st, acc, g_out, N,
                        H, d_weight, d_bias);
     return hept_launch_status();
 }
