@@ -220,7 +220,8 @@ def main():
         else:
             ach = algorithmic_flops(n, H, D, C, tables_per_gpu, B) / (attn_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF}
-        roof["kernel"] = "block_attn_kernel"
+        # f32 tiles run as split-bf16 products (6 bf16 MFMAs per f32 product): algorithmic f32 flops against the f32 peak
+        roof["kernel"] = "block_attn_kernel" if args.precision == "bf16" else "block_attn_split_kernel"
         roof["kernel_ms"] = attn_ms
         # what an event pair around NOTHING reads on this stream: the bracket's own cost is inside kernel_ms (the
         # rocprofv3 kernel trace in profiles/ shows the kernel itself shorter by about this much)

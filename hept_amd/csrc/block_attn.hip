@@ -230,8 +230,9 @@ void block_attn_kernel(const char* __restrict__ qhat,
 // slots, 1/16 of the cycles per slot).  Both products use all six terms (VP = 3 planes for V and three pieces of
 // P): measured against the CPU oracle the output error is then that of the f32 MFMA kernel (1.4e-8 vs 2.0e-8 mean
 // on the pileup case); with two pieces for P.V (VP = 2, relative error 2^-17) it is 7x larger.  K^ and V are split
-// once per workgroup while they are staged (3 + VP bf16 planes in LDS, 384 B per key instead of 256), the wave's
-// Q^ rows once into registers, P in registers after the exp.  The norms -|q|^2/2, -|k|^2/2 ride in the product
+// once per workgroup while they are staged (3 + VP bf16 planes in LDS, 384 B per key instead of 256; 64 keys at a
+// time, the next 64 gathered rows wait in registers while the current ones are computed), the wave's Q^ rows once
+// into registers, P in registers after the exp.  The norms -|q|^2/2, -|k|^2/2 ride in the product
 // through the two spare columns (30, 31) against a 1.0 on the other side.
 // Inputs, outputs and the (t, block, head) -> workgroup map are those of the f32-tile kernel.
 template <int NKT, bool FULL, int VP>
@@ -243,10 +244,13 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
                                                                     int B, int nb) {
     constexpr int NT = 64 * NKT;
     constexpr int KEYS = 32 * NKT;
-    constexpr int PROW = 64;  // bytes of one 32-column bf16 plane row
+    constexpr int PROW = 64;                    // bytes of one 32-column bf16 plane row
+    constexpr int CK = NKT >= 2 ? 64 : 32;      // keys staged at a time: 24 KB of planes whatever the block size
+    constexpr int NCH = (KEYS + CK - 1) / CK;   // chunks
+    constexpr int IPT = (CK * 8 + NT - 1) / NT; // 8-column items per thread and chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_s = smem;                         // 3 planes [KEYS][32 bf16], 16-B chunks XOR-swizzled
-    char* v_s = smem + 3 * KEYS * PROW;       // VP planes [KEYS][32 bf16], read transposed
+    char* k_s = smem;                   // 3 planes [CK][32 bf16], 16-B chunks XOR-swizzled
+    char* v_s = smem + 3 * CK * PROW;   // VP planes [CK][32 bf16], read transposed
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int bid = blockIdx.x;
@@ -258,6 +262,51 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     const int* __restrict__ qp = qpos + seg;
     const float* __restrict__ qbase = qhat + (size_t)h * N * 32;
     const float* __restrict__ kvbase = kvhat + (size_t)h * N * 64;
+
+    // ---- gathered kvhat rows of chunk ch -> registers (one item = 8 consecutive columns; c < 4: K^, c >= 4: V).
+    //      The loads of chunk ch + 1 are issued before chunk ch is computed, so their latency hides behind it.
+    float pre[IPT][8];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int it = 0; it < IPT; ++it) {
+            const int ci = it * NT + tid;
+            const int key = ch * CK + (ci >> 3), c = ci & 7;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pre[it][j] = 0.f;
+            if (ci < CK * 8 && key < (FULL ? KEYS : B)) {
+                const float* src = kvbase + (size_t)kp[key] * 64 + c * 8;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
+                pre[it][0] = a0[0]; pre[it][1] = a0[1]; pre[it][2] = a0[2]; pre[it][3] = a0[3];
+                pre[it][4] = a1[0]; pre[it][5] = a1[1]; pre[it][6] = a1[2]; pre[it][7] = a1[3];
+                if (c == 3) pre[it][6] = 1.f;  // k^ columns (30, 31) = (1, -|k|^2/2)
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < IPT; ++it) {
+            const int ci = it * NT + tid;
+            if (ci >= CK * 8) break;
+            const int row = ci >> 3, c = ci & 7;
+            u32x4 ph, pm, pl;
+            if (c < 4) {
+                split3_bf16(pre[it], ph, pm, pl);
+                const int off = row * PROW + ((c ^ ((row >> 2) & 3)) * 16);
+                *reinterpret_cast<u32x4*>(k_s + off) = ph;
+                *reinterpret_cast<u32x4*>(k_s + CK * PROW + off) = pm;
+                *reinterpret_cast<u32x4*>(k_s + 2 * CK * PROW + off) = pl;
+            } else {
+                if constexpr (VP == 3) split3_bf16(pre[it], ph, pm, pl);
+                else split2_bf16(pre[it], ph, pm);
+                const int off = row * PROW + (c - 4) * 16;
+                *reinterpret_cast<u32x4*>(v_s + off) = ph;
+                *reinterpret_cast<u32x4*>(v_s + CK * PROW + off) = pm;
+                if constexpr (VP == 3) *reinterpret_cast<u32x4*>(v_s + 2 * CK * PROW + off) = pl;
+            }
+        }
+    };
+    fetch(0);
 
     // ---- this wave's 32 query rows -> three bf16 planes in registers (B-operand layout: lane-half hh of step s
     //      holds columns 16 s + 8 hh .. + 8)
@@ -278,104 +327,78 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
         split3_bf16(a, qh[s], qm[s], ql[s]);
     }
 
-    // ---- stage K^ (3 planes) and V (2 planes): one item = 8 consecutive columns of a gathered kvhat row
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int ci = it * NT + tid;
-        const int key = ci >> 3, c = ci & 7;  // c < 4: K^ columns 8c..; c >= 4: V columns 8(c-4)..
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (FULL || key < B) {
-            const float* src = kvbase + (size_t)kp[key] * 64 + c * 8;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
-            a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
-            a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
-        }
-        if (c < 4) {
-            if (c == 3 && (FULL || key < B)) a[6] = 1.f;
-            u32x4 ph, pm, pl;
-            split3_bf16(a, ph, pm, pl);
-            const int off = key * PROW + ((c ^ ((key >> 2) & 3)) * 16);
-            *reinterpret_cast<u32x4*>(k_s + off) = ph;
-            *reinterpret_cast<u32x4*>(k_s + KEYS * PROW + off) = pm;
-            *reinterpret_cast<u32x4*>(k_s + 2 * KEYS * PROW + off) = pl;
-        } else {
-            u32x4 ph, pm, pl;
-            if constexpr (VP == 3) split3_bf16(a, ph, pm, pl);
-            else split2_bf16(a, ph, pm);
-            const int off = key * PROW + (c - 4) * 16;
-            *reinterpret_cast<u32x4*>(v_s + off) = ph;
-            *reinterpret_cast<u32x4*>(v_s + KEYS * PROW + off) = pm;
-            if constexpr (VP == 3) *reinterpret_cast<u32x4*>(v_s + 2 * KEYS * PROW + off) = pl;
-        }
-    }
-    __syncthreads();
-
     f32x16 z;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
     // lane part of the K^ chunk addresses (tile bases are multiples of 32 rows: the swizzle term is the lane's)
     const int krow[2] = {li * PROW + ((hh ^ ((li >> 2) & 3)) * 16), li * PROW + (((2 + hh) ^ ((li >> 2) & 3)) * 16)};
+    const int vlane = (4 * hh + ((lane & 15) >> 2)) * PROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
 
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        if (!FULL && kt * 32 >= B) break;  // uniform
-        f32x16 x;
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (!FULL && ch * CK >= B) break;  // uniform
+        if (ch > 0) __syncthreads();       // every wave is done with the previous chunk's planes
+        stage();
+        if (ch + 1 < NCH) fetch(ch + 1);
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = 0.f;
+        for (int kl = 0; kl < CK / 32; ++kl) {
+            const int kt = ch * (CK / 32) + kl;
+            if (kt >= NKT) break;
+            if (!FULL && kt * 32 >= B) break;  // uniform
+            f32x16 x;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int off = kt * 32 * PROW + krow[s];
-            const u32x4 kh = *reinterpret_cast<const u32x4*>(k_s + off);
-            const u32x4 km = *reinterpret_cast<const u32x4*>(k_s + KEYS * PROW + off);
-            const u32x4 kl = *reinterpret_cast<const u32x4*>(k_s + 2 * KEYS * PROW + off);
-            x = mfma_bf16(kl, qh[s], x);
-            x = mfma_bf16(kh, ql[s], x);
-            x = mfma_bf16(km, qm[s], x);
-            x = mfma_bf16(km, qh[s], x);
-            x = mfma_bf16(kh, qm[s], x);
-            x = mfma_bf16(kh, qh[s], x);
-        }
-
-        float pr[16];
+            for (int r = 0; r < 16; ++r) x[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = fminf(__expf(x[r]), 1.f);
-        if (!FULL && (kt + 1) * 32 > B) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kt * 32 + hept_acc_row(r, hh) >= B) pr[r] = 0.f;
-        }
-
-        const int g = lane >> 4, l16 = lane & 15;
-        const int vrow = kt * 32 + 4 * hh + (l16 >> 2);
-        const int vcol = 32 * (g & 1) + 8 * (l16 & 3);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float pa[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pa[j] = pr[8 * s + j];
-            u32x4 ph, pm, pl3;
-            if constexpr (VP == 3) split3_bf16(pa, ph, pm, pl3);
-            else split2_bf16(pa, ph, pm);
-            typedef __attribute__((ext_vector_type(8))) short s16x8;
-            u32x4 vpl[VP];
-#pragma unroll
-            for (int pl = 0; pl < VP; ++pl) {
-                const char* vb = v_s + pl * KEYS * PROW;
-                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vb + (vrow + 16 * s) * PROW + vcol));
-                const s16x4 v1 =
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vb + (vrow + 16 * s + 8) * PROW + vcol));
-                const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                vpl[pl] = __builtin_bit_cast(u32x4, vv);
+            for (int s = 0; s < 2; ++s) {
+                const int off = kl * 32 * PROW + krow[s];
+                const u32x4 kh = *reinterpret_cast<const u32x4*>(k_s + off);
+                const u32x4 km = *reinterpret_cast<const u32x4*>(k_s + CK * PROW + off);
+                const u32x4 kl3 = *reinterpret_cast<const u32x4*>(k_s + 2 * CK * PROW + off);
+                x = mfma_bf16(kl3, qh[s], x);
+                x = mfma_bf16(kh, ql[s], x);
+                x = mfma_bf16(km, qm[s], x);
+                x = mfma_bf16(km, qh[s], x);
+                x = mfma_bf16(kh, qm[s], x);
+                x = mfma_bf16(kh, qh[s], x);
             }
-            if constexpr (VP == 3) {
-                z = mfma_bf16(pl3, vpl[0], z);
-                z = mfma_bf16(ph, vpl[2], z);
-                z = mfma_bf16(pm, vpl[1], z);
+
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = fminf(__expf(x[r]), 1.f);
+            if (!FULL && (kt + 1) * 32 > B) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + hept_acc_row(r, hh) >= B) pr[r] = 0.f;
             }
-            z = mfma_bf16(pm, vpl[0], z);
-            z = mfma_bf16(ph, vpl[1], z);
-            z = mfma_bf16(ph, vpl[0], z);
+
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float pa[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pa[j] = pr[8 * s + j];
+                u32x4 ph, pm, pl3;
+                if constexpr (VP == 3) split3_bf16(pa, ph, pm, pl3);
+                else split2_bf16(pa, ph, pm);
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                u32x4 vpl[VP];
+#pragma unroll
+                for (int pl = 0; pl < VP; ++pl) {
+                    const char* vb = v_s + pl * CK * PROW + (kl * 32 + 16 * s) * PROW + vlane;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vb));
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vb + 8 * PROW));
+                    const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    vpl[pl] = __builtin_bit_cast(u32x4, vv);
+                }
+                if constexpr (VP == 3) {
+                    z = mfma_bf16(pl3, vpl[0], z);
+                    z = mfma_bf16(ph, vpl[2], z);
+                    z = mfma_bf16(pm, vpl[1], z);
+                }
+                z = mfma_bf16(pm, vpl[0], z);
+                z = mfma_bf16(ph, vpl[1], z);
+                z = mfma_bf16(ph, vpl[0], z);
+            }
         }
     }
 
@@ -398,7 +421,7 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
                       const int* kpos, float* part, int N, int H, int D, int B, int nb) {
 #define HEPT_SPLIT_CASE(K)                                                                                       \
     case K: {                                                                                                    \
-        constexpr size_t lds = (size_t)(3 + VP) * 32 * K * 64;                                                   \
+        constexpr size_t lds = (size_t)(3 + VP) * (K >= 2 ? 64 : 32) * 64;                                       \
         if (lds > 65536) {                                                                                       \
             static bool raised = false;                                                                          \
             if (!raised) {                                                                                       \
