@@ -321,6 +321,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
                                                                   const unsigned int* __restrict__ bstart, int N,
                                                                   int* __restrict__ pos_out,
                                                                   const int* __restrict__ seg_len) {
+    static_assert(CAP >= LOBINS, "the tile also holds the splitters of the streaming path");
     __shared__ unsigned long long tile_s[CAP];
     __shared__ unsigned int cur_s[LOBINS + 1];  // [0] stays 0; bin d lives at [d + 1]
     __shared__ unsigned int wsum_s[BKT_WAVES];
@@ -334,29 +335,15 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     const unsigned long long* src = pairs + (size_t)seg * N + start;
     int* out = pos_out + (size_t)seg * N + start;
     const SegParams rg = seg_params[seg];
-    const bool in_lds = nb <= CAP;
-    // Grouping key inside the bucket.  LDS path: the low bits of the global id.  Streaming path (a bucket that does
-    // not fit the tile holds a pile of equal or nearly equal keys, possibly next to a few spread ones, which neither
-    // those bits nor any linear map of the key range can separate): SPLITTERS -- LOBINS pairs sampled at regular
-    // positions of the bucket and sorted in LDS; a pair's bin is the number of splitters <= it (binary search).
-    // Pairs are unique u64, so even 60 000 equal keys spread over the bins by their index.
-    __shared__ unsigned long long spl_s[LOBINS];
-    if (!in_lds) {
-        for (int i = tid; i < LOBINS; i += BKT_THREADS) spl_s[i] = src[(size_t)i * nb / LOBINS];
-        __syncthreads();
-        for (int k = 2; k <= LOBINS; k <<= 1)          // bitonic sort, ascending
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < LOBINS; i += BKT_THREADS) {
-                    const int partner = i ^ j;
-                    if (partner > i) {
-                        const unsigned long long a = spl_s[i], b = spl_s[partner];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { spl_s[i] = b; spl_s[partner] = a; }
-                    }
-                }
-                __syncthreads();
-            }
-    }
+    // Grouping key inside the bucket.  LDS path: the low bits of the global id; a bucket of up to 2 CAP pairs (skewed
+    // key distributions -- pileup clouds of unequal size -- put 1.5x to 2x the expected pairs into a few buckets) goes
+    // through the tile in two passes, lower half of the id bins first, if each half fits.  Streaming path (anything
+    // else: a pile of equal or nearly equal keys, possibly next to a few spread ones, which neither those bits nor
+    // any linear map of the key range can separate): SPLITTERS -- LOBINS pairs sampled at regular positions of the
+    // bucket and sorted in LDS; a pair's bin is the number of splitters <= it (binary search).  Pairs are unique
+    // u64, so even 60 000 equal keys spread over the bins by their index.
+    bool in_lds = nb <= 2 * CAP;                 // workgroup-uniform
+    unsigned long long* spl_s = tile_s;          // the streaming path groups in global scratch, its tile is free
     auto lo_of = [&](unsigned long long p) -> unsigned int {
         if (in_lds) return bucket_id((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
         int lo = 0, hi = LOBINS;  // number of splitters <= p
@@ -367,28 +354,12 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         return (unsigned int)(lo > 0 ? lo - 1 : 0);
     };
     unsigned int* bin_s = cur_s + 1;
+    auto zero_bins = [&]() {
 #pragma unroll
-    for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) bin_s[u * BKT_THREADS + tid] = 0;
-    if (tid == 0) cur_s[0] = 0;
-    constexpr int ITEMS = CAP / BKT_THREADS;
-    unsigned long long mine[ITEMS];
-    if (in_lds) {
-#pragma unroll
-        for (int u = 0; u < ITEMS; ++u) {
-            const int i = u * BKT_THREADS + tid;
-            mine[u] = i < nb ? src[i] : 0ull;
-        }
-    }
-    __syncthreads();
-    if (in_lds) {
-#pragma unroll
-        for (int u = 0; u < ITEMS; ++u)
-            if (u * BKT_THREADS + tid < nb) atomicAdd(&bin_s[lo_of(mine[u])], 1u);
-    } else {
-        for (int i = tid; i < nb; i += BKT_THREADS) atomicAdd(&bin_s[lo_of(src[i])], 1u);
-    }
-    __syncthreads();
-    {   // exclusive prefix over the bins: thread owns bins BPT*tid .. BPT*tid + BPT - 1
+        for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) bin_s[u * BKT_THREADS + tid] = 0;
+        if (tid == 0) cur_s[0] = 0;
+    };
+    auto prefix_bins = [&]() {  // exclusive prefix over the bins: thread owns bins BPT*tid .. BPT*tid + BPT - 1
         unsigned int c[BKT_BINS_PER_THREAD], tot = 0;
 #pragma unroll
         for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) { c[u] = bin_s[BKT_BINS_PER_THREAD * tid + u]; tot += c[u]; }
@@ -409,14 +380,63 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
             bin_s[BKT_BINS_PER_THREAD * tid + u] = run;
             run += c[u];
         }
+        __syncthreads();
+    };
+    zero_bins();
+    // The first CAP pairs of the bucket are loaded into registers with every load in flight at once; only the
+    // grouped copy lives in LDS.  One bins array serves as histogram, exclusive prefix and scatter cursor: after
+    // the scatter cur[d] is one past the last slot of group d, i.e. group d = [cur[d-1], cur[d]).
+    constexpr int ITEMS = CAP / BKT_THREADS;
+    unsigned long long mine[ITEMS];
+    if (in_lds) {
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int i = u * BKT_THREADS + tid;
+            mine[u] = i < nb ? src[i] : 0ull;
+        }
     }
     __syncthreads();
+    int n_low = nb;  // pairs in the lower half of the id bins (two-pass buckets)
+    if (in_lds) {
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u)
+            if (u * BKT_THREADS + tid < nb) atomicAdd(&bin_s[lo_of(mine[u])], 1u);
+        for (int i = CAP + tid; i < nb; i += BKT_THREADS) atomicAdd(&bin_s[lo_of(src[i])], 1u);
+        __syncthreads();
+        prefix_bins();
+        if (nb > CAP) {
+            n_low = (int)bin_s[LOBINS / 2];
+            if (n_low > CAP || nb - n_low > CAP) in_lds = false;  // uniform: every thread reads the same word
+        }
+    }
+    if (!in_lds) {
+        __syncthreads();
+        for (int i = tid; i < LOBINS; i += BKT_THREADS) spl_s[i] = src[(size_t)i * nb / LOBINS];
+        zero_bins();
+        __syncthreads();
+        for (int k = 2; k <= LOBINS; k <<= 1)          // bitonic sort, ascending
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < LOBINS; i += BKT_THREADS) {
+                    const int partner = i ^ j;
+                    if (partner > i) {
+                        const unsigned long long a = spl_s[i], b = spl_s[partner];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { spl_s[i] = b; spl_s[partner] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < nb; i += BKT_THREADS) atomicAdd(&bin_s[lo_of(src[i])], 1u);
+        __syncthreads();
+        prefix_bins();
+    }
+    // rank the pairs grouped[0 .. cnt) = bucket positions [off, off + cnt) inside their groups
     // (separate LDS / global code paths: one pointer for both would compile to slow FLAT accesses)
-    auto rank_all = [&](const unsigned long long* grouped) {
-        for (int i = tid; i < nb; i += BKT_THREADS) {
+    auto rank_all = [&](const unsigned long long* grouped, int off, int cnt) {
+        for (int i = tid; i < cnt; i += BKT_THREADS) {
             const unsigned long long p = grouped[i];
             const unsigned int d = lo_of(p);
-            const int g0 = (int)cur_s[d], g1 = (int)cur_s[d + 1];  // = bin_s[d - 1], bin_s[d]
+            const int g0 = (int)cur_s[d] - off, g1 = (int)cur_s[d + 1] - off;  // = bin_s[d - 1], bin_s[d]
             int smaller = 0;
             for (int j = g0; j < g1; j += 4) {  // 4 independent reads per round trip
                 unsigned long long q[4];
@@ -425,15 +445,29 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
 #pragma unroll
                 for (int u = 0; u < 4; ++u) smaller += (j + u < g1) && (q[u] < p);
             }
-            out[g0 + smaller] = (int)(unsigned int)p;
+            out[off + g0 + smaller] = (int)(unsigned int)p;
         }
     };
     if (in_lds) {
+        const int n_pass = nb > CAP ? 2 : 1;
+        for (int ps = 0; ps < n_pass; ++ps) {
+            const unsigned int half = (unsigned int)ps;                  // bins [0, LOBINS/2) then [LOBINS/2, LOBINS)
+            const int off = ps ? n_low : 0, cnt = n_pass == 2 ? (ps ? nb - n_low : n_low) : nb;
 #pragma unroll
-        for (int u = 0; u < ITEMS; ++u)
-            if (u * BKT_THREADS + tid < nb) tile_s[atomicAdd(&bin_s[lo_of(mine[u])], 1u)] = mine[u];
-        __syncthreads();
-        rank_all(tile_s);
+            for (int u = 0; u < ITEMS; ++u)
+                if (u * BKT_THREADS + tid < nb) {
+                    const unsigned int d = lo_of(mine[u]);
+                    if (n_pass == 1 || (d >> (TOP_SHIFT - 1)) == half) tile_s[atomicAdd(&bin_s[d], 1u) - off] = mine[u];
+                }
+            for (int i = CAP + tid; i < nb; i += BKT_THREADS) {
+                const unsigned long long p = src[i];
+                const unsigned int d = lo_of(p);
+                if ((d >> (TOP_SHIFT - 1)) == half) tile_s[atomicAdd(&bin_s[d], 1u) - off] = p;
+            }
+            __syncthreads();
+            rank_all(tile_s, off, cnt);
+            __syncthreads();
+        }
     } else {
         unsigned long long* g = scratch + (size_t)seg * N + start;
         for (int i = tid; i < nb; i += BKT_THREADS) {
@@ -442,7 +476,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         }
         __threadfence_block();
         __syncthreads();
-        rank_all(g);
+        rank_all(g, 0, nb);
     }
 }
 
