@@ -31,12 +31,13 @@ for name in WORKLOADS:
             for _ in range(20):
                 m(g["q"], g["k"], g["v"], **kw)
             torch.cuda.synchronize()
-            reps = 300
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                m(g["q"], g["k"], g["v"], **kw)
-            torch.cuda.synchronize()
-        us = (time.perf_counter() - t0) / reps * 1e6
+            reps, us = 300, float("inf")
+            for _ in range(3):  # best of three: the small clouds are bound by the host's launch rate, which is noisy
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    m(g["q"], g["k"], g["v"], **kw)
+                torch.cuda.synchronize()
+                us = min(us, (time.perf_counter() - t0) / reps * 1e6)
         flops = 2.0 * t * h * n * b * (e + 24)
         print(f"{name:16s} N_raw={n_raw:6d} N={n:6d} B={b:3d} T={t} C={c} {prec:8s} {us:8.1f} us/forward "
               f"{n_raw / us:8.2f} M points/s  {flops / us * 1e-6:7.1f} TFLOP/s", flush=True)
