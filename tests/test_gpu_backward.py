@@ -149,3 +149,15 @@ def test_split_backward_matches_the_f32_mfma_kernel(name, gpu_device):
     rel = 5e-4 if name == "g3_ckpt6k" else 1e-4
     for a, r in zip(got, ref):
         assert _close(a, r, rel=rel)
+
+
+def test_split_backward_random_shapes(gpu_device):
+    """tools/bwd_stress.py: random block sizes (8..256, mostly not multiples of 32), 1..6 tables, every supported
+    (head_dim, coords_dim) pair, 1..3 clouds: split-bf16 backward == native f32 MFMA backward to 1e-4 of each scale."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "bwd_stress.py"), "18"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
