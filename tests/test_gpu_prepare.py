@@ -150,3 +150,19 @@ def test_segmented_argsort_ragged(gpu_device):
         for s in range(s_):
             n = int(lens[s])
             assert torch.equal(pos[s, :n], torch.sort(keys[s, :n], stable=True).indices), (s_, l_, s, n)
+
+
+@pytest.mark.parametrize("spread", ["whole_bucket", "lower_half", "one_bin"])
+def test_segmented_argsort_oversize_bucket_paths(gpu_device, spread):
+    """60 000 uniform keys + 1 500 extra keys inside one of the 256 top-level buckets: the bucket holds ~1 730 pairs,
+    more than the 1 024-pair LDS tile.  Spread over the whole bucket it takes the two-pass LDS path, packed into its
+    lower half (or a single id bin) the halves do not fit and the splitter streaming path takes over.  Exact either way."""
+    g = torch.Generator().manual_seed(5)
+    n = 60000
+    keys = torch.rand(3, n + 1500, generator=g)
+    width = {"whole_bucket": 1 / 256, "lower_half": 1 / 600, "one_bin": 1e-7}[spread]
+    keys[:, n:] = 100 / 256 + torch.rand(3, 1500, generator=g) * width
+    keys[:, 0], keys[:, 1] = 0.0, 1.0  # pin the key range so that the bucket boundaries are where the test expects
+    keys = keys[:, torch.randperm(n + 1500, generator=g)]
+    pos = ops.segmented_argsort(keys.to(gpu_device)).long().cpu()
+    assert torch.equal(pos, torch.sort(keys, dim=-1, stable=True).indices)
