@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 
-__all__ = ["HeptPartialSums", "HeptCombine", "rpe_scale_torch"]
+__all__ = ["HeptPartialSums", "HeptCombine", "RpeScale", "rpe_scale_torch"]
 
 
 def rpe_scale_torch(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dist: int) -> torch.Tensor:
@@ -23,6 +23,23 @@ def rpe_scale_torch(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_p
     w4 = w_rpe_weight.reshape(n_heads, head_dim, -1, w_per_dist)
     qw = w4.sum(dim=1).clamp(max=50).exp().sum(dim=-1)
     return torch.sqrt(2 * torch.cat([qw[:, :1], qw], dim=-1))
+
+
+class RpeScale(torch.autograd.Function):
+    """``w_rpe.weight`` -> sqrt_w (H, C): the HIP kernels ``hept_rpe_scale`` / ``hept_rpe_scale_bwd`` in place of the
+    seven (forward) + eight (backward) tiny torch kernels of ``rpe_scale_torch`` (5 us of launch each)."""
+
+    @staticmethod
+    def forward(ctx, w_rpe_weight, n_heads, head_dim, w_per_dist):
+        ctx.save_for_backward(w_rpe_weight)
+        ctx.dims = (n_heads, head_dim, w_per_dist)
+        return ops.rpe_scale(w_rpe_weight, n_heads, head_dim, w_per_dist)
+
+    @staticmethod
+    def backward(ctx, d_sqrt_w):
+        (w,) = ctx.saved_tensors
+        h, d, k = ctx.dims
+        return ops.rpe_scale_bwd(w, d_sqrt_w.contiguous(), h, d, k).to(w.dtype), None, None, None
 
 
 class HeptPartialSums(torch.autograd.Function):
@@ -56,13 +73,13 @@ class HeptPartialSums(torch.autograd.Function):
     def backward(ctx, gacc):
         qhat, kvhat, qpos, kpos, coords, sqrt_w = ctx.saved_tensors
         d, c, block_size = ctx.dims
-        dq, dk, dv, dcs = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size)
-        if ctx.raw_size < dq.shape[0]:
-            for g in (dq, dk, dv, dcs):
-                g[ctx.raw_size:] = 0
-        # scaled coordinates s[n,h,c] = sqrt_w[h,c] * coords[n,c]
-        # (a product + column sum: as an einsum this became a 48 x N GEMM that rocBLAS runs in 320 us)
-        dsw = (dcs * coords[:, None, :]).sum(dim=0) if ctx.needs_input_grad[4] else None
+        # scaled coordinates s[n,h,c] = sqrt_w[h,c] * coords[n,c]: d sqrt_w = sum_n dcs * coords comes out of the
+        # reduction kernel (as a torch einsum it was a 48 x N GEMM that rocBLAS ran in 320 us, as a product + column
+        # sum two kernels of 27 us); rows at and after raw_size (src variant padding) get zero gradients there too
+        dq, dk, dv, dcs, dsw = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size,
+                                                  coords=coords, raw_size=ctx.raw_size)
+        if not ctx.needs_input_grad[4]:
+            dsw = None
         dcoords = (dcs * sqrt_w[None]).sum(dim=1) if ctx.needs_input_grad[3] else None
         return dq, dk, dv, dcoords, dsw, None, None, None, None
 

@@ -450,10 +450,13 @@ void block_attn_bwd_split_kernel(
 
 // sum the per-table partial rows and undo the augmentation:
 //   dq,dk,dv (N, H*D);  dcs (N, H, C) = gradient of the scaled coordinates sqrt_w[h,c]*coords[n,c] (q^ and k^ share them)
+// One thread per (point, head, column): nine independent loads each, 60 000 workgroups -- the kernel runs at the
+// copy bandwidth (a variant that walked 16 points per workgroup to keep d_sqrt_w sums in registers ran at 60 % of it).
 __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict__ dq_part,
                                                          const float* __restrict__ dkv_part, int Tl, int N, int H,
-                                                         int D, int C, float* __restrict__ dq, float* __restrict__ dk,
-                                                         float* __restrict__ dv, float* __restrict__ dcs) {
+                                                         int D, int C, int raw_size, float* __restrict__ dq,
+                                                         float* __restrict__ dk, float* __restrict__ dv,
+                                                         float* __restrict__ dcs) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, h, col)
     const size_t total = (size_t)N * H * 32;
     if (i >= total) return;
@@ -465,6 +468,7 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict
         sk += dkv_part[((size_t)t * N * H + nh) * 64 + col];
         sv += dkv_part[((size_t)t * N * H + nh) * 64 + 32 + col];
     }
+    if (nh >= (size_t)raw_size * H) sq = sk = sv = 0.f;  // the src variant's zero-filled padding rows
     if (col < D) {
         dq[nh * D + col] = sq;
         dk[nh * D + col] = sk;
@@ -472,6 +476,35 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict
     } else if (col < D + C) {
         dcs[nh * C + (col - D)] = sq + sk;
     }
+}
+
+// d_sqrt_w[h][c] = sum_n dcs[n][h][c] * coords[n][c]: lane = (h, c) column of the H*C <= 64 wide rows, a wave walks
+// every fourth point of the workgroup's 256 (8 rows in flight), the four waves meet in LDS, one atomic per column
+constexpr int DSW_POINTS = 256;
+__global__ __launch_bounds__(256) void dsw_kernel(const float* __restrict__ dcs, const float* __restrict__ coords, int N,
+                                                  int H, int C, float* __restrict__ d_sqrt_w) {
+    __shared__ float red_s[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, HC = H * C;
+    const int n_begin = blockIdx.x * DSW_POINTS, n_end = min(N, n_begin + DSW_POINTS);
+    float acc = 0.f;
+    if (lane < HC) {
+        const int c = lane % C;
+        constexpr int UN = 8;
+        for (int n0 = n_begin + w; n0 < n_end; n0 += 4 * UN) {
+            float g[UN], x[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int n = n0 + 4 * u;
+                g[u] = n < n_end ? dcs[(size_t)n * HC + lane] : 0.f;
+                x[u] = n < n_end ? coords[(size_t)n * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = fmaf(g[u], x[u], acc);
+        }
+    }
+    red_s[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && lane < HC) atomicAdd(d_sqrt_w + lane, red_s[0][lane] + red_s[1][lane] + red_s[2][lane] + red_s[3][lane]);
 }
 
 template <bool FULL>
@@ -574,11 +607,20 @@ extern "C" int hept_block_attn_bwd_f32mfma(const float* qhat, const float* kvhat
 }
 
 extern "C" int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
-                               float* dq, float* dk, float* dv, float* dcs, void* stream) {
+                               const float* coords, int raw_size, float* dq, float* dk, float* dv, float* dcs,
+                               float* d_sqrt_w, void* stream) {
     if (!dq_part || !dkv_part || !dq || !dk || !dv || !dcs) return HEPT_ERR_ARG;
-    if (Tl < 1 || N < 1 || H < 1 || D < 1 || C < 1 || D + C > 30) return HEPT_ERR_SHAPE;
+    if (d_sqrt_w && !coords) return HEPT_ERR_ARG;
+    if (Tl < 1 || N < 1 || H < 1 || D < 1 || C < 1 || D + C > 30 || raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    if (d_sqrt_w && H * C > 64) return HEPT_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)N * H * 32;
-    hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       dq_part, dkv_part, Tl, N, H, D, C, dq, dk, dv, dcs);
+    hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dq_part, dkv_part, Tl,
+                       N, H, D, C, raw_size, dq, dk, dv, dcs);
+    if (d_sqrt_w) {
+        if (hipMemsetAsync(d_sqrt_w, 0, sizeof(float) * H * C, st) != hipSuccess) return HEPT_ERR_LAUNCH;
+        hipLaunchKernelGGL(dsw_kernel, dim3((unsigned)((N + DSW_POINTS - 1) / DSW_POINTS)), dim3(256), 0, st, dcs, coords,
+                           N, H, C, d_sqrt_w);
+    }
     return hept_launch_status();
 }

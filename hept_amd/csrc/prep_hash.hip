@@ -52,6 +52,35 @@ __global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict
     }
 }
 
+// backward of rpe_scale (training): d w[h*D+d][r*K+k] = [a <= 50] exp(a) * sum_{c -> r} d sqrt_w[h][c] / sqrt_w[h][c]
+// with a = sum_d w[h*D+d][r*K+k] (the same for every d of a head; torch's clamp passes the gradient at equality) and
+// columns c = 0 and c = 1 both fed by r = 0.  sqrt_w = 0 (all terms underflowed) gives inf/nan exactly as autograd does.
+__global__ __launch_bounds__(1024) void rpe_scale_bwd_kernel(const float* __restrict__ w,
+                                                             const float* __restrict__ d_sqrt_w, int H, int D, int C,
+                                                             int K, float* __restrict__ d_w) {
+    const int R = C - 1, RK = R * K, total = H * RK;
+    const int i = threadIdx.x;
+    __shared__ float term_s[1024];
+    float a = 0.f;
+    if (i < total) {
+        const int h = i / RK, rk = i - h * RK;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) a += w[(size_t)(h * D + d) * RK + rk];
+        term_s[i] = expf(fminf(a, 50.f));
+    }
+    __syncthreads();
+    if (i < total) {
+        const int h = i / RK, rk = i - h * RK, r = rk / K;
+        float tot = 0.f;
+        for (int kk = 0; kk < K; ++kk) tot += term_s[h * RK + r * K + kk];
+        const float s = sqrtf(2.f * tot);  // = sqrt_w[h][r + 1]
+        float g = d_sqrt_w[h * C + r + 1];
+        if (r == 0) g += d_sqrt_w[h * C];
+        const float da = a <= 50.f ? (g / s) * term_s[i] : 0.f;
+        for (int d = 0; d < D; ++d) d_w[(size_t)(h * D + d) * RK + rk] = da;
+    }
+}
+
 // Streaming transform, one lane per (point, head) row, three wave ROLES selected by blockIdx.y:
 //   role 0 (q): q row + coords -> q^ row, q hashes, hash min/max, largest AND code
 //   role 1 (k): k row + coords -> k^ half of the kvhat row, k hashes, hash min/max
@@ -403,6 +432,15 @@ extern "C" int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, fl
     if (!w_rpe || !sqrt_w) return HEPT_ERR_ARG;
     if (H < 1 || D < 1 || C < 2 || K < 1 || H * (C - 1) * K > 1024) return HEPT_ERR_SHAPE;
     hipLaunchKernelGGL(rpe_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_rpe, H, D, C, K, sqrt_w);
+    return hept_launch_status();
+}
+
+extern "C" int hept_rpe_scale_bwd(const float* w_rpe, const float* d_sqrt_w, int H, int D, int C, int K, float* d_w_rpe,
+                                  void* stream) {
+    if (!w_rpe || !d_sqrt_w || !d_w_rpe) return HEPT_ERR_ARG;
+    if (H < 1 || D < 1 || C < 2 || K < 1 || H * (C - 1) * K > 1024) return HEPT_ERR_SHAPE;
+    hipLaunchKernelGGL(rpe_scale_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_rpe, d_sqrt_w, H, D, C, K,
+                       d_w_rpe);
     return hept_launch_status();
 }
 

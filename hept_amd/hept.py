@@ -146,7 +146,7 @@ class HEPTAttention(nn.Module):
 
     def _forward_train(self, query, key, value, **kwargs):
         """Differentiable path: HIP forward/backward of the block attention inside autograd (f32 tiles)."""
-        from .autograd import HeptPartialSums, rpe_scale_torch
+        from .autograd import HeptPartialSums, RpeScale
 
         if self.precision != "fp32":
             raise RuntimeError("training needs precision='fp32' (the backward kernels use f32 tiles)")
@@ -157,7 +157,7 @@ class HEPTAttention(nn.Module):
             raise ValueError(f"number of points {n} is not a multiple of block_size {self.block_size}")
         h, d = self.num_heads, self.dim_per_head
         coords = kwargs["coords"].float()
-        sqrt_w = rpe_scale_torch(kwargs["w_rpe"].weight.float(), h, d, self.num_w_per_dist)
+        sqrt_w = RpeScale.apply(kwargs["w_rpe"].weight.float(), h, d, self.num_w_per_dist)
         geo = None
         if "combined_shifts" not in kwargs:
             geo = ops.geo_args(kwargs["region_indices"], kwargs["regions_h"], self.n_hashes, h, n) + (

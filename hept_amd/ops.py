@@ -17,7 +17,7 @@ __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
     "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part",
     "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args",
-    "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward", "combine_bwd",
+    "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward", "combine_bwd", "rpe_scale_bwd",
 ]
 
 
@@ -67,6 +67,19 @@ def rpe_scale(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dis
     out = torch.empty(n_heads, c, device=w.device, dtype=torch.float32)
     _lib.check(lib.hept_rpe_scale(w.data_ptr(), n_heads, head_dim, c, w_per_dist, out.data_ptr(), _stream(w)),
                "hept_rpe_scale")
+    return out
+
+
+def rpe_scale_bwd(w_rpe_weight: torch.Tensor, d_sqrt_w: torch.Tensor, n_heads: int, head_dim: int,
+                  w_per_dist: int) -> torch.Tensor:
+    """Gradient of ``rpe_scale`` with respect to ``w_rpe.weight``: (H*D, (C-1)*K) from d_sqrt_w (H, C)."""
+    lib = _lib.load()
+    w = _f32c(w_rpe_weight, "w_rpe.weight")
+    g = _f32c(d_sqrt_w, "d_sqrt_w")
+    c = w.shape[1] // w_per_dist + 1
+    out = torch.empty_like(w)
+    _lib.check(lib.hept_rpe_scale_bwd(w.data_ptr(), g.data_ptr(), n_heads, head_dim, c, w_per_dist, out.data_ptr(),
+                                      _stream(w)), "hept_rpe_scale_bwd")
     return out
 
 
@@ -221,10 +234,11 @@ def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int
 
 
 def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int, block_size: int,
-                   f32_mfma: bool = False):
+                   f32_mfma: bool = False, coords: Optional[torch.Tensor] = None, raw_size: Optional[int] = None):
     """Backward of block_attn + reduce_tables for f32 tiles: gradient rows gacc (N,H,32) -> dq, dk, dv (N, H*D)
     and dcs (N, H, C), the gradient of the scaled coordinates shared by q^ and k^.  ``f32_mfma`` selects the
-    native f32 MFMA kernel instead of the split-bf16 products."""
+    native f32 MFMA kernel instead of the split-bf16 products.  With ``coords`` (N, C) a fifth result
+    d_sqrt_w (H, C) = sum_n dcs * coords is reduced in the same pass; rows at and after ``raw_size`` get zeros."""
     lib = _lib.load()
     if qhat.dtype != torch.float32:
         raise TypeError("the backward pass needs f32 tiles (precision='fp32')")
@@ -241,8 +255,17 @@ def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int
     dq = torch.empty(n, h * head_dim, device=dev, dtype=torch.float32)
     dk, dv = torch.empty_like(dq), torch.empty_like(dq)
     dcs = torch.empty(n, h, coords_dim, device=dev, dtype=torch.float32)
+    dsw = None
+    if coords is not None:
+        coords = _f32c(coords, "coords")
+        dsw = torch.empty(h, coords_dim, device=dev, dtype=torch.float32)
     _lib.check(lib.hept_bwd_reduce(dq_part.data_ptr(), dkv_part.data_ptr(), tl, n, h, head_dim, coords_dim,
-                                   dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dcs.data_ptr(), st), "hept_bwd_reduce")
+                                   coords.data_ptr() if coords is not None else None,
+                                   n if raw_size is None else int(raw_size), dq.data_ptr(), dk.data_ptr(),
+                                   dv.data_ptr(), dcs.data_ptr(), dsw.data_ptr() if dsw is not None else None, st),
+               "hept_bwd_reduce")
+    if coords is not None:
+        return dq, dk, dv, dcs, dsw
     return dq, dk, dv, dcs
 
 

@@ -221,8 +221,15 @@ int hept_block_attn_bwd(const float* qhat, const float* kvhat, const int32_t* qp
 int hept_block_attn_bwd_f32mfma(const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
                                 const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part,
                                 float* dkv_part, void* stream);
+/* coords (N, C) + d_sqrt_w (H, C) (both may be NULL): also d_sqrt_w[h,c] = sum_n dcs[n,h,c] * coords[n,c], the
+ * gradient that flows on into w_rpe.weight.  Rows at and after raw_size (the src variant's zero-filled padding,
+ * raw_size = N otherwise) get zero gradients. */
 int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
-                    float* dq, float* dk, float* dv, float* dcs, void* stream);
+                    const float* coords, int raw_size, float* dq, float* dk, float* dv, float* dcs,
+                    float* d_sqrt_w, void* stream);
+/* backward of hept_rpe_scale (example/hept.py:22-23,25 under autograd): d_w_rpe (H*D, (C-1)*K) from d_sqrt_w (H, C) */
+int hept_rpe_scale_bwd(const float* w_rpe, const float* d_sqrt_w, int H, int D, int C, int K, float* d_w_rpe,
+                       void* stream);
 /* backward of hept_combine_out on table-summed f32 rows acc (N, H, 32) (example/hept.py:79-80 under autograd):
  * given g_out (N, D) writes gacc (N, H, 32) = gradient of acc, d_weight (D, H*D) and d_bias (D, may be NULL).
  * D == 24, H <= 8. */

@@ -161,3 +161,25 @@ def test_split_backward_random_shapes(gpu_device):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "bwd_stress.py"), "18"], capture_output=True, text=True)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+
+
+@pytest.mark.parametrize("c", [6, 4, 2])
+def test_rpe_scale_autograd_function_matches_torch(c, gpu_device):
+    """RpeScale (hept_rpe_scale / hept_rpe_scale_bwd) against autograd through the torch formula, including entries
+    above the clamp at 50 (no gradient there) and the duplicated first column."""
+    from hept_amd.autograd import RpeScale
+
+    h, d, k = 8, 24, 10
+    g = torch.Generator().manual_seed(c)
+    w = (torch.randn(h * d, (c - 1) * k, generator=g) * 0.3)
+    w[:d, 0] += 3.0   # sum over d = ~72 > 50: clamped term
+    w = w.to(gpu_device)
+    w1, w2 = w.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    up = torch.randn(h, c, generator=g).to(gpu_device)
+    s1 = rpe_scale_torch(w1, h, d, k)
+    s2 = RpeScale.apply(w2, h, d, k)
+    torch.testing.assert_close(s2, s1, rtol=2e-6, atol=0)
+    (s1 * up).sum().backward()
+    (s2 * up).sum().backward()
+    torch.testing.assert_close(w2.grad, w1.grad, rtol=1e-5, atol=1e-6 * float(w1.grad.abs().max()))
+    assert float(w2.grad[:d, 0].abs().max()) == 0.0
