@@ -411,7 +411,11 @@ __global__ __launch_bounds__(192 * CBW_GROUPS) void combine_bwd_weight_kernel(co
                                                                               const float* __restrict__ g_out, int N,
                                                                               int H, float* __restrict__ d_weight,
                                                                               float* __restrict__ d_bias) {
+    // one LDS region, used twice: the workgroup's g_out rows during the loop (every lane of a wave reads the same
+    // word: an LDS broadcast instead of 24 scalar loads per point), then the fold of the thread groups
     __shared__ float red_s[CBW_GROUPS - 1][CB_D + 1][192];
+    static_assert(sizeof(float) * CBW_POINTS * CB_D <= sizeof(float) * (CBW_GROUPS - 1) * (CB_D + 1) * 192, "g tile fits");
+    float* g_s = &red_s[0][0][0];
     const int col = threadIdx.x % 192, grp = threadIdx.x / 192;  // col = h * D + j; 192 = 3 waves, so grp is wave-uniform
     const int HD = H * CB_D;
     const bool live = col < HD;
@@ -421,6 +425,8 @@ __global__ __launch_bounds__(192 * CBW_GROUPS) void combine_bwd_weight_kernel(co
 #pragma unroll
     for (int c = 0; c < CB_D; ++c) s[c] = 0.f;
     float sb = 0.f;  // lanes < D also sum g_out[:, lane] for the bias gradient
+    for (int i = threadIdx.x; i < (n_end - n_begin) * CB_D; i += 192 * CBW_GROUPS) g_s[i] = g_out[(size_t)n_begin * CB_D + i];
+    __syncthreads();
     constexpr int UN = 4;
     for (int n0 = n_begin + grp; n0 < n_end; n0 += CBW_GROUPS * UN) {
         float ph[UN];
@@ -434,13 +440,14 @@ __global__ __launch_bounds__(192 * CBW_GROUPS) void combine_bwd_weight_kernel(co
         for (int u = 0; u < UN; ++u) {
             const int n = n0 + u * CBW_GROUPS;
             if (n < n_end) {                                 // wave-uniform
-                const float* gr = g_out + (size_t)n * CB_D;  // uniform across the wave: scalar loads
+                const float* gr = g_s + (n - n_begin) * CB_D;  // uniform across the wave: LDS broadcast
 #pragma unroll
                 for (int c = 0; c < CB_D; ++c) s[c] = fmaf(gr[c], ph[u], s[c]);
                 if (col < CB_D) sb += gr[col];
             }
         }
     }
+    __syncthreads();  // every group is done with the g tile
     if (grp > 0) {
 #pragma unroll
         for (int c = 0; c < CB_D; ++c) red_s[grp - 1][c][col] = s[c];
