@@ -14,7 +14,8 @@ SURVEY.md §8 f-3): construct with ``variant="src"`` (adds the unused ``e2lsh.be
 checkpoints carry) and call ``forward`` with that variant's kwargs — ``raw_size``, ``regions_h``,
 ``region_indices`` as built by ``hept_amd.prep.prepare_input_src`` — instead of ``combined_shifts``.
 
-Two keyword-only extensions: ``precision`` ("fp32" reference numerics /
+Two keyword-only extensions: ``precision`` ("fp32" reference numerics: f32 rows, tile products as split-bf16
+MFMAs accurate to f32 round-off / "fp32_mfma" the same on the native f32 MFMA, slower, kept as ground truth /
 "bf16" MFMA tiles / "mixed16" = fp16 q̂,k̂ tiles with bf16 weights and values) and ``process_group`` (shard the ``n_hashes`` tables over
 the ranks of a ``torch.distributed`` group).
 
