@@ -264,6 +264,28 @@ __device__ __forceinline__ f32x16 mfma5_tr(const u32x4& ah, const u32x4& am, con
     return z;
 }
 
+// Element (row, column li) of an f32 tile held as three bf16 planes (the sum of its pieces), for the rows a lane
+// meets in the accumulator layout: row = 32 w + acc_row(r, hh).  Its byte offset is a lane constant plus a
+// compile-time term: the swizzle of such a row is hh ^ (2 if r & 4), i.e. bit 5 of the offset flips for r & 4.
+struct ElemLanes {
+    int base[2];  // r & 4 == 0 / != 0
+};
+__device__ __forceinline__ ElemLanes elem_lanes(int w, int lane) {
+    const int li = lane & 31, hh = lane >> 5;
+    ElemLanes e;
+    e.base[0] = (w * 32 + 4 * hh) * BPROW + ((((li >> 3) ^ hh) & 3) << 4) + ((li & 7) << 1);
+    e.base[1] = e.base[0] ^ 32;
+    return e;
+}
+__device__ __forceinline__ float plane_elem3(const char* planes, int plane_bytes, const ElemLanes& e, int r) {
+    const int off = e.base[(r >> 2) & 1] + ((r & 3) + 8 * (r >> 2)) * BPROW;
+    float v = 0.f;
+#pragma unroll
+    for (int pc = 2; pc >= 0; --pc)
+        v += __uint_as_float((unsigned int)*reinterpret_cast<const unsigned short*>(planes + pc * plane_bytes + off) << 16);
+    return v;
+}
+
 template <int NKT, bool FULL>
 __global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu((NKT <= 4 && FULL) ? 3 : 2, (NKT <= 4 && FULL) ? 3 : 2)))
 void block_attn_bwd_split_kernel(
@@ -331,8 +353,8 @@ void block_attn_bwd_split_kernel(
     __syncthreads();
 
     // =========================== phase Q: d q^ ===========================
+    f32x16 z;
     {
-        f32x16 z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.f;
 #pragma unroll
@@ -363,34 +385,41 @@ void block_attn_bwd_split_kernel(
                 z = mfma5_tr(dh, dm, a_s, PL, pl, (kt * 32 + 16 * s) * BPROW, z);  // Z += dS . K^ ; column 30 = rowsum(dS)
             }
         }
-        // d q^_i = sum_j dS_ij k^_j - (sum_j dS_ij) q^_i ;  lane = column, registers = queries
+    }
+
+    // ---- hand-over between the phases.  After the barrier nobody reads the K^ / V planes as tiles any more and
+    // every wave touches only its own 32 rows of each plane until the next barrier:
+    //   own V rows -> registers;  own Q^ pieces -> the V planes (rows now private);  the phase Q epilogue reads q^ from
+    //   there with lane = column (reading it from global memory instead -- 16 dependent row reads per wave and
+    //   phase -- cost 15 % of the kernel);  own K^ rows -> registers;  Q^ / G pieces -> the planes of phase K.
+    u32x4 k3[2][3], v3[2][3];
+    const ElemLanes el = elem_lanes(w, lane);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int off = w * 32 * BPROW + pl.row[s];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) v3[s][pc] = *reinterpret_cast<const u32x4*>(b_s + pc * PL + off);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(b_s + pc * PL + off) = q3[s][pc];
+    }
+    {   // d q^_i = sum_j dS_ij k^_j - (sum_j dS_ij) q^_i ;  lane = column, registers = queries
         float* __restrict__ dst = dq_part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q2 = w * 32 + hept_acc_row(r, hh);
             const int src = __shfl(qsrc, hept_acc_row(r, hh));
             const float rs = __shfl(z[r], 30 + 32 * hh);
-            if (FULL || q2 < B) dst[(size_t)src * H * 32] = li < 30 ? z[r] - rs * qbase[(size_t)src * 32 + li] : 0.f;
+            const float qv = plane_elem3(b_s, PL, el, r);
+            if (FULL || q2 < B) dst[(size_t)src * H * 32] = li < 30 ? z[r] - rs * qv : 0.f;
         }
     }
-
-    // ---- own K^ / V rows: LDS -> registers; then the planes are re-used for Q^ / G
-    u32x4 k3[2][3], v3[2][3];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int off = w * 32 * BPROW + pl.row[s];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
             k3[s][pc] = *reinterpret_cast<const u32x4*>(a_s + pc * PL + off);
-            v3[s][pc] = *reinterpret_cast<const u32x4*>(b_s + pc * PL + off);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int off = w * 32 * BPROW + pl.row[s];
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
             *reinterpret_cast<u32x4*>(a_s + pc * PL + off) = q3[s][pc];
             *reinterpret_cast<u32x4*>(b_s + pc * PL + off) = g3[s][pc];
         }
@@ -433,15 +462,25 @@ void block_attn_bwd_split_kernel(
                 zv = mfma5_tr(ph, pm, b_s, PL, pl, (qt * 32 + 16 * s) * BPROW, zv);  // ZV += P^T . G
             }
         }
+        // the wave's K^ pieces go back into (its own rows of) the first three planes so that the epilogue can read
+        // k^ with lane = column
+        __syncthreads();  // every wave is done with the Q^ planes
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = w * 32 * BPROW + pl.row[s];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(a_s + pc * PL + off) = k3[s][pc];
+        }
         float* __restrict__ dst = dkv_part + (size_t)t * N * H * 64 + (size_t)h * 64 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k2 = w * 32 + hept_acc_row(r, hh);
             const int src = __shfl(ksrc, hept_acc_row(r, hh));
             const float rs = __shfl(zk[r], 31 + 32 * hh);
+            const float kv = plane_elem3(a_s, PL, el, r);
             if (FULL || k2 < B) {
                 float* row = dst + (size_t)src * H * 64;
-                row[0] = li < 30 ? zk[r] - rs * kvbase[(size_t)src * 64 + li] : 0.f;
+                row[0] = li < 30 ? zk[r] - rs * kv : 0.f;
                 row[32] = li < D ? zv[r] : 0.f;
             }
         }
