@@ -101,8 +101,7 @@ def c_stdout_to_stderr():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: the timed region carries ~0.7 ms of fixed cost (pipeline fill after the fence, final synchronize), which
-    # is 3 % of 100 steps of 0.2 ms and 0.7 % of 500
+    # defaults: 500 steps = 0.1 s of GPU time; 100-step regions (20 ms) scatter by +-2 % from run to run on one box
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
