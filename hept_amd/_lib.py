@@ -9,7 +9,8 @@ import ctypes
 import os
 from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 
-from .build import LIB_PATH
+# (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
 ABI_VERSION = 9
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3

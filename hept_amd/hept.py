@@ -149,7 +149,7 @@ class HEPTAttention(nn.Module):
         """Differentiable path: HIP forward/backward of the block attention inside autograd (f32 tiles)."""
         from .autograd import HeptPartialSums, RpeScale
 
-        if self.precision != "fp32":
+        if self.precision not in ("fp32", "fp32_mfma"):
             raise RuntimeError("training needs precision='fp32' (the backward kernels use f32 tiles)")
         if self.sharding is not None:
             raise RuntimeError("table sharding is an inference feature; train with process_group=None")
