@@ -183,3 +183,31 @@ def test_rpe_scale_autograd_function_matches_torch(c, gpu_device):
     (s2 * up).sum().backward()
     torch.testing.assert_close(w2.grad, w1.grad, rtol=1e-5, atol=1e-6 * float(w1.grad.abs().max()))
     assert float(w2.grad[:d, 0].abs().max()) == 0.0
+
+
+def test_gradients_at_tracking_60k(gpu_device):
+    """Full size: the training path (RpeScale -> HeptPartialSums -> HeptCombine, split-bf16 kernels) on the 60k golden
+    cloud against the oracle's autograd with the GPU's own permutations injected (no tie ambiguity)."""
+    from hept_amd.autograd import HeptCombine, HeptPartialSums, RpeScale
+
+    inp, _ = cases.load_case("g5_track60k")
+    dev = gpu_device
+    g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+    h, e, t = inp["alpha"].shape
+    n, d, b, kk = inp["q"].shape[0], 24, inp["block_size"], inp["w_per_dist"]
+    sw0 = ops.rpe_scale(g["w_rpe_weight"], h, d, kk)
+    ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw0, g["alpha"], g["combined_shifts"], "fp32")
+    qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], g["combined_shifts"], ph["minmax"])
+    g_out = torch.randn(n, d, generator=torch.Generator().manual_seed(11))
+    want, res = _oracle_grads(inp, g_out, qpos.long().cpu(), kpos.long().cpu())
+
+    q, k, v = (g[x].clone().requires_grad_(True) for x in ("q", "k", "v"))
+    w = g["w_rpe_weight"].clone().requires_grad_(True)
+    ow, ob = g["out_weight"].clone().requires_grad_(True), g["out_bias"].clone().requires_grad_(True)
+    acc = HeptPartialSums.apply(q, k, v, g["coords"], RpeScale.apply(w, h, d, kk), g["alpha"], g["combined_shifts"], b, None)
+    out = HeptCombine.apply(acc, ow, ob)
+    out.backward(g_out.to(dev))
+    assert _close(out.detach().cpu(), res["out"].detach(), rel=1e-4)
+    assert _close(q.grad.cpu(), want["q"]) and _close(k.grad.cpu(), want["k"]) and _close(v.grad.cpu(), want["v"])
+    assert _close(w.grad.cpu(), want["w_rpe_weight"], rel=1e-3)
+    assert _close(ow.grad.cpu(), want["out_weight"]) and _close(ob.grad.cpu(), want["out_bias"])
