@@ -239,8 +239,7 @@ def test_tracking_60k_full_size(precision, gpu_device):
     out2 = _forward(g2, inp, precision)
     bias = g["out_bias"]
     torch.testing.assert_close(out2 - bias, 2.0 * (out - bias), rtol=1e-4 if precision == "fp32" else 2e-3, atol=1e-5)
-    # (5) checksum of checksums vs the full oracle would take minutes on CPU: compare against the
-    #     oracle on the sampled rows' blocks instead -> done in (3); denominators must be positive
+    # (5) every row against the full oracle: test_bench_workloads_all_rows_vs_oracle; denominators must be positive
     assert bool((ops.unpack_part(st["part"])[..., d] > 0).all())
 
 
@@ -320,3 +319,25 @@ def test_split_bf16_products_match_the_f32_mfma_kernel(name, gpu_device):
     a = _forward(g, inp, "fp32").cpu()
     b = _forward(g, inp, "fp32_mfma").cpu()
     assert _rows_ok(a, b, ATOL.get(name, 1e-5), 1e-4) >= 0.995
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("workload", ["tracking-60k", "pileup-8clouds"])
+def test_bench_workloads_all_rows_vs_oracle(workload, precision, gpu_device):
+    """The exact inputs bench.py times (hept_amd.synthetic.workload_inputs, seed 0), full size, EVERY output row against
+    the oracle (a few seconds of CPU at 60k points): tie-aware row criterion as in the end-to-end test."""
+    from hept_amd.synthetic import WORKLOADS, workload_inputs
+
+    inp = workload_inputs(workload, seed=0)
+    b = WORKLOADS[workload]["block_size"]
+    g = _gpu(inp, gpu_device)
+    out = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
+                      g["out_weight"], g["out_bias"], block_size=b, w_per_dist=10, precision=precision).cpu()
+    orc = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
+                     inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=b, w_per_dist=10, keep=False,
+                     **_model_kw(precision))["out"]
+    assert bool(torch.isfinite(out).all())
+    if precision == "fp32":
+        assert _rows_ok(out, orc, 1e-5, 1e-4) >= 0.995
+    else:
+        assert _rows_ok(out, orc, atol=5e-3, rtol=8e-3) >= 0.995
