@@ -160,3 +160,25 @@ def test_src_argument_errors(gpu_device):
     with pytest.raises(ValueError):     # region indices of the wrong shape
         ops.forward_src(g["q"], g["k"], g["v"], g["coords"], (g["eta_idx"][:, :-1], g["phi_idx"]), g["regions_h"],
                         1000, g["w_rpe_weight"], g["alpha"], g["out_weight"], g["out_bias"], **kw)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_src_full_size_all_rows_vs_oracle(precision, gpu_device):
+    """src variant at tracking-60k size (60 000 real points + 32 padding rows, block 128, 3 tables): every real row
+    against the oracle."""
+    from hept_amd.synthetic import make_inputs_src
+
+    inp = make_inputs_src(60000, block_size=128, n_hashes=3, seed=4)
+    inp["block_size"], inp["w_per_dist"] = 128, 10
+    g = _gpu(inp, gpu_device)
+    raw = inp["raw_size"]
+    out = ops.forward_src(g["q"], g["k"], g["v"], g["coords"], (g["eta_idx"], g["phi_idx"]), g["regions_h"], raw,
+                          g["w_rpe_weight"], g["alpha"], g["out_weight"], g["out_bias"], block_size=128, w_per_dist=10,
+                          precision=precision).cpu()
+    kw = dict(tile_dtype=torch.bfloat16) if precision == "bf16" else {}
+    want = _oracle(inp, keep=False, **kw)["out"]
+    assert bool(torch.isfinite(out).all())
+    if precision == "fp32":
+        assert _rows_ok(out[:raw], want[:raw], 1e-5) >= 0.995
+    else:
+        assert _rows_ok(out[:raw], want[:raw], atol=5e-3, rtol=8e-3) >= 0.995
