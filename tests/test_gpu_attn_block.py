@@ -134,3 +134,31 @@ def test_attn_block_under_torch_compile_is_one_graph(gpu_device):
         torch._dynamo.reset()
         out = torch.compile(blk, backend="aot_eager", fullgraph=True)(x, kwargs)
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_attn_block_full_size_vs_oracle(precision, gpu_device):
+    """The fused block at tracking-60k size (the weights of case A2, the coordinates / AND codes of the bench workload,
+    random x): every row against the oracle's block."""
+    from hept_amd.synthetic import workload_inputs
+
+    a2, _ = cases.load_case_attn("a2_attn_rand")
+    wl = workload_inputs("tracking-60k", seed=0)
+    n = wl["coords"].shape[0]
+    inp = {"x": torch.randn(n, 24, generator=torch.Generator().manual_seed(21)), "coords": wl["coords"],
+           "combined_shifts": wl["combined_shifts"], "params": a2["params"], "block_size": 128, "w_per_dist": 10}
+    dev = gpu_device
+    blk = Attn(inp["coords"].shape[1], precision=precision, h_dim=24, num_heads=8, block_size=128, n_hashes=3,
+               num_w_per_dist=10, n_layers=4)
+    blk.load_state_dict(inp["params"], strict=True)
+    blk = blk.to(dev).eval()
+    with torch.no_grad():
+        y = blk(inp["x"].to(dev), {"coords": inp["coords"].to(dev), "combined_shifts": inp["combined_shifts"].to(dev)}).cpu()
+    want = _oracle(inp)["y"]
+    assert y.shape == want.shape and bool(torch.isfinite(y).all())
+    err = (y - want).abs()
+    if precision == "fp32":
+        assert float((err <= 2e-5 + 1e-4 * want.abs()).all(-1).float().mean()) >= 0.97
+    else:
+        assert float((err.amax(-1) <= 2.5e-2 * (want.abs().amax(-1) + 1)).float().mean()) >= 0.97
+    assert float((err.amax(-1) <= 5e-2 * (want.abs().amax(-1) + 1)).float().mean()) >= 0.995
