@@ -57,44 +57,48 @@ __device__ __forceinline__ int cloud_of(const int* __restrict__ cloud_start, int
     return lo;
 }
 
-// phase 0: max eta region per row; phase 1: max of (phi << bits_eta | eta) per row; phase 2: final codes
-template <int PHASE>
+// final codes of one (table, head) row: (cloud << bits1) | (phi_region << bits0) | eta_region, the bit widths from
+// row_bits_kernel
 __global__ __launch_bounds__(PT) void codes_kernel(const int* __restrict__ rank, const int* __restrict__ cloud_start,
                                                    int n_clouds, int n_raw, const float* __restrict__ regions, int T,
-                                                   int H, int* __restrict__ row_max /* [2][T*H] */,
+                                                   int H, const int* __restrict__ row_max /* [2][T*H] */,
                                                    int64_t* __restrict__ codes_raw) {
     const int row = blockIdx.y, t = row / H, h = row % H;
-    int val = 0;
-    // grid-stride: the reduction phases run with few workgroups per row (one atomic each: hundreds of atomics on
-    // one address were the whole cost of these phases)
-    for (int n = blockIdx.x * PT + threadIdx.x; n < n_raw; n += gridDim.x * PT) {
-        const int c = cloud_of(cloud_start, n_clouds, n);
+    const int n = blockIdx.x * PT + threadIdx.x;
+    if (n >= n_raw) return;
+    const int c = cloud_of(cloud_start, n_clouds, n);
+    const int n_c = cloud_start[c + 1] - cloud_start[c];
+    const int eta = region_of(rank[n], n_c, regions[((size_t)t * 2 + 0) * H + h]);
+    const int phi = region_of(rank[(size_t)n_raw + n], n_c, regions[((size_t)t * 2 + 1) * H + h]);
+    const int p1 = (phi << bit_length(row_max[row])) | eta;
+    codes_raw[(size_t)row * n_raw + n] = ((int64_t)c << bit_length(row_max[(size_t)T * H + row])) | (int64_t)p1;
+}
+
+// Largest region ids of a row without touching the points: ranks run 0 .. n_c - 1 in every cloud and region_of is
+// monotone in the rank, so the row maximum is the maximum over the clouds of region_of(n_c - 1).  The packing only
+// needs bit lengths: bit_length((phi << b) | eta) = bit_length(phi) + b for phi >= 1 (region ids start at 1), so
+// row_max[1][row] = (phi_max << b) | eta_max has the bit length of the true maximum of the packed values.
+__global__ __launch_bounds__(64) void row_bits_kernel(const int* __restrict__ cloud_start, int n_clouds,
+                                                      const float* __restrict__ regions, int T, int H,
+                                                      int* __restrict__ row_max /* [2][T*H] */) {
+    const int row = blockIdx.x, t = row / H, h = row % H;
+    const float r_eta = regions[((size_t)t * 2 + 0) * H + h], r_phi = regions[((size_t)t * 2 + 1) * H + h];
+    int eta = 0, phi = 0;
+    for (int c = threadIdx.x; c < n_clouds; c += 64) {
         const int n_c = cloud_start[c + 1] - cloud_start[c];
-        const int eta = region_of(rank[n], n_c, regions[((size_t)t * 2 + 0) * H + h]);
-        if (PHASE == 0) {
-            val = max(val, eta);
-        } else {
-            const int phi = region_of(rank[(size_t)n_raw + n], n_c, regions[((size_t)t * 2 + 1) * H + h]);
-            const int p1 = (phi << bit_length(row_max[row])) | eta;
-            if (PHASE == 1) {
-                val = max(val, p1);
-            } else {
-                codes_raw[(size_t)row * n_raw + n] =
-                    ((int64_t)c << bit_length(row_max[(size_t)T * H + row])) | (int64_t)p1;
-            }
+        if (n_c > 0) {
+            eta = max(eta, region_of(n_c - 1, n_c, r_eta));
+            phi = max(phi, region_of(n_c - 1, n_c, r_phi));
         }
     }
-    if (PHASE == 2) return;
-    // workgroup max -> one atomic per workgroup
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) val = max(val, __shfl_xor(val, off));
-    __shared__ int red_s[PT / HEPT_WAVE];
-    if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = val;
-    __syncthreads();
+    for (int off = 32; off >= 1; off >>= 1) {
+        eta = max(eta, __shfl_xor(eta, off));
+        phi = max(phi, __shfl_xor(phi, off));
+    }
     if (threadIdx.x == 0) {
-        int m = red_s[0];
-        for (int i = 1; i < PT / HEPT_WAVE; ++i) m = max(m, red_s[i]);
-        atomicMax(&row_max[(size_t)PHASE * T * H + row], m);
+        row_max[row] = eta;
+        row_max[(size_t)T * H + row] = (phi << bit_length(eta)) | eta;
     }
 }
 
@@ -196,13 +200,8 @@ extern "C" int hept_prepare_input(const float* coords, int C, const int32_t* clo
     int rc = hept_segmented_argsort_ragged(keys, S, L, seg_len, sort_ws, pos, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(rank_scatter_kernel, gridL, dim3(PT), 0, st, pos, cloud_start, L, n_raw, rank);
-    if (hipMemsetAsync(row_max, 0, (size_t)2 * rows * 4, st) != hipSuccess) return HEPT_ERR_LAUNCH;
-    const dim3 gridR(gridN.x < 8 ? gridN.x : 8, rows);  // reduction phases: <= 8 atomics per row
-    hipLaunchKernelGGL(codes_kernel<0>, gridR, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
-                       codes_raw);
-    hipLaunchKernelGGL(codes_kernel<1>, gridR, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
-                       codes_raw);
-    hipLaunchKernelGGL(codes_kernel<2>, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
+    hipLaunchKernelGGL(row_bits_kernel, dim3(rows), dim3(64), 0, st, cloud_start, n_clouds, regions, T, H, row_max);
+    hipLaunchKernelGGL(codes_kernel, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
                        codes_raw);
     hipLaunchKernelGGL(code_keys_kernel, dim3((n_raw + PT - 1) / PT), dim3(PT), 0, st, codes_raw, n_raw, ckeys);
     rc = hept_segmented_argsort(ckeys, 1, n_raw, sort_ws, by_code, stream);
