@@ -1,0 +1,43 @@
+"""bench.py's output contract (-m gpu): exactly one line on stdout, valid JSON, every key the driver reads; the
+forced-exchange path (1-rank RCCL group) keeps stdout clean of RCCL's banner."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"}
+
+
+def _run(*args):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", *args],
+                         capture_output=True, text=True, env=env, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, run.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("precision,bound,dtype", [("bf16", "hbm", "bf16"), ("fp32", "mfma", "f32")])
+def test_bench_line(precision, bound, dtype, gpu_device):
+    d = _run("--precision", precision, "--no-cpu-baseline")
+    assert KEYS <= set(d) and ROOF <= set(d["roofline"])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["metric"] == "attention-fwd points/sec" and d["unit"] == "points/s" and d["scaling"] == "weak"
+    assert d["dtype"] == dtype and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "tracking-60k" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == bound and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 1e7 < d["value"] < 1e10 and abs(d["value"] - 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_bench_line_with_the_exchange_forced_on(gpu_device):
+    d = _run("--force-dist", "--no-cpu-baseline")
+    assert KEYS <= set(d) and "exchange" in d["config"]["parallelism"]
