@@ -4,13 +4,20 @@
 One "step" = one ``HEPTAttention.forward`` (the whole hot path: E2LSH hash -> sort -> block
 attention -> combine + out_linear) over one synthetic tracking-60k cloud whose inputs are already
 resident in HBM.  N = 1: BASELINE config 3 (N_raw 60000 -> 60032 padded, block 128, n_hashes 3,
-bf16 MFMA tiles).  N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling
-over hash tables — every GPU keeps 3 tables (n_hashes = 3·N in total), inputs replicated, ONE
-exchange step (all-to-all of the packed per-rank table sums + all-gather of the output).
+bf16 MFMA tiles).  N > 1: weak scaling over hash tables — every GPU keeps 3 tables (n_hashes = 3·N
+in total), inputs replicated, one exchange (all-to-all of the packed per-rank table sums, pipelined
+by head groups behind the block attention, + all-gather of the output).
 ``value`` = points/s normalised to 3 table passes per point: N_gpus · N_raw / step time.
-``--tables-per-gpu 1`` is BASELINE config 4 (n_hashes = #GPUs, one table per GPU).
 
-Prints ONE JSON line on rank 0; see DESIGN.md §6 for every field.
+Launching: ``python bench.py --gpus N`` works on its own — with ``WORLD_SIZE`` unset and N > 1 this
+process starts N children (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment)
+*before it makes any GPU call*, never touches the GPU itself, relays rank 0's JSON line and exits
+non-zero if any child failed.  Under ``torch.distributed.run`` (WORLD_SIZE set) it is a rank.
+
+Beside the headline the line carries: ``fp32`` (N = 1: the reference-precision run of the same
+workload, measured in the same process after the bf16 region), ``c4`` (BASELINE config 4: one table
+per GPU, n_hashes = N), ``roofline`` (HBM bound, dominant kernel, HIP events on the launch stream)
+and ``cpu_baseline`` (N = 1).  See DESIGN.md §6 for every field.
 """
 from __future__ import annotations
 
@@ -18,21 +25,106 @@ import argparse
 import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 WORKLOAD = "tracking-60k"
-EVENT_STRIDE = int(os.environ.get("HEPT_BENCH_EVENT_STRIDE", "16"))
 TABLES_PER_GPU = 3
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_F32_PEAK_TF = 157.3   # dense f32-input MFMA
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA (both the bf16 and the split-bf16 f32 kernel issue bf16 MFMAs)
+B, H, D = 128, 8, 24
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    # defaults: 500 steps = 0.1 s of GPU time; 100-step regions (20 ms) scatter by +-2 % from run to run on one box
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--tables-per-gpu", type=int, default=TABLES_PER_GPU,
+                    help="hash tables per GPU (default 3 = BASELINE config 3 at N=1; 1 = config 4: n_hashes = #GPUs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the fp32 and c4 sub-records")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (process group, exchange step, barriers) even with one rank: a self-check")
+    ap.add_argument("--stages", action="store_true", help="also print a per-stage HIP-event breakdown to stderr")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher (no GPU)
+def launch(args) -> int:
+    """Start one child per GPU and relay rank 0's line.  Nothing here may touch the GPU: a process that has
+    initialised HIP must not be the parent of the ranks' device contexts (and must never exec)."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(port), HEPT_BENCH_CHILD="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout is the JSON line; the other ranks' stdout goes to stderr so that stdout stays one line
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    out0 = b""
+    failed = None
+    try:
+        alive = set(range(n))
+        # read rank 0's pipe without blocking the watch on the others
+        os.set_blocking(procs[0].stdout.fileno(), False)
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is not None:
+                    alive.discard(r)
+                    if rc != 0 and failed is None:
+                        failed = (r, rc)
+            try:
+                chunk = procs[0].stdout.read()
+                if chunk:
+                    out0 += chunk
+            except (BlockingIOError, ValueError):
+                pass
+            if failed is not None:
+                break
+            time.sleep(0.02)
+    finally:
+        for p in procs:  # exact PIDs only
+            if p.poll() is None:
+                if failed is not None:
+                    p.terminate()
+                try:
+                    p.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+    try:
+        rest = procs[0].stdout.read()
+        if rest:
+            out0 += rest
+    except (BlockingIOError, ValueError):
+        pass
+    if failed is not None:
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}", file=sys.stderr)
+        sys.stderr.write(out0.decode(errors="replace"))
+        return failed[1] if failed[1] > 0 else 1
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------ rank body
 def algorithmic_bytes(n, h, d, c, t, tile_bytes):
     """gather reads of q^,k^,v rows + per-table numer/denom writes, per block_attn launch."""
     e = d + c
@@ -45,6 +137,8 @@ def algorithmic_flops(n, h, d, c, t, b):
 
 def cpu_baseline(inp, block_size, min_seconds=10.0):
     """The oracle (CPU restatement of the reference, fp32, all host threads) timed on this box: kind 'port'."""
+    import torch
+
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hept_oracle as ho
 
@@ -98,34 +192,41 @@ def c_stdout_to_stderr():
         os.close(saved)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 500 steps = 0.1 s of GPU time; 100-step regions (20 ms) scatter by +-2 % from run to run on one box
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--tables-per-gpu", type=int, default=TABLES_PER_GPU,
-                    help="hash tables per GPU (default 3 = BASELINE config 3 at N=1; 1 = config 4: n_hashes = #GPUs)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="run the N>1 code path (process group, exchange step, barriers) even with one rank: a self-check")
-    ap.add_argument("--stages", action="store_true", help="also print a per-stage HIP-event breakdown to stderr")
-    args = ap.parse_args()
+def pmc_record(precision):
+    """Per-launch PMC figures of the block-attention kernel from profiles/attn_traffic.json (tools/pmc.sh passes):
+    HBM traffic in bytes and the fraction of the kernel's cycles the matrix pipe was busy."""
+    tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
+    try:
+        rec = json.load(open(tpath))
+    except Exception:  # noqa: BLE001
+        return None, None
+    return rec.get(precision), rec.get(precision + "_mfma_busy_frac")
+
+
+def worker(args) -> int:
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("HEPT_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        raise SystemExit(f"rank {rank}: HEPT_BENCH_FAIL_RANK set")
     # self-check hooks (never set by the driver): HEPT_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL refuses
     # that), HEPT_BENCH_EXCHANGE forces an exchange mode -- together they run the whole N>1 code path on a 1-GPU box
     backend = os.environ.get("HEPT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU: hept_amd has no CPU path")
+    if backend == "nccl" and n_dev < world:
+        raise SystemExit(f"--gpus {world} but only {n_dev} GPU(s) are visible (RCCL needs one device per rank)")
+    dev_index = local_rank % n_dev if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     group = None
     multi = world > 1 or args.force_dist
+    dist = None
     if multi:
         import torch.distributed as dist
 
@@ -143,64 +244,104 @@ def main():
     from hept_amd import HEPTAttention, ops
     from hept_amd.synthetic import workload_inputs
 
-    tables_per_gpu = args.tables_per_gpu
-    n_tables = tables_per_gpu * world
-    inp = workload_inputs(WORKLOAD, seed=0, n_hashes=n_tables)
-    B, H, D = 128, 8, 24
-    C = inp["coords"].shape[1]
-    n, n_raw = inp["q"].shape[0], inp["n_raw"]
-    g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
-
-    attn = HEPTAttention(D + C, h_dim=D, num_heads=H, block_size=B, n_hashes=n_tables, num_w_per_dist=10,
-                         precision=args.precision, process_group=group)
-    attn.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
-                          "e2lsh.alpha": inp["alpha"]}, strict=True)
-    attn = attn.to(dev).eval()
-    if args.force_dist and world == 1:
-        attn.sharding.always_exchange = True
-    if multi and os.environ.get("HEPT_BENCH_EXCHANGE"):
-        attn.sharding.mode = os.environ["HEPT_BENCH_EXCHANGE"]
-    w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(dev)
-    with torch.no_grad():
-        w_rpe.weight.copy_(g["w_rpe_weight"])
-    kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
-
-    def step():
-        with torch.no_grad():
-            return attn(g["q"], g["k"], g["v"], **kw)
-
     def fence():
         torch.cuda.synchronize()
         if multi:
-            torch.distributed.barrier()
+            dist.barrier()
             torch.cuda.synchronize()
 
+    def build(tables_per_gpu, precision):
+        n_tables = tables_per_gpu * world
+        inp = workload_inputs(WORKLOAD, seed=0, n_hashes=n_tables)
+        g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+        c = inp["coords"].shape[1]
+        attn = HEPTAttention(D + c, h_dim=D, num_heads=H, block_size=B, n_hashes=n_tables, num_w_per_dist=10,
+                             precision=precision, process_group=group)
+        attn.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
+                              "e2lsh.alpha": inp["alpha"]}, strict=True)
+        attn = attn.to(dev).eval()
+        if args.force_dist and world == 1:
+            attn.sharding.always_exchange = True
+        if multi and os.environ.get("HEPT_BENCH_EXCHANGE"):
+            attn.sharding.mode = os.environ["HEPT_BENCH_EXCHANGE"]
+        w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(dev)
+        with torch.no_grad():
+            w_rpe.weight.copy_(g["w_rpe_weight"])
+        kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+
+        def step():
+            with torch.no_grad():
+                return attn(g["q"], g["k"], g["v"], **kw)
+
+        return inp, attn, step
+
+    def launches_per_step(attn):
+        """block_attn launches per forward: the pipelined exchange runs the block attention one head group at a time"""
+        sh = attn.sharding
+        if sh is not None and sh.mode == "all_to_all" and (sh.world > 1 or sh.always_exchange):
+            return sh.groups_for(H)
+        return 1
+
+    def measure(step, steps, warmup, launches=1):
+        """W untimed steps, then exactly K steps between fences; HIP events around block_attn on the launch stream for
+        a sample of the steps (an event pair costs stream time, so the stride keeps >= 90 % of the steps bare).
+        Returns (elapsed s, mean block_attn ms per step, event samples)."""
+        for _ in range(warmup):
+            step()
+        stride = max(1, min(16, steps // 32)) if steps >= 64 else max(1, steps // 8)
+        ops.profile_enable(1, steps * launches, stride=stride * launches + (1 if launches > 1 else 0))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        stage_ms, n_rec = ops.profile_read()
+        ops.profile_enable(0)
+        if multi:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt)
+        return elapsed, stage_ms["block_attn"] / max(n_rec, 1) * launches, n_rec
+
+    def roofline(n, c, tables, precision, attn_ms, n_rec):
+        """HBM roofline of the block-attention kernel: algorithmic bytes per launch / mean launch duration.  The f32
+        kernel issues bf16 MFMAs (split products) and is bound by its gathers and scatters as well, so both precisions
+        are priced against HBM; ``mfma_busy_frac`` (PMC, profiles/) is the matrix pipe's share of the kernel's cycles."""
+        tile_bytes = 2 if precision == "bf16" else 4
+        nbytes = algorithmic_bytes(n, H, D, c, tables, tile_bytes)
+        ach = nbytes / (attn_ms * 1e-3) / 1e9
+        traffic, busy = pmc_record(precision)
+        flops = algorithmic_flops(n, H, D, c, tables, B)
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "kernel": "block_attn_kernel" if precision == "bf16" else "block_attn_split_kernel",
+                "kernel_ms": attn_ms, "event_samples": n_rec, "algorithmic_bytes": nbytes, "traffic": traffic,
+                "mfma_busy_frac": busy,
+                "algorithmic_tflops": flops / (attn_ms * 1e-3) / 1e12, "mfma_bf16_peak_tflops": MFMA_BF16_PEAK_TF}
+
+    # ---------------------------------------------------------------------------------------------- headline region
+    tables_per_gpu = args.tables_per_gpu
+    inp, attn, step = build(tables_per_gpu, args.precision)
+    n, n_raw, C = inp["q"].shape[0], inp["n_raw"], inp["coords"].shape[1]
     if multi:
-        # first sharded step: if this RCCL build rejects the all-to-all of packed rows, fall back to the reduce-scatter
-        # exchange (f32 rows) rather than lose the measurement; the mode used is reported in config.parallelism
+        # first sharded step; the ranks agree on the exchange mode (a rank-local failure must not leave the others
+        # inside a collective of a different kind): MAX of a failure flag over the group
+        failed = 0
         try:
             step()
             torch.cuda.synchronize()
         except Exception as exc:  # noqa: BLE001
-            print(f"[rank {rank}] all_to_all exchange failed ({exc!r}); using reduce_scatter", file=sys.stderr)
+            print(f"[rank {rank}] {attn.sharding.mode} exchange failed ({exc!r})", file=sys.stderr)
+            failed = 1
+        flag = torch.tensor([failed], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag) != 0:
+            if attn.sharding.mode == "reduce_scatter":
+                raise SystemExit("sharded step failed in reduce_scatter mode as well")
             attn.sharding.mode = "reduce_scatter"
-    for _ in range(args.warmup):
-        step()
-    # HIP events around block_attn on the launch stream, inside the timed region; every 16th step only: an
-    # event pair costs ~12 us of stream time per step, sampling keeps `value` within 0.5 % of un-instrumented
-    ops.profile_enable(1, args.steps, stride=EVENT_STRIDE)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    stage_ms, n_rec = ops.profile_read()
-    ops.profile_enable(0)
-    if multi:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt)
+            step()
+            torch.cuda.synchronize()
+    elapsed, attn_ms, n_rec = measure(step, args.steps, args.warmup, launches_per_step(attn))
     ms_per_step = elapsed / args.steps * 1e3
 
     if args.stages and rank == 0:
@@ -212,18 +353,9 @@ def main():
         ops.profile_enable(0)
         print("stage ms/step:", {k: round(v / cnt, 4) for k, v in all_ms.items()}, file=sys.stderr)
 
+    line = None
     if rank == 0:
-        tile_bytes = 2 if args.precision == "bf16" else 4
-        attn_ms = stage_ms["block_attn"] / max(n_rec, 1)
-        if args.precision == "bf16":
-            ach = algorithmic_bytes(n, H, D, C, tables_per_gpu, tile_bytes) / (attn_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-        else:
-            ach = algorithmic_flops(n, H, D, C, tables_per_gpu, B) / (attn_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF}
-        # f32 tiles run as split-bf16 products (6 bf16 MFMAs per f32 product): algorithmic f32 flops against the f32 peak
-        roof["kernel"] = "block_attn_kernel" if args.precision == "bf16" else "block_attn_split_kernel"
-        roof["kernel_ms"] = attn_ms
+        roof = roofline(n, C, tables_per_gpu, args.precision, attn_ms, n_rec)
         # what an event pair around NOTHING reads on this stream: the bracket's own cost is inside kernel_ms (the
         # rocprofv3 kernel trace in profiles/ shows the kernel itself shorter by about this much)
         gaps = []
@@ -234,14 +366,7 @@ def main():
             torch.cuda.synchronize()
             gaps.append(e0.elapsed_time(e1))
         roof["event_pair_overhead_ms"] = sorted(gaps)[len(gaps) // 2]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.precision)
-            except Exception:
-                traffic = None
-        roof["traffic"] = traffic
+        n_tables = tables_per_gpu * world
         line = {
             "metric": "attention-fwd points/sec", "value": world * n_raw / (elapsed / args.steps), "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -250,16 +375,54 @@ def main():
             "config": {"workload": f"{WORKLOAD}: N_raw={n_raw} padded N={n}, block_size={B}, n_hashes={tables_per_gpu}/GPU "
                                    f"({n_tables} total), H={H}, D={D}, C={C}, tiles {args.precision}",
                        "parallelism": f"tables sharded {tables_per_gpu}/GPU over {world} GPU(s)" +
-                                      (f", exchange {attn.sharding.mode}" if multi else ""),
-                       "hbm_algorithmic_GBps_block_attn": algorithmic_bytes(n, H, D, C, tables_per_gpu, tile_bytes) / (attn_ms * 1e-3) / 1e9},
+                                      (f", exchange {attn.sharding.describe()}" if multi else ""),
+                       "rccl_ranks": (dist.get_world_size() if multi and backend == "nccl" else 0),
+                       "hbm_algorithmic_GBps_block_attn": roof["achieved"]},
             "roofline": roof,
         }
+    del attn, step
+
+    # ------------------------------------------------------------------------------------------------- sub-records
+    if not args.no_extra:
+        sub_steps = max(20, min(args.steps, 200))
+        sub_warm = max(3, min(args.warmup, 10))
+        if world == 1 and not args.force_dist and args.precision == "bf16":
+            # reference precision (f32 tiles) on the same workload, same process
+            _, attn32, step32 = build(tables_per_gpu, "fp32")
+            el, ams, nrec = measure(step32, sub_steps, sub_warm)
+            line["fp32"] = {"ms_per_step": el / sub_steps * 1e3, "value": n_raw / (el / sub_steps), "unit": "points/s",
+                            "steps": sub_steps, "dtype": "f32", "roofline": roofline(n, C, tables_per_gpu, "fp32", ams, nrec)}
+            del attn32, step32
+        if tables_per_gpu != 1:
+            # BASELINE config 4: n_hashes = #GPUs, one table per GPU (at N = 1 a single table)
+            _, attn4, step4 = build(1, args.precision)
+            if multi:
+                step4()
+                torch.cuda.synchronize()
+            el, ams, nrec = measure(step4, sub_steps, sub_warm, launches_per_step(attn4))
+            if rank == 0:
+                line["c4"] = {"workload": f"{WORKLOAD}, n_hashes={world} sharded 1 per GPU over {world} GPU(s)",
+                              "ms_per_step": el / sub_steps * 1e3, "value": world * n_raw / (el / sub_steps),
+                              "unit": "points/s (N_gpus * N_raw / step time, one table pass per point and GPU)",
+                              "steps": sub_steps,
+                              "block_attn_ms": ams}
+            del attn4, step4
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(inp, B)
         print(json.dumps(line), flush=True)
     if multi:
         with c_stdout_to_stderr():
-            torch.distributed.destroy_process_group()
+            dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 # (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
@@ -40,7 +40,13 @@ SIGNATURES = {
     "hept_segmented_argsort_ragged": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "hept_segmented_argsort": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "hept_block_attn": (c_int, [_P] * 4 + [c_int] * 6 + [_P, _P]),
+    "hept_block_attn_heads": (c_int, [_P] * 4 + [c_int] * 11 + [_P, _P]),
     "hept_part_precision": (c_int, [c_int, c_int]),
+    "hept_reduce_heads": (c_int, [_P] + [c_int] * 8 + [_P, c_int, _P]),
+    "hept_combine_groups": (c_int, [_P] + [c_int] * 8 + [c_size_t] + [_P] * 4),
+    "hept_partial_begin": (c_int, [_P] * 7 + [c_int] * 10 + [_P, c_size_t, _P]),
+    "hept_partial_begin_src": (c_int, [_P] * 7 + [c_int] + [_P] * 2 + [c_int] * 10 + [_P, c_size_t, _P]),
+    "hept_partial_heads": (c_int, [_P, c_size_t] + [c_int] * 11 + [_P, _P]),
     "hept_reduce_tables": (c_int, [_P] + [c_int] * 5 + [_P, c_int, _P]),
     "hept_combine_out": (c_int, [_P] + [c_int] * 7 + [_P] * 4),
     "hept_forward": (c_int, [_P] * 9 + [c_int] * 8 + [_P, c_size_t, _P, _P]),

@@ -14,7 +14,46 @@ import torch
 
 from . import ops
 
-__all__ = ["HeptPartialSums", "HeptCombine", "RpeScale", "rpe_scale_torch"]
+__all__ = ["HeptPartialSums", "HeptCombine", "RpeScale", "rpe_scale_torch", "ReplicatedGrad", "sum_over_ranks"]
+
+
+class ReplicatedGrad(torch.autograd.Function):
+    """Identity on a tensor that every rank holds a copy of; the backward sums the ranks' gradient contributions
+    (each rank differentiates only its own hash tables)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+class _SumOverRanks(torch.autograd.Function):
+    """All-reduce (sum) whose result feeds the same computation on every rank: the gradient of the sum with respect to
+    this rank's term is the (replicated) upstream gradient itself."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+
+        y = x.contiguous().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def sum_over_ranks(x, group):
+    return _SumOverRanks.apply(x, group)
 
 
 def rpe_scale_torch(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dist: int) -> torch.Tensor:
@@ -51,7 +90,7 @@ class HeptPartialSums(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, q, k, v, coords, sqrt_w, alpha, codes, block_size, geo=None):
+    def forward(ctx, q, k, v, coords, sqrt_w, alpha, codes, block_size, geo=None, f32_mfma=False):
         n, hd = q.shape
         h = alpha.shape[0]
         d = hd // h
@@ -62,8 +101,9 @@ class HeptPartialSums(torch.autograd.Function):
             eta, phi, cfac, raw_size = geo
             ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, None, "fp32", raw_size=raw_size)
             qpos, kpos = ops.sort_tables_src(ph["qproj"], ph["kproj"], eta, phi, cfac, ph["minmax"])
-        part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, block_size)
+        part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, block_size, f32_mfma=f32_mfma)
         acc = ops.reduce_tables(part, d)
+        ctx.f32_mfma = f32_mfma
         ctx.save_for_backward(ph["qhat"], ph["kvhat"], qpos, kpos, coords, sqrt_w)
         ctx.dims = (d, coords.shape[1], block_size)
         ctx.raw_size = n if geo is None else int(geo[3])
@@ -77,11 +117,11 @@ class HeptPartialSums(torch.autograd.Function):
         # reduction kernel (as a torch einsum it was a 48 x N GEMM that rocBLAS ran in 320 us, as a product + column
         # sum two kernels of 27 us); rows at and after raw_size (src variant padding) get zero gradients there too
         dq, dk, dv, dcs, dsw = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size,
-                                                  coords=coords, raw_size=ctx.raw_size)
+                                                  f32_mfma=ctx.f32_mfma, coords=coords, raw_size=ctx.raw_size)
         if not ctx.needs_input_grad[4]:
             dsw = None
         dcoords = (dcs * sqrt_w[None]).sum(dim=1) if ctx.needs_input_grad[3] else None
-        return dq, dk, dv, dcoords, dsw, None, None, None, None
+        return dq, dk, dv, dcoords, dsw, None, None, None, None, None
 
 
 class HeptCombine(torch.autograd.Function):

@@ -44,7 +44,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
                                                               const int* __restrict__ qpos,
                                                               const int* __restrict__ kpos,
                                                               float* __restrict__ part, int N, int H, int D, int B,
-                                                              int nb) {
+                                                              int nb, HeadRange hr) {
     constexpr int NT = 64 * NKT;
     constexpr int KEYS = 32 * NKT;
     constexpr int ESZ = BF16 ? 2 : 4;
@@ -62,8 +62,8 @@ void block_attn_kernel(const char* __restrict__ qhat,
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int bid = blockIdx.x;
-    const int h = bid % H;
-    const int rest = bid / H;
+    const int h = hr.h0 + bid % hr.hg;
+    const int rest = bid / hr.hg;
     const int b = rest % nb, t = rest / nb;
     const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
     const int* __restrict__ kp = kpos + seg;
@@ -188,7 +188,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
         // ---- scatter, 64-B rows: even lane 2i packs columns (2i, 2i+1) as bf16 -> dword i (i < 12);
         //      lane 24 holds the denominator (f32, dword 12); lanes 26..30 write the zero padding
         unsigned int* __restrict__ pt =
-            reinterpret_cast<unsigned int*>(part) + (size_t)t * N * H * 16 + (size_t)h * 16 + (li >> 1);
+            reinterpret_cast<unsigned int*>(part) + (size_t)t * hr.tstride_rows * 16 + (size_t)(h - hr.hsub) * 16 + (li >> 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float mine = z[r];
@@ -200,12 +200,12 @@ void block_attn_kernel(const char* __restrict__ qhat,
                 unsigned int word = hept_pack_bf16(mine, nbr);
                 if (li == D) word = __float_as_uint(mine + 1e-20f);  // example/hept.py:14 (D is even)
                 if (li > D) word = 0u;
-                pt[(size_t)dst * H * 16] = word;
+                pt[(size_t)dst * hr.hout * 16] = word;
             }
         }
     } else {
         // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
-        float* __restrict__ pt = part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
+        float* __restrict__ pt = part + (size_t)t * hr.tstride_rows * 32 + (size_t)(h - hr.hsub) * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q2 = w * 32 + hept_acc_row(r, hh);
@@ -213,7 +213,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
                 const int dst = qidx_s[q2];
                 float val = z[r];
                 if (li == D) val += 1e-20f;  // example/hept.py:14
-                pt[(size_t)dst * H * 32] = val;
+                pt[(size_t)dst * hr.hout * 32] = val;
             }
         }
     }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
                                                                     const int* __restrict__ qpos,
                                                                     const int* __restrict__ kpos,
                                                                     float* __restrict__ part, int N, int H, int D,
-                                                                    int B, int nb) {
+                                                                    int B, int nb, HeadRange hr) {
     constexpr int NT = 64 * NKT;
     constexpr int KEYS = 32 * NKT;
     constexpr int PROW = 64;                    // bytes of one 32-column bf16 plane row
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int bid = blockIdx.x;
-    const int h = bid % H;
-    const int rest = bid / H;
+    const int h = hr.h0 + bid % hr.hg;
+    const int rest = bid / hr.hg;
     const int b = rest % nb, t = rest / nb;
     const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
     const int* __restrict__ kp = kpos + seg;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     }
 
     // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
-    float* __restrict__ pt = part + (size_t)t * N * H * 32 + (size_t)h * 32 + li;
+    float* __restrict__ pt = part + (size_t)t * hr.tstride_rows * 32 + (size_t)(h - hr.hsub) * 32 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int q2 = w * 32 + hept_acc_row(r, hh);
@@ -411,28 +411,24 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
         if (FULL || q2 < B) {
             float val = z[r];
             if (li == D) val += 1e-20f;  // example/hept.py:14
-            pt[(size_t)dst * H * 32] = val;
+            pt[(size_t)dst * hr.hout * 32] = val;
         }
     }
 }
 
 template <bool FULL, int VP>
 int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, const float* kvhat, const int* qpos,
-                      const int* kpos, float* part, int N, int H, int D, int B, int nb) {
+                      const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr) {
 #define HEPT_SPLIT_CASE(K)                                                                                       \
     case K: {                                                                                                    \
         constexpr size_t lds = (size_t)(3 + VP) * (K >= 2 ? 64 : 32) * 64;                                       \
         if (lds > 65536) {                                                                                       \
-            static bool raised = false;                                                                          \
-            if (!raised) {                                                                                       \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_split_kernel<K, FULL, VP>),        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
-                    return HEPT_ERR_LAUNCH;                                                                      \
-                raised = true;                                                                                   \
-            }                                                                                                    \
+            static LdsRaised raised;                                                                             \
+            if (hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_split_kernel<K, FULL, VP>), lds))   \
+                return HEPT_ERR_LAUNCH;                                                                          \
         }                                                                                                        \
         hipLaunchKernelGGL((block_attn_split_kernel<K, FULL, VP>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,   \
-                           kpos, part, N, H, D, B, nb);                                                          \
+                           kpos, part, N, H, D, B, nb, hr);                                                        \
         break;                                                                                                   \
     }
     switch (nkt) {
@@ -453,21 +449,17 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
 
 template <bool BF16, bool P16, bool F16QK, bool FULL>
 int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
-                const int* kpos, float* part, int N, int H, int D, int B, int nb) {
+                const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr) {
 #define HEPT_ATTN_CASE(K)                                                                                    \
     case K: {                                                                                                \
         constexpr size_t lds = (size_t)2 * 32 * K * 32 * (BF16 ? 2 : 4) + 32 * K * 8;                        \
         if (lds > 65536) {                                                                                   \
-            static bool raised = false;                                                                      \
-            if (!raised) {                                                                                   \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16, F16QK, FULL>),          \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-                    return HEPT_ERR_LAUNCH;                                                                  \
-                raised = true;                                                                               \
-            }                                                                                                \
+            static LdsRaised raised;                                                                         \
+            if (hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16, F16QK, FULL>), lds)) \
+                return HEPT_ERR_LAUNCH;                                                                      \
         }                                                                                                    \
         hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16, F16QK, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
-                           kpos, part, N, H, D, B, nb);                                                      \
+                           kpos, part, N, H, D, B, nb, hr);                                                    \
         break;                                                                                               \
     }
     switch (nkt) {
@@ -488,41 +480,60 @@ int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const
 
 template <bool BF16, bool P16, bool F16QK>
 int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
-                const int* kpos, float* part, int N, int H, int D, int B, int nb) {
+                const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr) {
     if (B == 32 * nkt)
-        return launch_attn_full<BF16, P16, F16QK, true>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb);
-    return launch_attn_full<BF16, P16, F16QK, false>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb);
+        return launch_attn_full<BF16, P16, F16QK, true>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr);
+    return launch_attn_full<BF16, P16, F16QK, false>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr);
 }
 
 }  // namespace
 
-extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
-                               int H, int D, int Tl, int B, int precision, float* part, void* stream) {
+namespace {
+int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N, int H, int D,
+                    int Tl, int B, int precision, const HeadRange& hr, float* part, void* stream) {
     if (!qhat || !kvhat || !qpos || !kpos || !part) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
         return HEPT_ERR_SHAPE;
+    if (hr.h0 < 0 || hr.hg < 1 || hr.h0 + hr.hg > H || hr.hout < 1 || hr.hsub < 0 || hr.hsub > hr.h0 ||
+        hr.h0 + hr.hg - hr.hsub > hr.hout)
+        return HEPT_ERR_SHAPE;
 
     const int nb = N / B, nkt = (B + 31) / 32;
-    const dim3 grid((unsigned)((size_t)Tl * nb * H));
+    const dim3 grid((unsigned)((size_t)Tl * nb * hr.hg));
     hipStream_t st = (hipStream_t)stream;
     // bf16 tiles with D == 24 write packed 64-B partial rows (HEPT_PART_PACKED), everything else 128-B f32 rows
     const char* qh = (const char*)qhat;
     const char* kv = (const char*)kvhat;
     if (precision == HEPT_PREC_BF16 && D == 24)
-        return launch_attn<true, true, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
+        return launch_attn<true, true, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
     if (precision == HEPT_PREC_BF16)
-        return launch_attn<true, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
+        return launch_attn<true, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
     if (precision == HEPT_PREC_MIXED16 && D == 24)
-        return launch_attn<true, true, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
+        return launch_attn<true, true, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
     if (precision == HEPT_PREC_MIXED16)
-        return launch_attn<true, false, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
+        return launch_attn<true, false, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
     if (precision == HEPT_PREC_F32) {
         const float* qf = (const float*)qhat;
         const float* kf = (const float*)kvhat;
-        if (B == 32 * nkt) return launch_attn_split<true, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb);
-        return launch_attn_split<false, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb);
+        if (B == 32 * nkt) return launch_attn_split<true, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr);
+        return launch_attn_split<false, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr);
     }
     if (precision == HEPT_PREC_F32_MFMA)
-        return launch_attn<false, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb);
+        return launch_attn<false, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
     return HEPT_ERR_SHAPE;
+}
+}  // namespace
+
+extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
+                               int H, int D, int Tl, int B, int precision, float* part, void* stream) {
+    const HeadRange all{0, H, H, 0, (long long)N * H};
+    return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, all, part, stream);
+}
+
+extern "C" int hept_block_attn_heads(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos,
+                                     int N, int H, int D, int Tl, int B, int precision, int h0, int hg, int hout,
+                                     int hsub, int n_rows_out, float* part, void* stream) {
+    if (n_rows_out < N) return HEPT_ERR_SHAPE;
+    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout};
+    return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, hr, part, stream);
 }

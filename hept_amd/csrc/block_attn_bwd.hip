@@ -553,13 +553,10 @@ int launch_bwd(int nkt, dim3 grid, hipStream_t st, const float* qhat, const floa
 #define HEPT_BWD_CASE(K)                                                                                         \
     case K: {                                                                                                    \
         constexpr size_t lds = (size_t)4 * 32 * K * 128 + 32 * K * 16;                                           \
-        static bool raised = false;                                                                              \
-        if (lds > 65536 && !raised) {                                                                            \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_bwd_kernel<K, FULL>),              \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)         \
-                return HEPT_ERR_LAUNCH;                                                                          \
-            raised = true;                                                                                       \
-        }                                                                                                        \
+        static LdsRaised raised;                                                                                 \
+        if (lds > 65536 &&                                                                                       \
+            hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_bwd_kernel<K, FULL>), lds))         \
+            return HEPT_ERR_LAUNCH;                                                                              \
         hipLaunchKernelGGL((block_attn_bwd_kernel<K, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
                            kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);                                       \
         break;                                                                                                   \
@@ -587,13 +584,10 @@ int launch_bwd_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, cons
 #define HEPT_BWDS_CASE(K)                                                                                        \
     case K: {                                                                                                    \
         constexpr size_t lds = (size_t)6 * 32 * K * BPROW;                                                       \
-        static bool raised = false;                                                                              \
-        if (lds > 65536 && !raised) {                                                                            \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&block_attn_bwd_split_kernel<K, FULL>),        \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)         \
-                return HEPT_ERR_LAUNCH;                                                                          \
-            raised = true;                                                                                       \
-        }                                                                                                        \
+        static LdsRaised raised;                                                                                 \
+        if (lds > 65536 &&                                                                                       \
+            hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_bwd_split_kernel<K, FULL>), lds))   \
+            return HEPT_ERR_LAUNCH;                                                                              \
         hipLaunchKernelGGL((block_attn_bwd_split_kernel<K, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat,     \
                            qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);                                 \
         break;                                                                                                   \

@@ -19,8 +19,13 @@ struct Workspace {
     size_t bytes;
 };
 
+// proj / minmax / sort scratch hold one chunk of at most HEPT_MAX_TABLES tables (prep_hash and the sort work on such
+// chunks); the permutations and the partial rows exist for all Tl tables of the call
+inline int chunk_tables(int Tl) { return Tl < HEPT_MAX_TABLES ? Tl : HEPT_MAX_TABLES; }
+
 Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
     const size_t esz = (precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA) ? 4 : 2;
+    const int Tc = chunk_tables(Tl);
     char* p = reinterpret_cast<char*>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -32,11 +37,11 @@ Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
     w.sqrt_w = reinterpret_cast<float*>(take((size_t)H * C * 4));
     w.qhat = take((size_t)H * N * 32 * esz);
     w.kvhat = take((size_t)H * N * 64 * esz);
-    w.qproj = reinterpret_cast<float*>(take((size_t)Tl * H * N * 4));
-    w.kproj = reinterpret_cast<float*>(take((size_t)Tl * H * N * 4));
-    w.minmax = reinterpret_cast<float*>(take((size_t)HEPT_PREP_GRID * Tl * H * 4 * 4));
+    w.qproj = reinterpret_cast<float*>(take((size_t)Tc * H * N * 4));
+    w.kproj = reinterpret_cast<float*>(take((size_t)Tc * H * N * 4));
+    w.minmax = reinterpret_cast<float*>(take((size_t)HEPT_PREP_GRID * Tc * H * 4 * 4));
     w.pos = reinterpret_cast<int32_t*>(take((size_t)2 * Tl * H * N * 4));
-    w.sort_ws = take(hept_sort_workspace_bytes(N, H, Tl));
+    w.sort_ws = take(hept_sort_workspace_bytes(N, H, Tc));
     w.part = reinterpret_cast<float*>(take((size_t)Tl * N * H * 32 * 4));
     w.bytes = off;
     return w;
@@ -55,7 +60,7 @@ inline bool prof_active() {
 inline void prof_mark(int slot, hipStream_t st) {
     if (!prof_active()) return;
     if (g_prof.mode == 1 && slot != 2 && slot != 3) return;
-    hipEventRecord(g_prof.ev[(size_t)g_prof.n_calls * 5 + slot], st);
+    (void)hipEventRecord(g_prof.ev[(size_t)g_prof.n_calls * 5 + slot], st);
 }
 inline void prof_call_done() {
     if (prof_active()) ++g_prof.n_calls;
@@ -71,33 +76,48 @@ struct GeoShift {
     int raw_size = -1;
 };
 
-// stages shared by hept_forward / hept_forward_partial; leaves per-table partials in w.part
-int run_tables(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
-               const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T,
-               int t0, int Tl, int B, int precision, const Workspace& w, float* part, void* stream) {
+// everything before the block attention, for tables [t0, t0 + Tl): parameter math, augmented rows + hashes, sort.
+// Leaves qhat / kvhat and the permutations (w.pos: q then k, (Tl, H, N) each) in the workspace.
+int run_begin(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
+              const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T,
+              int t0, int Tl, int precision, const Workspace& w, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     prof_mark(0, st);
     int rc = hept_rpe_scale(w_rpe, H, D, C, K, w.sqrt_w, stream);
     if (rc) return rc;
-    rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, codes, N, geo.eta ? geo.raw_size : N, H, D, C, T, t0, Tl,
-                        precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream);
-    if (rc) return rc;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)Tl * H * N;
-    prof_mark(1, st);
-    rc = geo.eta ? hept_sort_tables_src(w.qproj, w.kproj, geo.eta, geo.phi, geo.cfac, w.minmax, N, H, T, t0, Tl,
-                                        w.sort_ws, qpos, kpos, stream)
-                 : hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0, Tl, w.sort_ws, qpos, kpos, stream);
-    if (rc) return rc;
+    for (int c0 = 0; c0 < Tl; c0 += HEPT_MAX_TABLES) {   // chunks of tables (the rows are rewritten identically)
+        const int tc = Tl - c0 < HEPT_MAX_TABLES ? Tl - c0 : HEPT_MAX_TABLES;
+        rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, codes, N, geo.eta ? geo.raw_size : N, H, D, C, T,
+                            t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream);
+        if (rc) return rc;
+        if (c0 == 0) prof_mark(1, st);
+        const size_t off = (size_t)c0 * H * N;
+        rc = geo.eta ? hept_sort_tables_src(w.qproj, w.kproj, geo.eta, geo.phi, geo.cfac, w.minmax, N, H, T, t0 + c0, tc,
+                                            w.sort_ws, qpos + off, kpos + off, stream)
+                     : hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0 + c0, tc, w.sort_ws, qpos + off,
+                                        kpos + off, stream);
+        if (rc) return rc;
+    }
     prof_mark(2, st);
-    rc = hept_block_attn(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, part, stream);
-    prof_mark(3, st);
+    return HEPT_OK;
+}
+
+// stages shared by hept_forward / hept_forward_partial; leaves per-table partials in `part`
+int run_tables(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
+               const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T,
+               int t0, int Tl, int B, int precision, const Workspace& w, float* part, void* stream) {
+    int rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
+    if (rc) return rc;
+    rc = hept_block_attn(w.qhat, w.kvhat, w.pos, w.pos + (size_t)Tl * H * N, N, H, D, Tl, B, precision, part, stream);
+    prof_mark(3, (hipStream_t)stream);
     return rc;
 }
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 9; }
+extern "C" int hept_abi_version(void) { return 10; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -106,7 +126,7 @@ extern "C" int hept_part_precision(int precision, int D) {
 extern "C" int hept_check_shape(int N, int H, int D, int C, int Tl, int B) {
     if (N < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0) return HEPT_ERR_SHAPE;
     if (H != 8) return HEPT_ERR_SHAPE;
-    if (Tl < 1 || Tl > HEPT_MAX_TABLES) return HEPT_ERR_SHAPE;
+    if (Tl < 1) return HEPT_ERR_SHAPE;  // any number of tables: prep_hash and the sort run in chunks of HEPT_MAX_TABLES
     const bool dc = (D == 24 && (C == 6 || C == 4 || C == 2)) || (D == 16 && (C == 6 || C == 4)) || (D == 8 && C == 4);
     return dc ? HEPT_OK : HEPT_ERR_SHAPE;
 }
@@ -203,6 +223,78 @@ extern "C" int hept_forward_partial_src(const float* q, const float* k, const fl
                                 stream);
 }
 
+namespace {
+int partial_begin_impl(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
+                       const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K,
+                       int T, int t0, int Tl, int B, int precision, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    if (!q || !k || !v || !coords || !w_rpe || !alpha || !workspace) return HEPT_ERR_ARG;
+    int rc = hept_check_shape(N, H, D, C, Tl, B);
+    if (rc) return rc;
+    if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    const Workspace w = carve(workspace, N, H, C, Tl, precision);
+    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+    return run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
+}
+}  // namespace
+
+extern "C" int hept_partial_begin(const float* q, const float* k, const float* v, const float* coords,
+                                  const int64_t* codes, const float* w_rpe, const float* alpha, int N, int H, int D,
+                                  int C, int K, int T, int t0, int Tl, int B, int precision, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!codes) return HEPT_ERR_ARG;
+    return partial_begin_impl(q, k, v, coords, codes, GeoShift{}, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, B, precision,
+                              workspace, workspace_bytes, stream);
+}
+
+extern "C" int hept_partial_begin_src(const float* q, const float* k, const float* v, const float* coords,
+                                      const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
+                                      const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T,
+                                      int t0, int Tl, int B, int precision, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (!eta_idx || !phi_idx || !cfac) return HEPT_ERR_ARG;
+    if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    return partial_begin_impl(q, k, v, coords, nullptr, GeoShift{eta_idx, phi_idx, cfac, raw_size}, w_rpe, alpha, N, H,
+                              D, C, K, T, t0, Tl, B, precision, workspace, workspace_bytes, stream);
+}
+
+extern "C" int hept_partial_heads(void* workspace, size_t workspace_bytes, int N, int H, int D, int C, int Tl, int B,
+                                  int precision, int h0, int hg, int n_pad, int acc_precision, float* dst,
+                                  void* stream) {
+    if (!workspace || !dst) return HEPT_ERR_ARG;
+    int rc = hept_check_shape(N, H, D, C, Tl, B);
+    if (rc) return rc;
+    if (h0 < 0 || hg < 1 || h0 + hg > H || n_pad < N) return HEPT_ERR_SHAPE;
+    const int pprec = hept_part_precision(precision, D);
+    if (acc_precision != HEPT_PREC_F32 && acc_precision != pprec) return HEPT_ERR_SHAPE;
+    const Workspace w = carve(workspace, N, H, C, Tl, precision);
+    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t* qpos = w.pos;
+    const int32_t* kpos = w.pos + (size_t)Tl * H * N;
+    // one local table already in the requested row format: block_attn scatters straight into the group's rows of
+    // dst (n_pad, hg, row); the padding rows [N, n_pad) are zeroed (nothing reads them, but they travel)
+    const bool direct = Tl == 1 && pprec == acc_precision;
+    const bool rec = g_prof.mode == 1;
+    if (rec) prof_mark(2, st);
+    if (direct) {
+        const size_t row_bytes = (size_t)hg * (acc_precision == HEPT_PREC_BF16 ? 64 : 128);
+        if (n_pad > N && hipMemsetAsync(reinterpret_cast<char*>(dst) + (size_t)N * row_bytes, 0,
+                                        (size_t)(n_pad - N) * row_bytes, st) != hipSuccess)
+            return HEPT_ERR_LAUNCH;
+        rc = hept_block_attn_heads(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, h0, hg, hg, h0, n_pad, dst,
+                                   stream);
+        if (rec) prof_mark(3, st);
+    } else {
+        rc = hept_block_attn_heads(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, h0, hg, H, 0, N, w.part,
+                                   stream);
+        if (rec) prof_mark(3, st);
+        if (!rc) rc = hept_reduce_heads(w.part, pprec, Tl, N, H, D, h0, hg, n_pad, dst, acc_precision, stream);
+    }
+    if (rec) prof_call_done();
+    return rc;
+}
+
 extern "C" int hept_attn_block_forward(const float* x, const float* coords, const int64_t* codes,
                                        const hept_attn_params* p, int N, int H, int D, int C, int K, int T, int B,
                                        int precision, void* workspace, size_t workspace_bytes, float* y,
@@ -213,7 +305,7 @@ extern "C" int hept_attn_block_forward(const float* x, const float* coords, cons
         return HEPT_ERR_ARG;
     int rc = hept_check_shape(N, H, D, C, T, B);
     if (rc) return rc;
-    if (D != 24) return HEPT_ERR_SHAPE;
+    if (D != 24 || T > HEPT_MAX_TABLES) return HEPT_ERR_SHAPE;
     const Workspace w = carve(workspace, N, H, C, T, precision);
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -243,7 +335,7 @@ extern "C" int hept_attn_block_forward(const float* x, const float* coords, cons
 extern "C" int hept_profile_enable(int mode, int max_calls) {
     if (mode < 0 || mode > 2 || max_calls < 0) return HEPT_ERR_ARG;
     if (g_prof.ev) {
-        for (size_t i = 0; i < (size_t)g_prof.max_calls * 5; ++i) hipEventDestroy(g_prof.ev[i]);
+        for (size_t i = 0; i < (size_t)g_prof.max_calls * 5; ++i) (void)hipEventDestroy(g_prof.ev[i]);
         delete[] g_prof.ev;
         g_prof.ev = nullptr;
     }

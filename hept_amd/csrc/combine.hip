@@ -91,9 +91,9 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                                                                   int H, int D_rt, int n0, int n_count,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ bias,
-                                                                  float* __restrict__ out, FfnIn ffn = FfnIn{}) {
+                                                                  float* __restrict__ out, int HG, size_t gstride,
+                                                                  FfnIn ffn = FfnIn{}) {
     constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
-    constexpr int TMAX = HEPT_MAX_TABLES;
     extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H (even-padded)][28 (d)][32 (c, zero padded)]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int D = DT ? DT : D_rt;
@@ -125,7 +125,9 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         }
     }
     __syncthreads();
-    const size_t tstride = (size_t)N * H * ROWF;
+    // rows of head group g = head / HG live in their own (Tl, N, HG, row) buffer at part + g * gstride (table
+    // sharding receives the head groups one exchange at a time); HG == H: the plain (Tl, N, H, row) layout
+    const size_t tstride = (size_t)N * HG * ROWF;
     const int n_tiles = (n_count + 31) / 32;
     const int hp0 = SPLIT ? 2 * w : 0, hstep = SPLIT ? 2 * CMB_WAVES : 2;
     float* red_s = stage_s_end;  // SPLIT: [CMB_WAVES - 1][16][64] partial accumulators of waves 1..
@@ -133,8 +135,11 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
          tile += SPLIT ? gridDim.x : gridDim.x * CMB_WAVES) {
         const int i = tile * 32 + li;
         const int n = n0 + (i < n_count ? i : n_count - 1);
-        const float* prow = part + (size_t)n * H * ROWF;
-        auto row_of = [&](int hp) { const int head = hp + hh; return prow + (size_t)(head < H ? head : 0) * ROWF; };
+        const float* prow = part + (size_t)n * HG * ROWF;
+        auto row_of = [&](int hp) {
+            const int head = hp + hh < H ? hp + hh : 0, g = head / HG;
+            return prow + (size_t)g * gstride + (size_t)(head - g * HG) * ROWF;
+        };
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 if (t < tpre) den += cur[t].add_to(s, D);
-            for (int t = 3; t < Tl && t < TMAX; ++t) {  // beyond three tables: plain loads
+            for (int t = 3; t < Tl; ++t) {  // beyond three tables: plain loads
                 RawRow<P16> extra;
                 extra.load(row_of(hp) + (size_t)t * tstride);
                 den += extra.add_to(s, D);
@@ -339,6 +344,52 @@ __global__ __launch_bounds__(256) void reduce_tables_kernel(const float* __restr
     }
 }
 
+// Table sharding, one head group at a time: dst (n_pad, hg, row) = sum over tables of the rows of heads [h0, h0 + hg)
+// of part (Tl, N, H, row); points >= N (padding up to a multiple of the rank count) get zero rows.  Same arithmetic
+// and row formats as reduce_tables_kernel.
+template <bool P16, bool OUT16>
+__global__ __launch_bounds__(256) void reduce_heads_kernel(const float* __restrict__ part, int Tl, int N, int H, int h0,
+                                                           int hg, int n_pad, float* __restrict__ dst) {
+    constexpr int ROWF = P16 ? 16 : 32;
+    constexpr int OUTF = OUT16 ? 16 : 32;
+    const size_t total = (size_t)n_pad * hg * 2;  // one lane per half row
+    const size_t tstride = (size_t)N * H * ROWF;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t orow = i >> 1;
+        const int hh = (int)(i & 1);
+        const size_t n = orow / hg;
+        const int hl = (int)(orow - n * hg);
+        float s[16];
+        if (n < (size_t)N) {
+            const float* src = part + (n * H + h0 + hl) * ROWF;
+            load_half_row<P16>(src, hh, s);
+            for (int t = 1; t < Tl; ++t) {
+                float x[16];
+                load_half_row<P16>(src + (size_t)t * tstride, hh, x);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s[u] += x[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s[u] = 0.f;
+        }
+        if constexpr (OUT16) {
+            u32x4* o = reinterpret_cast<u32x4*>(dst + orow * OUTF + 8 * hh);
+            o[0] = u32x4{hept_pack_bf16(s[0], s[1]), hept_pack_bf16(s[2], s[3]), hept_pack_bf16(s[4], s[5]),
+                         hept_pack_bf16(s[6], s[7])};
+            if (hh == 0)
+                o[1] = u32x4{hept_pack_bf16(s[8], s[9]), hept_pack_bf16(s[10], s[11]), hept_pack_bf16(s[12], s[13]),
+                             hept_pack_bf16(s[14], s[15])};
+            else  // widened columns 16..23 = numerators, 24 = denominator
+                o[1] = u32x4{__float_as_uint(s[8]), 0u, 0u, 0u};
+        } else {
+            f32x4* o = reinterpret_cast<f32x4*>(dst + orow * OUTF + 16 * hh);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) o[c4] = f32x4{s[4 * c4], s[4 * c4 + 1], s[4 * c4 + 2], s[4 * c4 + 3]};
+        }
+    }
+}
+
 // ---- backward of combine_out (training path): out = bias + W . (numer / den) -----------------------
 // Two kernels.  Rows: lane (point, head) recomputes per_head = numer / den, pulls g_out back through its head's
 // D x D weight slab (LDS, packed fp32 FMAs) and writes the gradient of the partial row [d numer | d den | 0].
@@ -493,12 +544,37 @@ extern "C" int hept_reduce_tables(const float* part, int part_precision, int Tl,
     return hept_launch_status();
 }
 
+extern "C" int hept_reduce_heads(const float* part, int part_precision, int Tl, int N, int H, int D, int h0, int hg,
+                                 int n_pad, float* dst, int acc_precision, void* stream) {
+    if (!part || !dst) return HEPT_ERR_ARG;
+    if (acc_precision != HEPT_PREC_F32 && !(acc_precision == HEPT_PREC_BF16 && part_precision == HEPT_PREC_BF16))
+        return HEPT_ERR_SHAPE;
+    if (Tl < 1 || N < 1 || H < 1 || D < 1 || D > 28 || h0 < 0 || hg < 1 || h0 + hg > H || n_pad < N)
+        return HEPT_ERR_SHAPE;
+    const size_t blocks = ((size_t)n_pad * hg * 2 + 255) / 256;
+    const int grid = (int)(blocks < 4096 ? blocks : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (part_precision == HEPT_PREC_BF16) {
+        if (D != 24) return HEPT_ERR_SHAPE;
+        if (acc_precision == HEPT_PREC_BF16)
+            hipLaunchKernelGGL((reduce_heads_kernel<true, true>), dim3(grid), dim3(256), 0, st, part, Tl, N, H, h0, hg, n_pad, dst);
+        else
+            hipLaunchKernelGGL((reduce_heads_kernel<true, false>), dim3(grid), dim3(256), 0, st, part, Tl, N, H, h0, hg, n_pad, dst);
+    } else if (part_precision == HEPT_PREC_F32) {
+        hipLaunchKernelGGL((reduce_heads_kernel<false, false>), dim3(grid), dim3(256), 0, st, part, Tl, N, H, h0, hg, n_pad, dst);
+    } else {
+        return HEPT_ERR_SHAPE;
+    }
+    return hept_launch_status();
+}
+
 // few tiles: one tile per workgroup, head pairs split over its waves (SPLIT); else one tile per wave
 constexpr int CMB_SPLIT_BELOW = 1024;  // tiles; 1024 tiles = one wave per SIMD on 256 CUs
 
 template <bool P16, bool FFN, int DT>
 int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int D, int n0, int n_count, const float* W,
-                   const float* b, float* out, const FfnIn& ffn) {
+                   const float* b, float* out, const FfnIn& ffn, int HG = 0, size_t gstride = 0) {
+    if (HG <= 0) HG = H;
     const int n_tiles = (n_count + 31) / 32;
     const bool split = n_tiles < CMB_SPLIT_BELOW;
     const size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * WT_PITCH +
@@ -506,32 +582,40 @@ int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int 
                                         (split ? (CMB_WAVES - 1) * 16 * 64 : 0));
     if (split) {
         hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true>), dim3(n_tiles), dim3(CMB_THREADS), lds, st, part, Tl, N,
-                           H, D, n0, n_count, W, b, out, ffn);
+                           H, D, n0, n_count, W, b, out, HG, gstride, ffn);
     } else {
         const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
         hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, false>), dim3(wgs < 2048 ? wgs : 2048), dim3(CMB_THREADS), lds,
-                           st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn);
+                           st, part, Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn);
     }
     return hept_launch_status();
+}
+
+extern "C" int hept_combine_groups(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
+                                   int n_count, int HG, size_t group_stride, const float* out_weight,
+                                   const float* out_bias, float* out, void* stream) {
+    if (!part || !out_weight || !out) return HEPT_ERR_ARG;
+    if (Tl < 1 || N < 1 || H < 1 || H > 15 || D < 1 || D > 28 || n0 < 0 || n_count < 0 || n0 + n_count > N)
+        return HEPT_ERR_SHAPE;
+    if (HG < 1 || HG > H || H % HG != 0) return HEPT_ERR_SHAPE;
+    if (n_count == 0) return HEPT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const FfnIn none{};
+    const size_t gs = group_stride;
+    if (part_precision == HEPT_PREC_BF16) {
+        if (D != 24) return HEPT_ERR_SHAPE;  // packed rows keep the denominator at widened column 24
+        return combine_launch<true, false, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none, HG, gs);
+    }
+    if (part_precision != HEPT_PREC_F32) return HEPT_ERR_SHAPE;
+    if (D == 24) return combine_launch<false, false, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none, HG, gs);
+    if (D == 16) return combine_launch<false, false, 16>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none, HG, gs);
+    return combine_launch<false, false, 0>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none, HG, gs);
 }
 
 extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
                                 int n_count, const float* out_weight, const float* out_bias, float* out,
                                 void* stream) {
-    if (!part || !out_weight || !out) return HEPT_ERR_ARG;
-    if (Tl < 1 || N < 1 || H < 1 || H > 15 || D < 1 || D > 28 || n0 < 0 || n_count < 0 || n0 + n_count > N)
-        return HEPT_ERR_SHAPE;
-    if (n_count == 0) return HEPT_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const FfnIn none{};
-    if (part_precision == HEPT_PREC_BF16) {
-        if (D != 24) return HEPT_ERR_SHAPE;  // packed rows keep the denominator at widened column 24
-        return combine_launch<true, false, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none);
-    }
-    if (part_precision != HEPT_PREC_F32) return HEPT_ERR_SHAPE;
-    if (D == 24) return combine_launch<false, false, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none);
-    if (D == 16) return combine_launch<false, false, 16>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none);
-    return combine_launch<false, false, 0>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none);
+    return hept_combine_groups(part, part_precision, Tl, N, H, D, n0, n_count, H, 0, out_weight, out_bias, out, stream);
 }
 
 extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,

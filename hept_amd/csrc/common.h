@@ -12,9 +12,33 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// Which heads a block_attn launch covers and where their partial rows go: heads [h0, h0 + hg) of the H input slabs;
+// the row of (table t, point n, head h) is written at row index t * tstride_rows + n * hout + (h - hsub) of `part`.
+// Whole operator: {0, H, H, 0, N * H}.  Table sharding sends head groups one at a time: hout = hg, hsub = h0 makes
+// the launch write a (n_rows, hg, row) buffer of its own.
+struct HeadRange {
+    int h0, hg, hout, hsub;
+    long long tstride_rows;
+};
+
 static inline int hept_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? HEPT_OK : HEPT_ERR_LAUNCH;
+}
+
+// Kernels that need more than 64 KiB of dynamic LDS have to be told so once per device (the attribute belongs to the
+// device's copy of the function): every call site keeps one flag per device ordinal.
+#define HEPT_MAX_DEVICES 64
+struct LdsRaised {
+    bool done[HEPT_MAX_DEVICES] = {};
+};
+static inline int hept_raise_lds(LdsRaised& flags, const void* fn, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HEPT_MAX_DEVICES) return HEPT_ERR_LAUNCH;
+    if (flags.done[dev]) return HEPT_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return HEPT_ERR_LAUNCH;
+    flags.done[dev] = true;
+    return HEPT_OK;
 }
 
 // float -> bf16, round to nearest even, on the hardware converter (v_cvt_pk_bf16_f32)

@@ -741,13 +741,8 @@ template <int MODE>
 int launch_small_sort(int segs, hipStream_t st, const float* qproj, const float* kproj, const int64_t* codes,
                       const float* eta, const float* phi, const float* cfac, const float* minmax, int N, int H, int t0,
                       int Tl, int* pos, const int* seg_len = nullptr) {
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_sort_kernel<MODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS) != hipSuccess)
-            return HEPT_ERR_LAUNCH;
-        raised = true;
-    }
+    static LdsRaised raised;
+    if (hept_raise_lds(raised, reinterpret_cast<const void*>(small_sort_kernel<MODE>), SMALL_LDS)) return HEPT_ERR_LAUNCH;
     hipLaunchKernelGGL(small_sort_kernel<MODE>, dim3(segs), dim3(SMALL_THREADS), SMALL_LDS, st, qproj, kproj, codes, eta,
                        phi, cfac, minmax, N, H, t0, Tl, pos, seg_len);
     return hept_launch_status();

@@ -76,6 +76,7 @@ class HEPTAttention(nn.Module):
             TableSharding(self.n_hashes, process_group) if process_group is not None else None
         )
         self._workspace: Optional[torch.Tensor] = None
+        self._warned_eval_grad = False
 
     def _scratch(self, nbytes: int, device) -> torch.Tensor:
         ws = self._workspace
@@ -90,7 +91,20 @@ class HEPTAttention(nn.Module):
         if torch.is_grad_enabled() and any(
             t.requires_grad for t in (query, key, value, kwargs["w_rpe"].weight, self.out_linear.weight)
         ):
-            return self._forward_train(query, key, value, **kwargs)
+            # differentiable path (f32 tiles).  The usual ``model.eval(); model(x)`` without ``torch.no_grad()`` also
+            # lands here because the parameters require grad: with fp32 tiles on one GPU it simply takes the autograd
+            # path (same values); with 16-bit tiles or table sharding an eval-mode call whose inputs carry no
+            # gradient is served by the inference path instead, as the reference would serve it
+            light = self.precision in ("fp32", "fp32_mfma") and self.sharding is None
+            if light or self.training or any(t.requires_grad for t in (query, key, value)):
+                return self._forward_train(query, key, value, **kwargs)
+            if not self._warned_eval_grad:
+                import warnings
+
+                warnings.warn("hept_amd.HEPTAttention: eval-mode call with grad enabled and no input gradient under "
+                              f"precision={self.precision!r}/table sharding runs the inference path (no parameter "
+                              "gradients); call under torch.no_grad() or .train() to be explicit", stacklevel=2)
+                self._warned_eval_grad = True
         coords = kwargs["coords"]
         src = "combined_shifts" not in kwargs  # the src variant's kwargs: raw_size, regions_h, region_indices
         w_rpe_weight = kwargs["w_rpe"].weight
@@ -129,30 +143,44 @@ class HEPTAttention(nn.Module):
                                       self.e2lsh.alpha, self.out_linear.weight, self.out_linear.bias, workspace=ws,
                                       **common)
             else:
-                t0, tl = self.sharding.local_tables()
-                packed = self.sharding.packed_ok and ops.packed_partials(self.precision, d)
-                ws = self._scratch(ops.workspace_bytes(n, h, d, c, tl, self.block_size, self.precision), query.device)
-                if src:
-                    acc = ops.forward_partial_src(q2, k2, v2, coords.float(), kwargs["region_indices"],
-                                                  kwargs["regions_h"], kwargs["raw_size"], w_rpe_weight,
-                                                  self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, packed=packed,
-                                                  **common)
-                else:
-                    acc = ops.forward_partial(q2, k2, v2, coords.float(), kwargs["combined_shifts"], w_rpe_weight,
-                                              self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, packed=packed, **common)
-                out = self.sharding.finish(
-                    acc, lambda part, n0, cnt: ops.combine_out(part, d, self.out_linear.weight,
-                                                               self.out_linear.bias, n0, cnt))
+                out = self._forward_sharded(q2, k2, v2, coords.float(), w_rpe_weight, src, kwargs, common)
         return out.to(query.dtype)
+
+    def _forward_sharded(self, q2, k2, v2, coords, w_rpe_weight, src, kwargs, common):
+        """Tables [t0, t0 + tl) of this rank, then the exchange (reference coupling: example/hept.py:79)."""
+        sh = self.sharding
+        n, h, d = q2.shape[0], self.num_heads, self.dim_per_head
+        c = coords.shape[1]
+        t0, tl = sh.local_tables()
+        packed = sh.packed_ok and ops.packed_partials(self.precision, d)
+        ws = self._scratch(ops.workspace_bytes(n, h, d, c, tl, self.block_size, self.precision), q2.device)
+        geo = (kwargs["region_indices"], kwargs["regions_h"], kwargs["raw_size"]) if src else None
+        if sh.mode == "all_to_all" and (sh.world > 1 or sh.always_exchange):
+            # pipelined: the block attention runs one head group at a time and every finished group is on the links
+            # while the next one is computed
+            dims = ops.partial_begin(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
+                                     self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, geo=geo, **common)
+            return sh.pipelined(
+                n, h, 16 if packed else 32, torch.int32 if packed else torch.float32, q2.device,
+                lambda g, h0, dst: ops.partial_heads(ws, dims, tl, self.block_size, self.precision, h0, dst),
+                lambda recv, cnt: ops.combine_groups(recv, d, self.out_linear.weight, self.out_linear.bias, 0, cnt))
+        if src:
+            acc = ops.forward_partial_src(q2, k2, v2, coords, kwargs["region_indices"], kwargs["regions_h"],
+                                          kwargs["raw_size"], w_rpe_weight, self.e2lsh.alpha, t0=t0, tl=tl,
+                                          workspace=ws, packed=packed, **common)
+        else:
+            acc = ops.forward_partial(q2, k2, v2, coords, kwargs["combined_shifts"], w_rpe_weight, self.e2lsh.alpha,
+                                      t0=t0, tl=tl, workspace=ws, packed=packed, **common)
+        return sh.finish(acc, lambda part, n0, cnt: ops.combine_out(part, d, self.out_linear.weight,
+                                                                     self.out_linear.bias, n0, cnt))
 
     def _forward_train(self, query, key, value, **kwargs):
         """Differentiable path: HIP forward/backward of the block attention inside autograd (f32 tiles)."""
-        from .autograd import HeptPartialSums, RpeScale
+        from .autograd import HeptPartialSums, RpeScale, ReplicatedGrad, sum_over_ranks
 
-        if self.precision not in ("fp32", "fp32_mfma"):
-            raise RuntimeError("training needs precision='fp32' (the backward kernels use f32 tiles)")
-        if self.sharding is not None:
-            raise RuntimeError("table sharding is an inference feature; train with process_group=None")
+        # the backward kernels use f32 tiles, so training always runs them -- also for a module whose inference
+        # precision is 16-bit (gradients are those of the reference's fp32 arithmetic)
+        f32_mfma = self.precision == "fp32_mfma"
         n = query.shape[0]
         if n % self.block_size != 0:
             raise ValueError(f"number of points {n} is not a multiple of block_size {self.block_size}")
@@ -163,9 +191,26 @@ class HEPTAttention(nn.Module):
         if "combined_shifts" not in kwargs:
             geo = ops.geo_args(kwargs["region_indices"], kwargs["regions_h"], self.n_hashes, h, n) + (
                 int(kwargs["raw_size"]),)
-        acc = HeptPartialSums.apply(query.reshape(n, h * d).float(), key.reshape(n, h * d).float(),
-                                    value.reshape(n, h * d).float(), coords, sqrt_w, self.e2lsh.alpha.detach(),
-                                    kwargs.get("combined_shifts"), self.block_size, geo)
+        q2, k2, v2 = (x.reshape(n, h * d).float() for x in (query, key, value))
+        alpha, codes = self.e2lsh.alpha.detach(), kwargs.get("combined_shifts")
+        sh = self.sharding
+        if sh is not None and sh.world > 1:
+            # table sharding under autograd: inputs and loss are replicated, so every rank differentiates its own
+            # tables' partial sums; the forward sums them over the ranks, the backward sums the ranks' contributions
+            # to the gradients of the replicated inputs (reference coupling example/hept.py:79)
+            t0, tl = sh.local_tables()
+            alpha = alpha[:, :, t0:t0 + tl].contiguous()
+            if codes is not None:
+                codes = codes[t0:t0 + tl].contiguous()
+            if geo is not None:
+                eta, phi, cfac, raw = geo
+                geo = (eta.view(self.n_hashes, h, n)[t0:t0 + tl].reshape(tl * h, n).contiguous(),
+                       phi.view(self.n_hashes, h, n)[t0:t0 + tl].reshape(tl * h, n).contiguous(),
+                       cfac.view(self.n_hashes, h)[t0:t0 + tl].reshape(tl * h).contiguous(), raw)
+            q2, k2, v2, coords, sqrt_w = (ReplicatedGrad.apply(x, sh.group) for x in (q2, k2, v2, coords, sqrt_w))
+        acc = HeptPartialSums.apply(q2, k2, v2, coords, sqrt_w, alpha, codes, self.block_size, geo, f32_mfma)
+        if sh is not None and sh.world > 1:
+            acc = sum_over_ranks(acc, sh.group)
         if d == 24:
             from .autograd import HeptCombine
 

@@ -6,6 +6,7 @@ can check every stage against the oracle and inject permutations.
 """
 from __future__ import annotations
 
+import functools
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -18,6 +19,7 @@ __all__ = [
     "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part",
     "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args",
     "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward", "combine_bwd", "rpe_scale_bwd",
+    "partial_begin", "partial_heads", "combine_groups",
 ]
 
 
@@ -37,6 +39,21 @@ def precision_code(precision) -> int:
 
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _on_device(fn):
+    """The C ABI launches on the thread's *current* HIP device: make that the device of the first GPU tensor argument
+    for the duration of the call (a module on cuda:1 called while cuda:0 is current)."""
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = next((a.device for a in args if torch.is_tensor(a) and a.is_cuda), None)
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+
+    return wrapped
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -60,6 +77,7 @@ def workspace_bytes(n, h, d, c, tl, b, precision) -> int:
     return int(_lib.load().hept_workspace_bytes(n, h, d, c, tl, b, precision_code(precision)))
 
 
+@_on_device
 def rpe_scale(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dist: int) -> torch.Tensor:
     lib = _lib.load()
     w = _f32c(w_rpe_weight, "w_rpe.weight")
@@ -70,6 +88,7 @@ def rpe_scale(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dis
     return out
 
 
+@_on_device
 def rpe_scale_bwd(w_rpe_weight: torch.Tensor, d_sqrt_w: torch.Tensor, n_heads: int, head_dim: int,
                   w_per_dist: int) -> torch.Tensor:
     """Gradient of ``rpe_scale`` with respect to ``w_rpe.weight``: (H*D, (C-1)*K) from d_sqrt_w (H, C)."""
@@ -83,6 +102,7 @@ def rpe_scale_bwd(w_rpe_weight: torch.Tensor, d_sqrt_w: torch.Tensor, n_heads: i
     return out
 
 
+@_on_device
 def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int = 0, tl: Optional[int] = None,
               raw_size: Optional[int] = None) -> Dict[str, torch.Tensor]:
     lib = _lib.load()
@@ -114,6 +134,7 @@ def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int =
     return dict(qhat=qhat, kvhat=kvhat, qproj=qproj, kproj=kproj, minmax=minmax)
 
 
+@_on_device
 def sort_tables(qproj, kproj, codes, minmax, t0: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """Stable ascending permutations (Tl,H,N) int32 of ``proj + float(code) * span`` for q and k."""
     lib = _lib.load()
@@ -130,6 +151,7 @@ def sort_tables(qproj, kproj, codes, minmax, t0: int = 0) -> Tuple[torch.Tensor,
     return pos[0], pos[1]
 
 
+@_on_device
 def sort_tables_src(qproj, kproj, eta_idx, phi_idx, cfac, minmax, t0: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """src-variant keys (hash + get_geo_shift): stable ascending permutations (Tl,H,N) int32 for q and k."""
     lib = _lib.load()
@@ -145,6 +167,7 @@ def sort_tables_src(qproj, kproj, eta_idx, phi_idx, cfac, minmax, t0: int = 0) -
     return pos[0], pos[1]
 
 
+@_on_device
 def segmented_argsort(keys: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Stable ascending argsort of every row of a float32 (S, L) GPU tensor (+inf pads sort last); int32 (S, L).
 
@@ -167,6 +190,7 @@ def segmented_argsort(keys: torch.Tensor, lens: Optional[torch.Tensor] = None) -
     return pos
 
 
+@_on_device
 def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int, f32_mfma: bool = False) -> torch.Tensor:
     """Per-table partial rows (Tl, N, H, row).  fp32 tiles: row = 32 f32 (numer in [:D], denom (+1e-20) at [D]);
     bf16 tiles with D == 24: packed row = 16 int32 dwords (24 bf16 numer | f32 denom | 0); see ``unpack_part``.
@@ -204,6 +228,7 @@ def unpack_part(part: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def reduce_tables(part: torch.Tensor, head_dim: int = 24, packed: bool = False) -> torch.Tensor:
     """Sum of the per-table partial rows: f32 rows (N,H,32), or with ``packed`` (packed input only) packed rows
     (N,H,16) int32 again -- the form table sharding sends over xGMI."""
@@ -217,6 +242,7 @@ def reduce_tables(part: torch.Tensor, head_dim: int = 24, packed: bool = False) 
     return acc
 
 
+@_on_device
 def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int = 0, n_count: Optional[int] = None) -> torch.Tensor:
     """(sum_t numer / sum_t denom) -> Linear(H*D -> D) for points [n0, n0+n_count); part is (Tl,N,H,row) or (N,H,32)."""
     lib = _lib.load()
@@ -233,6 +259,7 @@ def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int
     return out
 
 
+@_on_device
 def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int, block_size: int,
                    f32_mfma: bool = False, coords: Optional[torch.Tensor] = None, raw_size: Optional[int] = None):
     """Backward of block_attn + reduce_tables for f32 tiles: gradient rows gacc (N,H,32) -> dq, dk, dv (N, H*D)
@@ -269,6 +296,7 @@ def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int
     return dq, dk, dv, dcs
 
 
+@_on_device
 def combine_bwd(acc: torch.Tensor, g_out: torch.Tensor, out_weight: torch.Tensor, need_bias: bool = True):
     """Backward of ``combine_out`` on table-summed f32 rows: returns (gacc (N,H,32), d_weight (D,H*D), d_bias (D))."""
     lib = _lib.load()
@@ -318,6 +346,7 @@ def _prepare(q, k, v, coords, codes, w_rpe_weight, alpha, block_size, w_per_dist
     return q, k, v, coords, codes.contiguous() if codes is not None else None, w, alpha, (n, h, d, c, t)
 
 
+@_on_device
 def forward(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *, block_size: int, w_per_dist: int,
             precision="fp32", workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Whole operator (reference ``example/hept.py:43-81``) in one C call; returns (N, D) float32."""
@@ -348,6 +377,7 @@ def _acc_buffer(n, h, packed, device):
     return torch.empty(n, h, 16 if packed else 32, device=device, dtype=torch.int32 if packed else torch.float32)
 
 
+@_on_device
 def forward_partial(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: int, w_per_dist: int, t0: int,
                     tl: int, precision="fp32", workspace: Optional[torch.Tensor] = None,
                     packed: bool = False) -> torch.Tensor:
@@ -369,6 +399,7 @@ def forward_partial(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: 
     return acc
 
 
+@_on_device
 def forward_src(q, k, v, coords, region_indices, regions_h, raw_size: int, w_rpe_weight, alpha, out_weight, out_bias,
                 *, block_size: int, w_per_dist: int, precision="fp32",
                 workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -393,6 +424,7 @@ def forward_src(q, k, v, coords, region_indices, regions_h, raw_size: int, w_rpe
     return out
 
 
+@_on_device
 def forward_partial_src(q, k, v, coords, region_indices, regions_h, raw_size: int, w_rpe_weight, alpha, *,
                         block_size: int, w_per_dist: int, t0: int, tl: int, precision="fp32",
                         workspace: Optional[torch.Tensor] = None, packed: bool = False) -> torch.Tensor:
@@ -416,6 +448,7 @@ def forward_partial_src(q, k, v, coords, region_indices, regions_h, raw_size: in
     return acc
 
 
+@_on_device
 def prep_hash_fused(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, precision="fp32",
                     t0: int = 0, tl: Optional[int] = None, raw_size: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """``prep_hash`` with LayerNorm and the q/k/v projections fused in: ``x`` is the (N, D) input of the Attn block
@@ -455,6 +488,7 @@ def prep_hash_fused(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha
     return {"qhat": qhat, "kvhat": kvhat, "qproj": qproj, "kproj": kproj, "minmax": minmax}
 
 
+@_on_device
 def combine_ffn(part: torch.Tensor, head_dim: int, out_weight, out_bias, x, norm_w, norm_b, eps, ff1_w, ff1_b, ff2_w,
                 ff2_b, n0: int = 0, n_count: Optional[int] = None) -> torch.Tensor:
     """``combine_out`` followed by the rest of the Attn block (residual, norm2, feed-forward, residual) in the
@@ -477,6 +511,7 @@ def combine_ffn(part: torch.Tensor, head_dim: int, out_weight, out_bias, x, norm
     return y
 
 
+@_on_device
 def attn_block_forward(x, coords, codes, params: Dict[str, torch.Tensor], *, num_heads: int, block_size: int,
                        w_per_dist: int, eps1: float = 1e-5, eps2: float = 1e-5, precision="fp32",
                        workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -513,6 +548,70 @@ def attn_block_forward(x, coords, codes, params: Dict[str, torch.Tensor], *, num
                                            d, c, w_per_dist, t, block_size, prec, workspace.data_ptr(),
                                            workspace.numel(), y.data_ptr(), _stream(x)), "hept_attn_block_forward")
     return y
+
+
+@_on_device
+def partial_begin(q, k, v, coords, codes, w_rpe_weight, alpha, *, block_size: int, w_per_dist: int, t0: int, tl: int,
+                  precision="fp32", workspace: torch.Tensor, geo=None) -> Tuple[int, int, int, int]:
+    """Table sharding, first half (``hept_partial_begin``): parameter math, rows + hashes and the sort for tables
+    [t0, t0+tl); everything stays in ``workspace`` for :func:`partial_heads`.  ``geo`` = (region_indices, regions_h,
+    raw_size) selects the src variant (``codes`` is then None).  Returns (N, H, D, C)."""
+    lib = _lib.load()
+    q, k, v, coords, codes, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, codes, w_rpe_weight, alpha,
+                                                                block_size, w_per_dist)
+    prec = precision_code(precision)
+    _lib.check(lib.hept_check_shape(n, h, d, c, tl, block_size), "hept_check_shape")
+    if workspace.numel() < int(lib.hept_workspace_bytes(n, h, d, c, tl, block_size, prec)):
+        raise ValueError("workspace too small: size it with ops.workspace_bytes")
+    if geo is None:
+        rc = lib.hept_partial_begin(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), codes.data_ptr(),
+                                    w.data_ptr(), alpha.data_ptr(), n, h, d, c, w_per_dist, t, t0, tl, block_size, prec,
+                                    workspace.data_ptr(), workspace.numel(), _stream(q))
+    else:
+        region_indices, regions_h, raw_size = geo
+        eta, phi, cfac = geo_args(region_indices, regions_h, t, h, n)
+        rc = lib.hept_partial_begin_src(q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(), eta.data_ptr(),
+                                        phi.data_ptr(), cfac.data_ptr(), int(raw_size), w.data_ptr(), alpha.data_ptr(),
+                                        n, h, d, c, w_per_dist, t, t0, tl, block_size, prec, workspace.data_ptr(),
+                                        workspace.numel(), _stream(q))
+    _lib.check(rc, "hept_partial_begin")
+    return n, h, d, c
+
+
+@_on_device
+def partial_heads(workspace: torch.Tensor, dims: Tuple[int, int, int, int], tl: int, block_size: int, precision,
+                  h0: int, dst: torch.Tensor) -> None:
+    """Second half (``hept_partial_heads``): block attention of heads [h0, h0 + dst.shape[1]) for the tables of the
+    preceding :func:`partial_begin`, summed over those tables into ``dst`` (n_pad, hg, row) -- int32 rows of 16 (packed)
+    or float32 rows of 32; rows at and after N are zero."""
+    lib = _lib.load()
+    n, h, d, c = dims
+    n_pad, hg, row = dst.shape
+    packed = dst.dtype == torch.int32
+    if (packed and row != 16) or (not packed and (dst.dtype != torch.float32 or row != 32)) or not dst.is_contiguous():
+        raise ValueError("dst must be a contiguous (n_pad, hg, 16) int32 or (n_pad, hg, 32) float32 tensor")
+    _lib.check(lib.hept_partial_heads(workspace.data_ptr(), workspace.numel(), n, h, d, c, tl, block_size,
+                                      precision_code(precision), h0, hg, n_pad, PREC_BF16 if packed else PREC_F32,
+                                      dst.data_ptr(), _stream(dst)), "hept_partial_heads")
+
+
+@_on_device
+def combine_groups(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int = 0,
+                   n_count: Optional[int] = None) -> torch.Tensor:
+    """``combine_out`` on rows that arrive split by head groups: ``part`` is (G, Tl, N, HG, row) -- group g holds heads
+    [g*HG, (g+1)*HG) -- and is summed over Tl (the slices received from the ranks); returns (n_count, D)."""
+    lib = _lib.load()
+    if part.dim() != 5 or not part.is_contiguous():
+        raise ValueError("part must be a contiguous (groups, tables, points, heads per group, row) tensor")
+    g, tl, n, hg, row = part.shape
+    n_count = n - n0 if n_count is None else n_count
+    w = _f32c(out_weight, "out_linear.weight")
+    b = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
+    out = torch.empty(n_count, head_dim, device=part.device, dtype=torch.float32)
+    _lib.check(lib.hept_combine_groups(part.data_ptr(), _part_prec(part), tl, n, g * hg, head_dim, n0, n_count, hg,
+                                       tl * n * hg * row, w.data_ptr(), b.data_ptr() if b is not None else None,
+                                       out.data_ptr(), _stream(part)), "hept_combine_groups")
+    return out
 
 
 def profile_enable(mode: int, max_calls: int = 0, stride: int = 1) -> None:

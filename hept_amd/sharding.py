@@ -20,12 +20,19 @@ RCCL/xGMI:
 * ``mode="all_reduce"``: all-reduce of ``acc``, every rank finishes all points
   (used on backends without reduce-scatter, e.g. gloo in the CPU tests).
 
+The all-to-all is pipelined behind the block attention (``TableSharding.pipelined``): the heads are cut into
+``head_groups`` groups; as soon as the block attention of group g has written its table-summed rows, a
+communication stream sends them while the main stream computes group g + 1, and the HIP combine reads the
+received groups in place (``hept_combine_groups``).  Only the last group's transfer, the combine of the N/G-point
+slice and the all-gather of the (N, D) output stay on the critical path.
+
 This module is device-agnostic glue around ``torch.distributed``; the
 numerator/denominator arithmetic stays in the HIP ``combine_out`` kernel, which
 is passed in as ``finish_fn``.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -46,8 +53,13 @@ def table_slice(n_tables: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 class TableSharding:
-    def __init__(self, n_tables: int, group=None, mode: Optional[str] = None, always_exchange: bool = False):
+    def __init__(self, n_tables: int, group=None, mode: Optional[str] = None, always_exchange: bool = False,
+                 head_groups: Optional[int] = None):
         self.group = group
+        # head groups of the pipelined all-to-all (2: the second half of the block attention hides the first transfer)
+        self.head_groups = int(os.environ.get("HEPT_HEAD_GROUPS", "2")) if head_groups is None else int(head_groups)
+        self._bufs = {}
+        self._comm = None
         self.always_exchange = always_exchange  # run the collectives even on a 1-rank group (tests)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -59,6 +71,73 @@ class TableSharding:
         if self.mode == "all_to_all" and self.world > 8:
             raise ValueError("all_to_all mode sums at most 8 received slices (one node)")
         table_slice(n_tables, self.rank, self.world)  # validate
+
+    def describe(self) -> str:
+        if self.mode == "all_to_all":
+            return f"all_to_all pipelined in {self.head_groups} head group(s) + all_gather"
+        return self.mode
+
+    def groups_for(self, n_heads: int) -> int:
+        """Head groups actually used for ``n_heads`` heads (equal groups only)."""
+        g = max(1, min(self.head_groups, n_heads))
+        while n_heads % g != 0:
+            g -= 1
+        return g
+
+    def _all_gather_rows(self, full: torch.Tensor, mine: torch.Tensor) -> None:
+        if dist.get_backend(self.group) == "gloo":  # gloo has no all_gather_into_tensor
+            per = mine.shape[0]
+            parts = [full[r * per:(r + 1) * per] for r in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+        else:
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+
+    def pipelined(self, n: int, n_heads: int, row: int, dtype: torch.dtype, device: torch.device,
+                  produce: Callable[[int, int, torch.Tensor], None],
+                  finish_fn: Callable[[torch.Tensor, int], torch.Tensor]) -> torch.Tensor:
+        """The all-to-all exchange with its transfers hidden behind the producer.
+
+        ``produce(g, h0, dst)`` fills ``dst`` (world * per, hg, row) with this rank's table-summed rows of heads
+        [h0, h0 + hg) on the current stream; group g is sent (rank r gets points [r * per, (r + 1) * per)) while
+        ``produce`` runs for group g + 1.  ``finish_fn(recv, count)`` gets ``recv`` (G, world, per, hg, row) -- for
+        every head group the slices of all ranks -- sums over the ranks and returns ``(count, D)`` for the first
+        ``count`` points of this rank's slice.  Returns the full (N, D) output on every rank.
+        """
+        ng = self.groups_for(n_heads)
+        hg = n_heads // ng
+        per = (n + self.world - 1) // self.world
+        key = (n, n_heads, row, dtype, device, ng)
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            self._bufs.clear()  # one shape at a time: the buffers are as large as the partial rows
+            send = torch.empty((ng, self.world * per, hg, row), device=device, dtype=dtype)
+            recv = torch.empty((ng, self.world, per, hg, row), device=device, dtype=dtype)
+            events = [torch.cuda.Event() for _ in range(ng)] if device.type == "cuda" else None
+            bufs = self._bufs[key] = (send, recv, events)
+        send, recv, events = bufs
+        on_gpu = device.type == "cuda"
+        if on_gpu and self._comm is None:
+            self._comm = torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream(device) if on_gpu else None
+        for g in range(ng):
+            produce(g, g * hg, send[g])
+            if on_gpu:
+                events[g].record(main)
+                self._comm.wait_event(events[g])
+                with torch.cuda.stream(self._comm):
+                    dist.all_to_all_single(recv[g].view(self.world * per, hg, row), send[g], group=self.group)
+            else:
+                dist.all_to_all_single(recv[g].view(self.world * per, hg, row), send[g], group=self.group)
+        if on_gpu:
+            main.wait_stream(self._comm)
+        _, cnt = self.point_slice(n)
+        out_slice = finish_fn(recv, cnt)
+        d = out_slice.shape[1]
+        if cnt != per:
+            out_slice = torch.cat([out_slice, out_slice.new_zeros((per - cnt, d))], dim=0)
+        full = torch.empty((self.world * per, d), device=device, dtype=out_slice.dtype)
+        self._all_gather_rows(full, out_slice.contiguous())
+        return full[:n]
 
     def local_tables(self) -> Tuple[int, int]:
         return table_slice(self.n_tables, self.rank, self.world)
@@ -107,5 +186,5 @@ class TableSharding:
         if cnt != per:
             out_slice = torch.cat([out_slice, out_slice.new_zeros((per - cnt, d))], dim=0)
         full = torch.empty((padded, d), device=acc.device, dtype=out_slice.dtype)
-        dist.all_gather_into_tensor(full, out_slice.contiguous(), group=self.group)
+        self._all_gather_rows(full, out_slice.contiguous())
         return full[:n]

@@ -59,7 +59,8 @@ extern "C" {
                                 formats as HEPT_PREC_F32, ~2x slower -- kept as the in-library ground truth */
 
 #define HEPT_ROW 32          /* padded row width (elements) of qhat / k / v / part rows */
-#define HEPT_MAX_TABLES 8    /* tables per call */
+#define HEPT_MAX_TABLES 8    /* tables per hept_prep_hash / hept_sort_tables call; the whole-operator entry points
+                                take any number of tables and walk them in chunks of this size */
 #define HEPT_MAX_BLOCK 256   /* largest block_size */
 
 /* ABI version of this library (bumped on any signature change). */
@@ -119,6 +120,13 @@ int hept_segmented_argsort_ragged(const float* keys, int S, int L, const int32_t
 int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos,
                     int N, int H, int D, int Tl, int B, int precision, float* part, void* stream);
 
+/* The same for heads [h0, h0 + hg) only (table sharding sends head groups one at a time): the row
+ * of (table t, point n, head h) goes to row index (t * n_rows_out + n) * hout + (h - hsub) of `part`
+ * (hept_block_attn = h0 0, hg H, hout H, hsub 0, n_rows_out N).  n_rows_out >= N. */
+int hept_block_attn_heads(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos,
+                          int N, int H, int D, int Tl, int B, int precision, int h0, int hg, int hout, int hsub,
+                          int n_rows_out, float* part, void* stream);
+
 /* Format of the partial rows hept_block_attn writes for (precision, D): HEPT_PREC_BF16 (packed) or
  * HEPT_PREC_F32. */
 int hept_part_precision(int precision, int D);
@@ -129,12 +137,25 @@ int hept_part_precision(int precision, int D);
 int hept_reduce_tables(const float* part, int part_precision, int Tl, int N, int H, int D, float* acc,
                        int acc_precision, void* stream);
 
+/* One head group of the same sum: dst (n_pad, hg, row) = sum_t part[t][n][h0 + j] for j < hg; points [N, n_pad)
+ * (padding up to a multiple of the rank count) get zero rows. */
+int hept_reduce_heads(const float* part, int part_precision, int Tl, int N, int H, int D, int h0, int hg,
+                      int n_pad, float* dst, int acc_precision, void* stream);
+
 /* replaces the cross-table combine (example/hept.py:79) and out_linear (:80) for points
  * [n0, n0+n_count): out[n] = bias + W . (sum_t numer / sum_t denom).  `part` may hold Tl >= 1
  * tables (Tl == 1: an already reduced `acc`).  out points at row n0 of the (N, D) output. */
 int hept_combine_out(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
                      int n_count, const float* out_weight, const float* out_bias, float* out,
                      void* stream);
+
+/* hept_combine_out on partial rows that arrive split by head groups: the rows of heads [g*HG, (g+1)*HG) live in
+ * their own (Tl, N, HG, row) buffer at part + g * group_stride (in 4-byte units); H % HG == 0.  HG == H is
+ * hept_combine_out.  (Table sharding: the "tables" are the slices received from the ranks, one buffer per
+ * exchanged head group.) */
+int hept_combine_groups(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
+                        int n_count, int HG, size_t group_stride, const float* out_weight,
+                        const float* out_bias, float* out, void* stream);
 
 /* Whole operator for tables [t0, t0+Tl): everything above in one call.
  * hept_forward writes out (N, D); hept_forward_partial stops at acc (N, H, row) in the row format
@@ -149,6 +170,24 @@ int hept_forward_partial(const float* q, const float* k, const float* v, const f
                          int N, int H, int D, int C, int K, int T, int t0, int Tl, int B,
                          int precision, int acc_precision, void* workspace, size_t workspace_bytes,
                          float* acc, void* stream);
+
+/* Table sharding with the exchange pipelined behind the block attention: hept_partial_begin runs
+ * everything up to the sort for tables [t0, t0+Tl) and leaves rows and permutations in `workspace`
+ * (hept_workspace_bytes(N,H,D,C,Tl,B,precision)); hept_partial_heads then runs the block attention for heads
+ * [h0, h0+hg) and writes the sum over the local tables as dst (n_pad, hg, row) in the row format acc_precision --
+ * the caller sends that head group to the other ranks while the next group is computed.  The same workspace and
+ * sizes must be passed to both; the sequence begin, heads(0..), heads(..) is stream-ordered. */
+int hept_partial_begin(const float* q, const float* k, const float* v, const float* coords,
+                       const int64_t* codes, const float* w_rpe, const float* alpha,
+                       int N, int H, int D, int C, int K, int T, int t0, int Tl, int B, int precision,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int hept_partial_begin_src(const float* q, const float* k, const float* v, const float* coords,
+                           const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
+                           const float* w_rpe, const float* alpha,
+                           int N, int H, int D, int C, int K, int T, int t0, int Tl, int B, int precision,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int hept_partial_heads(void* workspace, size_t workspace_bytes, int N, int H, int D, int C, int Tl, int B,
+                       int precision, int h0, int hg, int n_pad, int acc_precision, float* dst, void* stream);
 
 /* SURVEY.md §8 f-3 — the reference's src variant of the same operator (src/models/attention/hept.py:74-117, caller
  * src/models/baselines/transformer.py:43-57): no AND codes; the sort key is hash + get_geo_shift (see

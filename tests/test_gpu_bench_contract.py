@@ -15,8 +15,10 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"}
 
 
-def _run(*args):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+def _run(*args, **env_extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", *args],
                          capture_output=True, text=True, env=env, cwd=ROOT)
     assert run.returncode == 0, run.stderr[-2000:]
@@ -25,9 +27,15 @@ def _run(*args):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("precision,bound,dtype", [("bf16", "hbm", "bf16"), ("fp32", "mfma", "f32")])
+@pytest.mark.parametrize("precision,bound,dtype", [("bf16", "hbm", "bf16"), ("fp32", "hbm", "f32")])
 def test_bench_line(precision, bound, dtype, gpu_device):
     d = _run("--precision", precision, "--no-cpu-baseline")
+    if precision == "bf16":  # the default run carries the reference-precision record and BASELINE config 4
+        f = d["fp32"]
+        assert f["dtype"] == "f32" and f["ms_per_step"] > d["ms_per_step"] and 0.0 < f["roofline"]["frac"] < 1.0
+        assert f["roofline"]["bound"] == "hbm" and f["roofline"]["kernel"] == "block_attn_split_kernel"
+        assert d["c4"]["ms_per_step"] < d["ms_per_step"] and "n_hashes=1" in d["c4"]["workload"]
+    assert d["config"]["rccl_ranks"] == 0
     assert KEYS <= set(d) and ROOF <= set(d["roofline"])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["metric"] == "attention-fwd points/sec" and d["unit"] == "points/s" and d["scaling"] == "weak"
@@ -40,4 +48,24 @@ def test_bench_line(precision, bound, dtype, gpu_device):
 
 def test_bench_line_with_the_exchange_forced_on(gpu_device):
     d = _run("--force-dist", "--no-cpu-baseline")
-    assert KEYS <= set(d) and "exchange" in d["config"]["parallelism"]
+    assert KEYS <= set(d) and "exchange" in d["config"]["parallelism"] and d["config"]["rccl_ranks"] == 1
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_launches_its_own_ranks(ranks, gpu_device):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: the parent starts N ranks (here they share the one GPU through
+    a gloo group: RCCL refuses two ranks per device), relays rank 0's line and exits 0."""
+    d = _run("--gpus", str(ranks), "--no-cpu-baseline", HEPT_BENCH_BACKEND="gloo")
+    assert KEYS <= set(d) and d["n_gpus"] == ranks and d["scaling"] == "weak"
+    assert f"({3 * ranks} total)" in d["config"]["workload"] and "all_to_all" in d["config"]["parallelism"]
+    assert abs(d["value"] - ranks * 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert f"n_hashes={ranks}" in d["c4"]["workload"]
+
+
+def test_bench_launcher_reports_a_failing_rank(gpu_device):
+    env = dict(os.environ, HEPT_BENCH_BACKEND="gloo", HEPT_BENCH_FAIL_RANK="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert run.returncode != 0 and not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]

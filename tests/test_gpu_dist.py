@@ -30,9 +30,11 @@ def nccl_group(gpu_device):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["all_to_all", "reduce_scatter", "all_reduce"])
+@pytest.mark.parametrize("mode", ["all_to_all", "all_to_all/1", "all_to_all/4", "all_to_all/8", "reduce_scatter",
+                                  "all_reduce"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_sharded_module_equals_plain_module(mode, precision, nccl_group, gpu_device):
+    mode, _, groups = mode.partition("/")  # all_to_all/G: the pipelined exchange with G head groups (default 2)
     inp, _ = cases.load_case("g6_block100")
     g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
     h, e, t = inp["alpha"].shape
@@ -40,7 +42,8 @@ def test_sharded_module_equals_plain_module(mode, precision, nccl_group, gpu_dev
     sd = {"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"], "e2lsh.alpha": inp["alpha"]}
     plain = HEPTAttention(e, **kw)
     shard = HEPTAttention(e, process_group=nccl_group, **kw)
-    shard.sharding = TableSharding(t, nccl_group, mode=mode, always_exchange=True)
+    shard.sharding = TableSharding(t, nccl_group, mode=mode, always_exchange=True,
+                                   head_groups=int(groups) if groups else None)
     for m in (plain, shard):
         m.load_state_dict(sd, strict=True)
         m.to(gpu_device).eval()

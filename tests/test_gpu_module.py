@@ -56,8 +56,45 @@ def test_module_bf16_and_errors(gpu_device):
     ref = torch.from_numpy(fx["out"])
     err = (out.cpu() - ref).abs().amax(-1)
     assert (err <= 2.5e-2 * (ref.abs().amax(-1) + 1e-3)).float().mean() >= 0.97
-    with pytest.raises(RuntimeError, match="training needs precision='fp32'"):
-        m(g["q"].clone().requires_grad_(True), g["k"], g["v"], **kw)
+    # a 16-bit module trains through the f32-tile kernels (the reference trains through the same operator,
+    # example/trainer.py:11-22): same values as the fp32 module, gradients flow
+    q = g["q"].clone().requires_grad_(True)
+    out_t = m(q, g["k"], g["v"], **kw)
+    m32, _ = _module(inp, gpu_device)
+    with torch.no_grad():
+        out32 = m32(g["q"], g["k"], g["v"], **kw)
+    torch.testing.assert_close(out_t, out32, rtol=1e-5, atol=1e-6)
+    out_t.sum().backward()
+    assert q.grad is not None and bool(q.grad.abs().sum() > 0)
+    # model.eval(); model(x) WITHOUT no_grad and without input gradients: served by the inference path (one warning)
+    with pytest.warns(UserWarning, match="runs the inference path"):
+        out_e = m(g["q"], g["k"], g["v"], **kw)
+    assert torch.equal(out_e, out) and not out_e.requires_grad
+
+
+def test_more_tables_than_one_chunk(gpu_device):
+    """n_hashes = 10 > HEPT_MAX_TABLES: the entry points walk the tables in chunks (the reference takes any n_hashes,
+    example/hept.py:37-41)."""
+    from hept_amd.synthetic import make_inputs
+
+    inp = make_inputs([1500, 700], block_size=128, n_hashes=10, seed=3, cluster_size=8)
+    inp["block_size"] = 128
+    ref = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
+                     inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=128, w_per_dist=10, keep=False)["out"]
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    for precision, atol, rtol in (("fp32", 1e-5, 1e-4), ("bf16", 2e-2, 2e-2)):
+        m, w_rpe = _module(inp, gpu_device, precision=precision)
+        with torch.no_grad():
+            out = m(g["q"], g["k"], g["v"], w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"]).cpu()
+        ok = ((out - ref).abs() <= atol + rtol * ref.abs()).all(-1).float().mean().item()
+        assert ok >= 0.99, (precision, ok)
+        # tables [0, 8) + [8, 10) as two partial calls, summed: the same rows as the one-call chunked walk
+        if precision == "fp32":
+            args = (g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"])
+            a = ops.forward_partial(*args, block_size=128, w_per_dist=10, t0=0, tl=8)
+            b = ops.forward_partial(*args, block_size=128, w_per_dist=10, t0=8, tl=2)
+            whole = ops.forward_partial(*args, block_size=128, w_per_dist=10, t0=0, tl=10)
+            torch.testing.assert_close(whole, a + b, rtol=1e-6, atol=1e-30)
     with torch.no_grad(), pytest.raises(ValueError, match="multiple of block_size"):
         m(g["q"][:150], g["k"][:150], g["v"][:150], w_rpe=w_rpe, coords=g["coords"][:150],
           combined_shifts=g["combined_shifts"][..., :150])

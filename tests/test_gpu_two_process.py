@@ -46,6 +46,70 @@ def _worker(rank, world, port, name, precision, mode, ret):
         dist.destroy_process_group()
 
 
+def _train_worker(rank, world, port, name, ret):
+    """Table sharding under autograd: every rank differentiates its own tables, the ranks' gradients are summed."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hept_amd import HEPTAttention
+
+        dev = torch.device("cuda", 0)
+        inp, _ = cases.load_case(name)
+        g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+        h, e, t = inp["alpha"].shape
+        m = HEPTAttention(e, h_dim=24, num_heads=h, block_size=inp["block_size"], n_hashes=t, num_w_per_dist=10,
+                          precision="bf16", process_group=dist.group.WORLD)  # 16-bit inference precision: trains in f32
+        m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
+                           "e2lsh.alpha": inp["alpha"]})
+        m = m.to(dev).train()
+        w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(dev)
+        with torch.no_grad():
+            w_rpe.weight.copy_(g["w_rpe_weight"])
+        q, k, v = (g[x].clone().requires_grad_(True) for x in "qkv")
+        out = m(q, k, v, w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+        gen = torch.Generator().manual_seed(11)
+        out.backward(torch.randn(out.shape, generator=gen).to(dev))
+        ret[rank] = {"out": out.detach().cpu(), "dq": q.grad.cpu(), "dk": k.grad.cpu(), "dv": v.grad.cpu(),
+                     "dw_rpe": w_rpe.weight.grad.cpu(), "dW": m.out_linear.weight.grad.cpu()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_matches_single_process(gpu_device):
+    name, world = "g6_block100", 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_train_worker, args=(world, port, name, ret), nprocs=world, join=True)
+    from hept_amd import HEPTAttention
+
+    inp, _ = cases.load_case(name)
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    h, e, t = inp["alpha"].shape
+    m = HEPTAttention(e, h_dim=24, num_heads=h, block_size=inp["block_size"], n_hashes=t, num_w_per_dist=10)
+    m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
+                       "e2lsh.alpha": inp["alpha"]})
+    m = m.to(gpu_device).train()
+    w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(gpu_device)
+    with torch.no_grad():
+        w_rpe.weight.copy_(g["w_rpe_weight"])
+    q, k, v = (g[x].clone().requires_grad_(True) for x in "qkv")
+    out = m(q, k, v, w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+    gen = torch.Generator().manual_seed(11)
+    out.backward(torch.randn(out.shape, generator=gen).to(gpu_device))
+    want = {"out": out.detach().cpu(), "dq": q.grad.cpu(), "dk": k.grad.cpu(), "dv": v.grad.cpu(),
+            "dw_rpe": w_rpe.weight.grad.cpu(), "dW": m.out_linear.weight.grad.cpu()}
+    for r in range(world):
+        for key, ref in want.items():
+            scale = ref.abs().max().item() + 1e-30
+            err = (ret[r][key] - ref).abs().max().item() / scale
+            # same kernels on the same tables; only the association of the table sums differs (f32 round-off)
+            assert err < 2e-5, (r, key, err)
+
+
 @pytest.mark.parametrize("world,mode,precision", [(2, "all_reduce", "fp32"), (2, "all_reduce", "bf16"),
                                                   (2, "all_to_all", "fp32"), (2, "all_to_all", "bf16"),
                                                   (3, "all_to_all", "bf16"), (3, "all_to_all", "mixed16")])

@@ -74,7 +74,7 @@ def _finish_cpu(inp):
     return fn
 
 
-def _worker(rank, world, port, mode, name, ret):
+def _worker(rank, world, port, mode, name, ret, groups=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -82,9 +82,40 @@ def _worker(rank, world, port, mode, name, ret):
         torch.set_num_threads(2)
         inp, _ = cases.load_case(name)
         n_tables = inp["alpha"].shape[2]
-        sh = TableSharding(n_tables, dist.group.WORLD, mode="all_to_all" if mode == "all_to_all_packed" else mode)
+        sh = TableSharding(n_tables, dist.group.WORLD,
+                           mode="all_to_all" if mode == "all_to_all_packed" or mode.startswith("pipelined") else mode)
         t0, tl = sh.local_tables()
         acc = _acc_from_oracle(inp, t0, tl)
+        if mode.startswith("pipelined"):
+            # the production exchange: head groups sent one at a time (TableSharding.pipelined); the producer and the
+            # finishing call are CPU stand-ins for hept_partial_heads / hept_combine_groups
+            if mode == "pipelined_packed":
+                acc = _pack_rows(acc)
+            n, h, row = acc.shape
+            sh.mode, sh.head_groups = "all_to_all", groups
+            d = inp["out_weight"].shape[0]
+            seen = []
+
+            def produce(g, h0, dst):
+                seen.append((g, h0, tuple(dst.shape)))
+                dst.zero_()
+                dst[:n] = acc[:, h0:h0 + dst.shape[1]]
+
+            def finish(recv, cnt):
+                wide = unpack_part(recv).sum(1)                          # (G, per, hg, 32): summed over the ranks
+                rows = wide.permute(1, 0, 2, 3).reshape(wide.shape[1], h, 32)[:cnt]
+                per_head = rows[..., :d] / rows[..., d:d + 1]
+                return torch.nn.functional.linear(per_head.reshape(cnt, -1), inp["out_weight"], inp["out_bias"])
+
+            out = sh.pipelined(n, h, row, acc.dtype, acc.device, produce, finish)
+            assert [s_[0] for s_ in seen] == list(range(sh.groups_for(h)))
+            if rank == 0:
+                ret["out"] = out.clone()
+            gathered = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(gathered, out)
+            if rank == 0:
+                ret["same_on_all_ranks"] = all(torch.equal(gathered[0], g) for g in gathered)
+            return
         packed = mode == "all_to_all_packed"
         if packed:
             acc, mode = _pack_rows(acc), "all_to_all"
@@ -117,6 +148,26 @@ def _worker(rank, world, port, mode, name, ret):
             ret["same_on_all_ranks"] = all(torch.equal(gathered[0], g) for g in gathered)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,name,world,groups", [
+    ("pipelined", "g6_block100", 2, 2), ("pipelined_packed", "g6_block100", 2, 4), ("pipelined", "g4_pileup", 3, 2),
+    ("pipelined_packed", "g4_pileup", 3, 8), ("pipelined", "g1_rand512", 2, 3)])
+def test_pipelined_exchange_matches_single_process(mode, name, world, groups):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), mode, name, ret, groups), nprocs=world, join=True)
+    inp, _ = cases.load_case(name)
+    assert ret["same_on_all_ranks"]
+    if mode == "pipelined_packed":
+        n_tables = inp["alpha"].shape[2]
+        accs = [unpack_part(_pack_rows(_acc_from_oracle(inp, *table_slice(n_tables, r, world)))) for r in range(world)]
+        want = _finish_cpu(inp)(torch.stack(accs), 0, accs[0].shape[0])
+    else:
+        want = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
+                          inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=inp["block_size"],
+                          w_per_dist=inp["w_per_dist"], keep=False)["out"]
+    torch.testing.assert_close(ret["out"], want, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("mode,name,world", [
