@@ -49,7 +49,8 @@ def test_shape_checks_are_host_side(lib):
     assert ok(2400, 8, 24, 6, 3, 100) == 0
     assert ok(60000, 8, 24, 6, 3, 128) == 1      # N % B != 0 (the reference raises EinopsError)
     assert ok(4096, 4, 24, 6, 3, 128) == 1       # heads
-    assert ok(4096, 8, 24, 6, 9, 128) == 1       # too many tables per call
+    assert ok(4096, 8, 24, 6, 9, 128) == 0       # any number of tables (walked in chunks of HEPT_MAX_TABLES)
+    assert ok(4096, 8, 24, 6, 0, 128) == 1
     assert ok(4096, 8, 24, 6, 3, 512) == 1       # block too large
     assert ok(4096, 8, 20, 6, 3, 128) == 1       # head dim
 
