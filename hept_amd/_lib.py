@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 # (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
@@ -23,6 +23,7 @@ _ERRORS = {
     1: "HEPT_ERR_SHAPE: unsupported or inconsistent sizes",
     2: "HEPT_ERR_LAUNCH: HIP reported a launch error",
     3: "HEPT_ERR_ARG: null pointer or workspace too small",
+    4: "HEPT_ERR_COMM: RCCL unavailable or reported an error",
 }
 
 _P = c_void_p
@@ -63,6 +64,15 @@ SIGNATURES = {
     "hept_rpe_scale_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "hept_prepare_workspace_bytes": (c_size_t, [c_int] * 5),
     "hept_prepare_input": (c_int, [_P, c_int, _P, _P] + [c_int] * 4 + [_P] + [c_int] * 3 + [_P, c_size_t] + [_P] * 5),
+    "hept_comm_unique_id": (c_int, [_P]),
+    "hept_comm_create": (c_int, [_P, c_int, c_int, _P]),
+    "hept_comm_destroy": (c_int, [_P]),
+    "hept_comm_rank": (c_int, [_P]),
+    "hept_comm_world": (c_int, [_P]),
+    "hept_comm_last_error": (ctypes.c_char_p, []),
+    "hept_exchange_bytes": (c_size_t, [c_int] * 5),
+    "hept_forward_sharded": (c_int, [_P] * 10 + [c_int] * 11 + [_P, c_size_t, _P, c_size_t, _P, _P]),
+    "hept_forward_sharded_src": (c_int, [_P] * 8 + [c_int] + [_P] * 4 + [c_int] * 11 + [_P, c_size_t, _P, c_size_t, _P, _P]),
     "hept_profile_enable": (c_int, [c_int, c_int]),
     "hept_profile_read": (c_int, [_P, _P]),
     "hept_profile_stride": (c_int, [c_int]),
@@ -103,4 +113,7 @@ class AttnParams(ctypes.Structure):
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        raise RuntimeError(f"{what} failed: {_ERRORS.get(rc, f'error code {rc}')}")
+        detail = ""
+        if rc == 4 and _lib is not None:
+            detail = " (" + (_lib.hept_comm_last_error() or b"").decode(errors="replace") + ")"
+        raise RuntimeError(f"{what} failed: {_ERRORS.get(rc, f'error code {rc}')}{detail}")

@@ -1,6 +1,7 @@
 // Whole-operator entry points of the C ABI (include/hept_hip.h): workspace carving + launch order.
 // Replaces HEPTAttention.forward, reference example/hept.py:43-81.
 #include "common.h"
+#include "comm.h"
 
 namespace {
 
@@ -14,6 +15,7 @@ struct Workspace {
     float* kproj;
     float* minmax;
     int32_t* pos;   // (2, Tl, H, N): q then k
+    int32_t* pos_chunk;  // Tl > HEPT_MAX_TABLES only: (2, chunk, H, N) the sort of one chunk writes before it is filed
     void* sort_ws;
     float* part;    // (Tl, N, H, 32)
     size_t bytes;
@@ -41,6 +43,7 @@ Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
     w.kproj = reinterpret_cast<float*>(take((size_t)Tc * H * N * 4));
     w.minmax = reinterpret_cast<float*>(take((size_t)HEPT_PREP_GRID * Tc * H * 4 * 4));
     w.pos = reinterpret_cast<int32_t*>(take((size_t)2 * Tl * H * N * 4));
+    w.pos_chunk = Tl > Tc ? reinterpret_cast<int32_t*>(take((size_t)2 * Tc * H * N * 4)) : nullptr;
     w.sort_ws = take(hept_sort_workspace_bytes(N, H, Tc));
     w.part = reinterpret_cast<float*>(take((size_t)Tl * N * H * 32 * 4));
     w.bytes = off;
@@ -93,12 +96,20 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
                             t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream);
         if (rc) return rc;
         if (c0 == 0) prof_mark(1, st);
-        const size_t off = (size_t)c0 * H * N;
+        // the sort writes one (2, tc, H, N) array: straight into w.pos when the call is a single chunk
+        int32_t* cq = Tl <= HEPT_MAX_TABLES ? qpos : w.pos_chunk;
+        int32_t* ck = cq + (size_t)tc * H * N;
         rc = geo.eta ? hept_sort_tables_src(w.qproj, w.kproj, geo.eta, geo.phi, geo.cfac, w.minmax, N, H, T, t0 + c0, tc,
-                                            w.sort_ws, qpos + off, kpos + off, stream)
-                     : hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0 + c0, tc, w.sort_ws, qpos + off,
-                                        kpos + off, stream);
+                                            w.sort_ws, cq, ck, stream)
+                     : hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0 + c0, tc, w.sort_ws, cq, ck,
+                                        stream);
         if (rc) return rc;
+        if (cq != qpos) {
+            const size_t off = (size_t)c0 * H * N, bytes = (size_t)tc * H * N * 4;
+            if (hipMemcpyAsync(qpos + off, cq, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(kpos + off, ck, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return HEPT_ERR_LAUNCH;
+        }
     }
     prof_mark(2, st);
     return HEPT_OK;
@@ -117,7 +128,7 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 10; }
+extern "C" int hept_abi_version(void) { return 11; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -258,24 +269,20 @@ extern "C" int hept_partial_begin_src(const float* q, const float* k, const floa
                               D, C, K, T, t0, Tl, B, precision, workspace, workspace_bytes, stream);
 }
 
-extern "C" int hept_partial_heads(void* workspace, size_t workspace_bytes, int N, int H, int D, int C, int Tl, int B,
-                                  int precision, int h0, int hg, int n_pad, int acc_precision, float* dst,
-                                  void* stream) {
-    if (!workspace || !dst) return HEPT_ERR_ARG;
-    int rc = hept_check_shape(N, H, D, C, Tl, B);
-    if (rc) return rc;
-    if (h0 < 0 || hg < 1 || h0 + hg > H || n_pad < N) return HEPT_ERR_SHAPE;
-    const int pprec = hept_part_precision(precision, D);
-    if (acc_precision != HEPT_PREC_F32 && acc_precision != pprec) return HEPT_ERR_SHAPE;
-    const Workspace w = carve(workspace, N, H, C, Tl, precision);
-    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+namespace {
+// block attention of heads [h0, h0 + hg) for the tables of the preceding run_begin, summed over those tables into
+// dst (n_pad, hg, row); rows [N, n_pad) are zero
+int partial_heads_impl(const Workspace& w, int N, int H, int D, int Tl, int B, int precision, int h0, int hg, int n_pad,
+                       int acc_precision, float* dst, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    const int pprec = hept_part_precision(precision, D);
     const int32_t* qpos = w.pos;
     const int32_t* kpos = w.pos + (size_t)Tl * H * N;
     // one local table already in the requested row format: block_attn scatters straight into the group's rows of
-    // dst (n_pad, hg, row); the padding rows [N, n_pad) are zeroed (nothing reads them, but they travel)
+    // dst; the padding rows are zeroed (nothing reads them, but they travel)
     const bool direct = Tl == 1 && pprec == acc_precision;
     const bool rec = g_prof.mode == 1;
+    int rc;
     if (rec) prof_mark(2, st);
     if (direct) {
         const size_t row_bytes = (size_t)hg * (acc_precision == HEPT_PREC_BF16 ? 64 : 128);
@@ -293,6 +300,136 @@ extern "C" int hept_partial_heads(void* workspace, size_t workspace_bytes, int N
     }
     if (rec) prof_call_done();
     return rc;
+}
+}  // namespace
+
+extern "C" int hept_partial_heads(void* workspace, size_t workspace_bytes, int N, int H, int D, int C, int Tl, int B,
+                                  int precision, int h0, int hg, int n_pad, int acc_precision, float* dst,
+                                  void* stream) {
+    if (!workspace || !dst) return HEPT_ERR_ARG;
+    int rc = hept_check_shape(N, H, D, C, Tl, B);
+    if (rc) return rc;
+    if (h0 < 0 || hg < 1 || h0 + hg > H || n_pad < N) return HEPT_ERR_SHAPE;
+    if (acc_precision != HEPT_PREC_F32 && acc_precision != hept_part_precision(precision, D)) return HEPT_ERR_SHAPE;
+    const Workspace w = carve(workspace, N, H, C, Tl, precision);
+    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+    return partial_heads_impl(w, N, H, D, Tl, B, precision, h0, hg, n_pad, acc_precision, dst, stream);
+}
+
+// ---- table sharding in one call: kernels on the caller's stream, RCCL transfers of finished head groups on the
+//      communicator's side stream
+extern "C" size_t hept_exchange_bytes(int N, int H, int D, int world, int precision) {
+    if (N < 1 || H < 1 || world < 1) return 0;
+    const size_t per = ((size_t)N + world - 1) / world;
+    const size_t row = hept_part_precision(precision, D) == HEPT_PREC_BF16 ? 64 : 128;
+    return 2 * up256(per * world * H * row);  // send + recv, all head groups
+}
+
+namespace {
+int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
+                         const int64_t* codes, const GeoShift& geo, const float* w_rpe, const float* alpha,
+                         const float* out_weight, const float* out_bias, int N, int H, int D, int C, int K, int T,
+                         int t0, int Tl, int B, int precision, int head_groups, void* workspace,
+                         size_t workspace_bytes, void* xbuf, size_t xbuf_bytes, float* out_full, void* stream) {
+    if (!comm || !q || !k || !v || !coords || !w_rpe || !alpha || !out_weight || !workspace || !xbuf || !out_full)
+        return HEPT_ERR_ARG;
+    int rc = hept_check_shape(N, H, D, C, Tl, B);
+    if (rc) return rc;
+    if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (head_groups < 1 || head_groups > HEPT_MAX_HEAD_GROUPS || H % head_groups != 0) return HEPT_ERR_SHAPE;
+    const Workspace w = carve(workspace, N, H, C, Tl, precision);
+    if (workspace_bytes < w.bytes || xbuf_bytes < hept_exchange_bytes(N, H, D, comm->world, precision))
+        return HEPT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int world = comm->world, hg = H / head_groups;
+    const int per = (N + world - 1) / world, n_pad = per * world;
+    const int aprec = hept_part_precision(precision, D);
+    const size_t row = aprec == HEPT_PREC_BF16 ? 64 : 128;
+    const size_t group_bytes = (size_t)n_pad * hg * row;       // one head group, all ranks' slices
+    char* send = reinterpret_cast<char*>(xbuf);
+    char* recv = send + up256((size_t)n_pad * H * row);
+    rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
+    if (rc) return rc;
+    // Caller's stream: the block attention of the head groups back to back.  Side stream: for every group but the
+    // last, wait for its attention, sum the local tables into the send buffer and put it on the links.  The last
+    // group has nothing left to hide behind: its table sum and transfer run on the caller's stream (a cross-stream
+    // hand-over costs ~15 us each way), which then joins the side stream and combines.
+    const int pprec = hept_part_precision(precision, D);
+    const bool direct = Tl == 1;   // one local table: block_attn scatters straight into the send buffer
+    const int32_t* qpos = w.pos;
+    const int32_t* kpos = w.pos + (size_t)Tl * H * N;
+    const bool rec = g_prof.mode == 1;
+    for (int g = 0; g < head_groups; ++g) {
+        const bool last = g == head_groups - 1;
+        float* dst = reinterpret_cast<float*>(send + g * group_bytes);
+        if (rec) prof_mark(2, st);
+        if (direct) {
+            const size_t row_bytes = (size_t)hg * row;
+            if (n_pad > N && hipMemsetAsync(reinterpret_cast<char*>(dst) + (size_t)N * row_bytes, 0,
+                                            (size_t)(n_pad - N) * row_bytes, st) != hipSuccess)
+                return HEPT_ERR_LAUNCH;
+            rc = hept_block_attn_heads(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, g * hg, hg, hg, g * hg,
+                                       n_pad, dst, stream);
+        } else {
+            rc = hept_block_attn_heads(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, g * hg, hg, H, 0, N,
+                                       w.part, stream);
+        }
+        if (rec) {
+            prof_mark(3, st);
+            prof_call_done();
+        }
+        if (rc) return rc;
+        hipStream_t xs = last ? st : comm->side;
+        if (!last && (hipEventRecord(comm->fork[g], st) != hipSuccess ||
+                      hipStreamWaitEvent(comm->side, comm->fork[g], 0) != hipSuccess))
+            return HEPT_ERR_LAUNCH;
+        if (!direct) {
+            rc = hept_reduce_heads(w.part, pprec, Tl, N, H, D, g * hg, hg, n_pad, dst, aprec, xs);
+            if (rc) return rc;
+        }
+        rc = hept_comm_all_to_all(comm, dst, recv + g * group_bytes, (size_t)per * hg * row, xs);
+        if (rc) return rc;
+    }
+    if (head_groups > 1 &&
+        (hipEventRecord(comm->join, comm->side) != hipSuccess || hipStreamWaitEvent(st, comm->join, 0) != hipSuccess))
+        return HEPT_ERR_LAUNCH;
+    // this rank's points [rank * per, ...): the `world` received slices are the "tables" of the combine
+    const int first = comm->rank * per;
+    const int cnt = first >= N ? 0 : (N - first < per ? N - first : per);
+    float* mine = out_full + (size_t)first * D;
+    rc = hept_combine_groups(reinterpret_cast<const float*>(recv), aprec, world, per, H, D, 0, cnt, hg,
+                             group_bytes / 4, out_weight, out_bias, mine, stream);
+    if (rc) return rc;
+    if (cnt < per && hipMemsetAsync(mine + (size_t)cnt * D, 0, (size_t)(per - cnt) * D * 4, st) != hipSuccess)
+        return HEPT_ERR_LAUNCH;
+    return hept_comm_all_gather_f32(comm, out_full, (size_t)per * D, st);
+}
+}  // namespace
+
+extern "C" int hept_forward_sharded(hept_comm* comm, const float* q, const float* k, const float* v,
+                                    const float* coords, const int64_t* codes, const float* w_rpe,
+                                    const float* alpha, const float* out_weight, const float* out_bias, int N, int H,
+                                    int D, int C, int K, int T, int t0, int Tl, int B, int precision, int head_groups,
+                                    void* workspace, size_t workspace_bytes, void* xbuf, size_t xbuf_bytes,
+                                    float* out_full, void* stream) {
+    if (!codes) return HEPT_ERR_ARG;
+    return forward_sharded_impl(comm, q, k, v, coords, codes, GeoShift{}, w_rpe, alpha, out_weight, out_bias, N, H, D,
+                                C, K, T, t0, Tl, B, precision, head_groups, workspace, workspace_bytes, xbuf,
+                                xbuf_bytes, out_full, stream);
+}
+
+extern "C" int hept_forward_sharded_src(hept_comm* comm, const float* q, const float* k, const float* v,
+                                        const float* coords, const float* eta_idx, const float* phi_idx,
+                                        const float* cfac, int raw_size, const float* w_rpe, const float* alpha,
+                                        const float* out_weight, const float* out_bias, int N, int H, int D, int C,
+                                        int K, int T, int t0, int Tl, int B, int precision, int head_groups,
+                                        void* workspace, size_t workspace_bytes, void* xbuf, size_t xbuf_bytes,
+                                        float* out_full, void* stream) {
+    if (!eta_idx || !phi_idx || !cfac) return HEPT_ERR_ARG;
+    if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    return forward_sharded_impl(comm, q, k, v, coords, nullptr, GeoShift{eta_idx, phi_idx, cfac, raw_size}, w_rpe,
+                                alpha, out_weight, out_bias, N, H, D, C, K, T, t0, Tl, B, precision, head_groups,
+                                workspace, workspace_bytes, xbuf, xbuf_bytes, out_full, stream);
 }
 
 extern "C" int hept_attn_block_forward(const float* x, const float* coords, const int64_t* codes,

@@ -156,8 +156,16 @@ class HEPTAttention(nn.Module):
         ws = self._scratch(ops.workspace_bytes(n, h, d, c, tl, self.block_size, self.precision), q2.device)
         geo = (kwargs["region_indices"], kwargs["regions_h"], kwargs["raw_size"]) if src else None
         if sh.mode == "all_to_all" and (sh.world > 1 or sh.always_exchange):
-            # pipelined: the block attention runs one head group at a time and every finished group is on the links
-            # while the next one is computed
+            comm = sh.native_comm(q2.device)
+            if comm:
+                # one C call: kernels on this stream, RCCL transfers of finished head groups on the communicator's
+                # side stream, combine of this rank's points, all-gather
+                xbuf = sh.exchange_buffer(ops.exchange_bytes(n, h, d, sh.world, self.precision), q2.device)
+                return ops.forward_sharded(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
+                                           self.e2lsh.alpha, self.out_linear.weight, self.out_linear.bias, comm=comm,
+                                           world=sh.world, t0=t0, tl=tl, head_groups=sh.groups_for(h), workspace=ws,
+                                           xbuf=xbuf, geo=geo, **common)
+            # the same pipeline driven from Python over torch.distributed (gloo in the tests; fallback)
             dims = ops.partial_begin(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
                                      self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, geo=geo, **common)
             return sh.pipelined(

@@ -19,7 +19,7 @@ __all__ = [
     "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part",
     "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args",
     "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward", "combine_bwd", "rpe_scale_bwd",
-    "partial_begin", "partial_heads", "combine_groups",
+    "partial_begin", "partial_heads", "combine_groups", "forward_sharded",
 ]
 
 
@@ -75,6 +75,10 @@ def _dims(q: torch.Tensor, coords: torch.Tensor, alpha: torch.Tensor) -> Tuple[i
 
 def workspace_bytes(n, h, d, c, tl, b, precision) -> int:
     return int(_lib.load().hept_workspace_bytes(n, h, d, c, tl, b, precision_code(precision)))
+
+
+def exchange_bytes(n, h, d, world, precision) -> int:
+    return int(_lib.load().hept_exchange_bytes(n, h, d, world, precision_code(precision)))
 
 
 @_on_device
@@ -612,6 +616,43 @@ def combine_groups(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: 
                                        tl * n * hg * row, w.data_ptr(), b.data_ptr() if b is not None else None,
                                        out.data_ptr(), _stream(part)), "hept_combine_groups")
     return out
+
+
+@_on_device
+def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *, comm: int, world: int,
+                    block_size: int, w_per_dist: int, t0: int, tl: int, head_groups: int, precision="fp32",
+                    workspace: torch.Tensor, xbuf: torch.Tensor, geo=None) -> torch.Tensor:
+    """Table-sharded operator in one C call (``hept_forward_sharded``): this rank's tables [t0, t0+tl), the RCCL
+    exchange pipelined by head groups on the communicator's side stream, combine of this rank's points and the
+    all-gather; returns the full (N, D) output.  ``comm`` is a ``hept_comm*`` (see ``hept_amd.sharding``)."""
+    lib = _lib.load()
+    q, k, v, coords, codes, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, codes, w_rpe_weight, alpha,
+                                                                block_size, w_per_dist)
+    prec = precision_code(precision)
+    _lib.check(lib.hept_check_shape(n, h, d, c, tl, block_size), "hept_check_shape")
+    if workspace.numel() < int(lib.hept_workspace_bytes(n, h, d, c, tl, block_size, prec)):
+        raise ValueError("workspace too small: size it with ops.workspace_bytes")
+    if xbuf.numel() < int(lib.hept_exchange_bytes(n, h, d, world, prec)):
+        raise ValueError("exchange buffer too small: size it with hept_exchange_bytes")
+    ow = _f32c(out_weight, "out_linear.weight")
+    ob = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
+    per = (n + world - 1) // world
+    out_full = torch.empty(per * world, d, device=q.device, dtype=torch.float32)
+    tail = (n, h, d, c, w_per_dist, t, t0, tl, block_size, prec, head_groups, workspace.data_ptr(), workspace.numel(),
+            xbuf.data_ptr(), xbuf.numel(), out_full.data_ptr(), _stream(q))
+    if geo is None:
+        rc = lib.hept_forward_sharded(comm, q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(),
+                                      codes.data_ptr(), w.data_ptr(), alpha.data_ptr(), ow.data_ptr(),
+                                      ob.data_ptr() if ob is not None else None, *tail)
+    else:
+        region_indices, regions_h, raw_size = geo
+        eta, phi, cfac = geo_args(region_indices, regions_h, t, h, n)
+        rc = lib.hept_forward_sharded_src(comm, q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(),
+                                          eta.data_ptr(), phi.data_ptr(), cfac.data_ptr(), int(raw_size), w.data_ptr(),
+                                          alpha.data_ptr(), ow.data_ptr(), ob.data_ptr() if ob is not None else None,
+                                          *tail)
+    _lib.check(rc, "hept_forward_sharded")
+    return out_full[:n]
 
 
 def profile_enable(mode: int, max_calls: int = 0, stride: int = 1) -> None:

@@ -60,6 +60,10 @@ class TableSharding:
         self.head_groups = int(os.environ.get("HEPT_HEAD_GROUPS", "2")) if head_groups is None else int(head_groups)
         self._bufs = {}
         self._comm = None
+        # hept_comm* of the native exchange (hept_forward_sharded: RCCL called from the C library, no Python between
+        # the kernels and the collectives); None = not tried yet, 0 = unavailable (torch.distributed path)
+        self._native = None
+        self._xbuf = None
         self.always_exchange = always_exchange  # run the collectives even on a 1-rank group (tests)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -74,8 +78,66 @@ class TableSharding:
 
     def describe(self) -> str:
         if self.mode == "all_to_all":
-            return f"all_to_all pipelined in {self.head_groups} head group(s) + all_gather"
+            via = "RCCL from the C library" if self._native else "torch.distributed"
+            return f"all_to_all pipelined in {self.head_groups} head group(s) + all_gather ({via})"
         return self.mode
+
+    def native_comm(self, device: torch.device) -> int:
+        """``hept_comm*`` for the one-call exchange, or 0 when it is not available (backend other than RCCL,
+        ``HEPT_EXCHANGE=torch``, or communicator creation failed on some rank)."""
+        if self._native is not None:
+            return self._native
+        self._native = 0
+        if (dist.get_backend(self.group) != "nccl" or self.mode != "all_to_all"
+                or os.environ.get("HEPT_EXCHANGE", "native") == "torch" or device.type != "cuda"):
+            return 0
+        import ctypes
+
+        from . import _lib
+
+        lib = _lib.load()
+        ident = (ctypes.c_char * 128)()
+        box = [None]
+        if self.rank == 0 and lib.hept_comm_unique_id(ident) == 0:
+            box[0] = bytes(ident.raw)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=self.group, device=device)
+        handle = ctypes.c_void_p()
+        rc = 1
+        if box[0] is not None and any(box[0]):
+            with torch.cuda.device(device):
+                rc = lib.hept_comm_create(box[0], self.rank, self.world, ctypes.byref(handle))
+        ok = torch.tensor([1 if rc == 0 else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok) == 1:
+            self._native = handle.value
+        else:
+            if rc == 0:
+                lib.hept_comm_destroy(handle)
+            import warnings
+
+            warnings.warn("hept_amd: native RCCL communicator unavailable ("
+                          + (lib.hept_comm_last_error() or b"").decode(errors="replace")
+                          + "); table sharding falls back to torch.distributed collectives")
+        return self._native
+
+    def exchange_buffer(self, nbytes: int, device: torch.device) -> torch.Tensor:
+        if self._xbuf is None or self._xbuf.numel() < nbytes or self._xbuf.device != device:
+            self._xbuf = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        return self._xbuf
+
+    def close(self) -> None:
+        if self._native:
+            from . import _lib
+
+            _lib.load().hept_comm_destroy(self._native)
+        self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def groups_for(self, n_heads: int) -> int:
         """Head groups actually used for ``n_heads`` heads (equal groups only)."""

@@ -47,6 +47,7 @@ extern "C" {
 #define HEPT_ERR_SHAPE 1   /* unsupported or inconsistent sizes */
 #define HEPT_ERR_LAUNCH 2  /* HIP reported a launch error */
 #define HEPT_ERR_ARG 3     /* null pointer / workspace too small */
+#define HEPT_ERR_COMM 4    /* RCCL unavailable or reported an error: see hept_comm_last_error() */
 
 #define HEPT_PREC_F32 0      /* f32 tiles: the reference's numerics.  The tile products run on the bf16 matrix pipe
                                 with every f32 factor split into bf16 pieces (6 products for the logits, 3 for
@@ -188,6 +189,45 @@ int hept_partial_begin_src(const float* q, const float* k, const float* v, const
                            void* workspace, size_t workspace_bytes, void* stream);
 int hept_partial_heads(void* workspace, size_t workspace_bytes, int N, int H, int D, int C, int Tl, int B,
                        int precision, int h0, int hg, int n_pad, int acc_precision, float* dst, void* stream);
+
+/* ---- Table sharding over the GPUs of one node, RCCL over xGMI -------------------------------------
+ * The reference is single-process; its only cross-table coupling is `out = o.sum(0) / logits.sum(0)`
+ * (example/hept.py:79).  One process per GPU owns tables [t0, t0+Tl) and holds a hept_comm: an RCCL communicator
+ * (bound with dlopen at first use, so this library has no link-time dependency on RCCL), a side stream and the
+ * events that order it against the caller's stream.  hept_forward_sharded runs the whole operator on replicated
+ * inputs in ONE call:
+ *   begin (rows, hashes, sort)  ->  for each of `head_groups` head groups: block attention + sum over the local
+ *   tables into the send buffer, then ncclAllToAll of that group on the side stream (rank r receives points
+ *   [r*per, (r+1)*per), per = ceil(N / world)) while the caller's stream computes the next group  ->  join  ->
+ *   combine of the received slices + out_linear for this rank's points, written into its slice of
+ *   out_full (world*per, D)  ->  in-place ncclAllGather of out_full on the caller's stream.
+ * Rows travel in the format hept_part_precision(precision, D) (packed 64-B rows for 16-bit tiles with D == 24,
+ * f32 rows otherwise).  xbuf: hept_exchange_bytes(...) bytes of device scratch that must stay untouched between
+ * calls in flight; out_full rows [0, N) are the result (every rank ends with all of them).
+ * Creating a communicator: rank 0 calls hept_comm_unique_id, the HEPT_COMM_ID_BYTES bytes reach every rank by any
+ * host-side means, every rank (with its GPU current) calls hept_comm_create -- collective and blocking. */
+#define HEPT_MAX_HEAD_GROUPS 8
+#define HEPT_COMM_ID_BYTES 128
+typedef struct hept_comm hept_comm;
+int hept_comm_unique_id(void* id128);
+int hept_comm_create(const void* id128, int rank, int world, hept_comm** out);
+int hept_comm_destroy(hept_comm* comm);
+int hept_comm_rank(const hept_comm* comm);
+int hept_comm_world(const hept_comm* comm);
+const char* hept_comm_last_error(void);
+size_t hept_exchange_bytes(int N, int H, int D, int world, int precision);
+int hept_forward_sharded(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
+                         const int64_t* codes, const float* w_rpe, const float* alpha,
+                         const float* out_weight, const float* out_bias,
+                         int N, int H, int D, int C, int K, int T, int t0, int Tl, int B, int precision,
+                         int head_groups, void* workspace, size_t workspace_bytes, void* xbuf, size_t xbuf_bytes,
+                         float* out_full, void* stream);
+int hept_forward_sharded_src(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
+                             const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
+                             const float* w_rpe, const float* alpha, const float* out_weight, const float* out_bias,
+                             int N, int H, int D, int C, int K, int T, int t0, int Tl, int B, int precision,
+                             int head_groups, void* workspace, size_t workspace_bytes, void* xbuf, size_t xbuf_bytes,
+                             float* out_full, void* stream);
 
 /* SURVEY.md §8 f-3 — the reference's src variant of the same operator (src/models/attention/hept.py:74-117, caller
  * src/models/baselines/transformer.py:43-57): no AND codes; the sort key is hash + get_geo_shift (see

@@ -30,11 +30,14 @@ def nccl_group(gpu_device):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["all_to_all", "all_to_all/1", "all_to_all/4", "all_to_all/8", "reduce_scatter",
-                                  "all_reduce"])
+@pytest.mark.parametrize("mode", ["all_to_all", "all_to_all/1", "all_to_all/4", "all_to_all/8", "all_to_all/2/torch",
+                                  "all_to_all/4/torch", "reduce_scatter", "all_reduce"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_sharded_module_equals_plain_module(mode, precision, nccl_group, gpu_device):
-    mode, _, groups = mode.partition("/")  # all_to_all/G: the pipelined exchange with G head groups (default 2)
+    # all_to_all/G: the pipelined exchange with G head groups (default 2), driven by the C library's own RCCL
+    # communicator (hept_forward_sharded); .../torch: the same pipeline over torch.distributed collectives
+    mode, _, rest = mode.partition("/")
+    groups, _, via = rest.partition("/")
     inp, _ = cases.load_case("g6_block100")
     g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
     h, e, t = inp["alpha"].shape
@@ -44,6 +47,8 @@ def test_sharded_module_equals_plain_module(mode, precision, nccl_group, gpu_dev
     shard = HEPTAttention(e, process_group=nccl_group, **kw)
     shard.sharding = TableSharding(t, nccl_group, mode=mode, always_exchange=True,
                                    head_groups=int(groups) if groups else None)
+    if via == "torch":
+        shard.sharding._native = 0
     for m in (plain, shard):
         m.load_state_dict(sd, strict=True)
         m.to(gpu_device).eval()
@@ -54,6 +59,9 @@ def test_sharded_module_equals_plain_module(mode, precision, nccl_group, gpu_dev
         kwargs = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
         a = plain(*args, **kwargs)
         b = shard(*args, **kwargs)
+        assert torch.equal(b, shard(*args, **kwargs))   # buffers reused across calls
+    if mode == "all_to_all":
+        assert bool(shard.sharding._native) == (via != "torch")
     # same kernels; the sharded path sums the tables before the divide (reduce_tables) instead of inside
     # combine_out, and for 16-bit tiles widens the packed partial rows first: fp32 round-off only
     if mode == "all_to_all" and precision == "bf16":
