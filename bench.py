@@ -323,26 +323,40 @@ def worker(args) -> int:
     tables_per_gpu = args.tables_per_gpu
     inp, attn, step = build(tables_per_gpu, args.precision)
     n, n_raw, C = inp["q"].shape[0], inp["n_raw"], inp["coords"].shape[1]
+    def settle(attn, step):
+        """First sharded steps: walk down the transport ladder (one-sided xGMI stores -> RCCL from the C library ->
+        torch.distributed -> reduce-scatter) until one works on EVERY rank -- a rank-local failure must not leave the
+        others inside an exchange of a different kind, so the ranks agree through a MAX over a failure flag."""
+        dist.barrier()
+        while True:
+            failed = 0
+            try:
+                step()
+                step()
+                torch.cuda.synchronize()
+                attn.sharding.check()
+            except Exception as exc:  # noqa: BLE001
+                print(f"[rank {rank}] exchange '{attn.sharding.describe()}' failed: {exc!r}", file=sys.stderr)
+                failed = 1
+            flag = torch.tensor([failed], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag) == 0:
+                break
+            if not attn.sharding.downgrade():
+                raise SystemExit("no working exchange left")
+        # which transport and how many head groups are fastest is a property of the machine (xGMI store rate against
+        # RCCL's launch latency): measure, keep the best
+        table = attn.sharding.tune(step, dev)
+        if rank == 0 and table:
+            print("exchange tuning (us/step): " + ", ".join(f"{t}/{g}: {v * 1e6:.1f}" for (t, g), v in sorted(table.items())),
+                  file=sys.stderr)
+
     if multi:
-        # first sharded step; the ranks agree on the exchange mode (a rank-local failure must not leave the others
-        # inside a collective of a different kind): MAX of a failure flag over the group
-        failed = 0
-        try:
-            step()
-            torch.cuda.synchronize()
-        except Exception as exc:  # noqa: BLE001
-            print(f"[rank {rank}] {attn.sharding.mode} exchange failed ({exc!r})", file=sys.stderr)
-            failed = 1
-        flag = torch.tensor([failed], device=dev, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag) != 0:
-            if attn.sharding.mode == "reduce_scatter":
-                raise SystemExit("sharded step failed in reduce_scatter mode as well")
-            attn.sharding.mode = "reduce_scatter"
-            step()
-            torch.cuda.synchronize()
+        settle(attn, step)
     elapsed, attn_ms, n_rec = measure(step, args.steps, args.warmup, launches_per_step(attn))
     ms_per_step = elapsed / args.steps * 1e3
+    if multi:
+        attn.sharding.check()   # a one-sided wait that timed out inside the region voids the measurement
 
     if args.stages and rank == 0:
         ops.profile_enable(2, args.steps)
@@ -397,9 +411,10 @@ def worker(args) -> int:
             # BASELINE config 4: n_hashes = #GPUs, one table per GPU (at N = 1 a single table)
             _, attn4, step4 = build(1, args.precision)
             if multi:
-                step4()
-                torch.cuda.synchronize()
+                settle(attn4, step4)
             el, ams, nrec = measure(step4, sub_steps, sub_warm, launches_per_step(attn4))
+            if multi:
+                attn4.sharding.check()
             if rank == 0:
                 line["c4"] = {"workload": f"{WORKLOAD}, n_hashes={world} sharded 1 per GPU over {world} GPU(s)",
                               "ms_per_step": el / sub_steps * 1e3, "value": world * n_raw / (el / sub_steps),

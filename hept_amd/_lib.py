@@ -12,12 +12,13 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 # (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
 MAX_BLOCK = 256
 PREP_GRID = 1024
+TRANSPORT_RCCL, TRANSPORT_ONE_SIDED = 0, 1
 
 _ERRORS = {
     1: "HEPT_ERR_SHAPE: unsupported or inconsistent sizes",
@@ -71,8 +72,16 @@ SIGNATURES = {
     "hept_comm_world": (c_int, [_P]),
     "hept_comm_last_error": (ctypes.c_char_p, []),
     "hept_exchange_bytes": (c_size_t, [c_int] * 5),
-    "hept_forward_sharded": (c_int, [_P] * 10 + [c_int] * 11 + [_P, c_size_t, _P, c_size_t, _P, _P]),
-    "hept_forward_sharded_src": (c_int, [_P] * 8 + [c_int] + [_P] * 4 + [c_int] * 11 + [_P, c_size_t, _P, c_size_t, _P, _P]),
+    "hept_forward_sharded": (c_int, [_P] * 10 + [c_int] * 12 + [_P, c_size_t, _P, c_size_t, _P, _P]),
+    "hept_forward_sharded_src": (c_int, [_P] * 8 + [c_int] + [_P] * 4 + [c_int] * 12 + [_P, c_size_t, _P, c_size_t, _P, _P]),
+    "hept_comm_has_rccl": (c_int, [_P]),
+    "hept_comm_create_local": (c_int, [c_int, c_int, _P]),
+    "hept_p2p_bytes": (c_size_t, [c_int] * 5),
+    "hept_comm_p2p_alloc": (c_int, [_P, c_size_t, _P]),
+    "hept_comm_p2p_open": (c_int, [_P, _P]),
+    "hept_comm_p2p_ready": (c_int, [_P, c_size_t]),
+    "hept_comm_status": (c_int, [_P, _P]),
+    "hept_comm_p2p_flags": (c_int, [_P, _P, _P]),
     "hept_profile_enable": (c_int, [c_int, c_int]),
     "hept_profile_read": (c_int, [_P, _P]),
     "hept_profile_stride": (c_int, [c_int]),

@@ -128,7 +128,7 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 11; }
+extern "C" int hept_abi_version(void) { return 12; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -329,17 +329,21 @@ namespace {
 int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
                          const int64_t* codes, const GeoShift& geo, const float* w_rpe, const float* alpha,
                          const float* out_weight, const float* out_bias, int N, int H, int D, int C, int K, int T,
-                         int t0, int Tl, int B, int precision, int head_groups, void* workspace,
+                         int t0, int Tl, int B, int precision, int head_groups, int transport, void* workspace,
                          size_t workspace_bytes, void* xbuf, size_t xbuf_bytes, float* out_full, void* stream) {
-    if (!comm || !q || !k || !v || !coords || !w_rpe || !alpha || !out_weight || !workspace || !xbuf || !out_full)
+    if (!comm || !q || !k || !v || !coords || !w_rpe || !alpha || !out_weight || !workspace || !out_full)
         return HEPT_ERR_ARG;
+    const bool one_sided = transport == HEPT_TRANSPORT_ONE_SIDED;
+    if (!one_sided && (transport != HEPT_TRANSPORT_RCCL || !xbuf)) return HEPT_ERR_ARG;
     int rc = hept_check_shape(N, H, D, C, Tl, B);
     if (rc) return rc;
     if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
     if (head_groups < 1 || head_groups > HEPT_MAX_HEAD_GROUPS || H % head_groups != 0) return HEPT_ERR_SHAPE;
     const Workspace w = carve(workspace, N, H, C, Tl, precision);
-    if (workspace_bytes < w.bytes || xbuf_bytes < hept_exchange_bytes(N, H, D, comm->world, precision))
-        return HEPT_ERR_ARG;
+    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+    if (!one_sided && xbuf_bytes < hept_exchange_bytes(N, H, D, comm->world, precision)) return HEPT_ERR_ARG;
+    const P2pLayout lay = hept_p2p_layout(N, H, D, comm->world, precision);
+    if (one_sided && (!comm->p2p_open || comm->p2p_bytes < lay.bytes)) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int world = comm->world, hg = H / head_groups;
     const int per = (N + world - 1) / world, n_pad = per * world;
@@ -347,7 +351,8 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
     const size_t row = aprec == HEPT_PREC_BF16 ? 64 : 128;
     const size_t group_bytes = (size_t)n_pad * hg * row;       // one head group, all ranks' slices
     char* send = reinterpret_cast<char*>(xbuf);
-    char* recv = send + up256((size_t)n_pad * H * row);
+    char* recv = one_sided ? comm->p2p_local + lay.recv_off : send + up256((size_t)n_pad * H * row);
+    if (one_sided) ++comm->epoch;
     rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
     if (rc) return rc;
     // Caller's stream: the block attention of the head groups back to back.  Side stream: for every group but the
@@ -355,7 +360,7 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
     // group has nothing left to hide behind: its table sum and transfer run on the caller's stream (a cross-stream
     // hand-over costs ~15 us each way), which then joins the side stream and combines.
     const int pprec = hept_part_precision(precision, D);
-    const bool direct = Tl == 1;   // one local table: block_attn scatters straight into the send buffer
+    const bool direct = Tl == 1 && !one_sided;   // one local table: block_attn scatters straight into the send buffer
     const int32_t* qpos = w.pos;
     const int32_t* kpos = w.pos + (size_t)Tl * H * N;
     const bool rec = g_prof.mode == 1;
@@ -383,6 +388,12 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
         if (!last && (hipEventRecord(comm->fork[g], st) != hipSuccess ||
                       hipStreamWaitEvent(comm->side, comm->fork[g], 0) != hipSuccess))
             return HEPT_ERR_LAUNCH;
+        if (one_sided) {
+            // the table sum stores every row straight into the receive buffer of the rank that finishes its point
+            rc = hept_p2p_reduce_push(comm, w.part, pprec, Tl, N, H, D, g * hg, hg, g, aprec, lay, xs);
+            if (rc) return rc;
+            continue;
+        }
         if (!direct) {
             rc = hept_reduce_heads(w.part, pprec, Tl, N, H, D, g * hg, hg, n_pad, dst, aprec, xs);
             if (rc) return rc;
@@ -396,12 +407,30 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
     // this rank's points [rank * per, ...): the `world` received slices are the "tables" of the combine
     const int first = comm->rank * per;
     const int cnt = first >= N ? 0 : (N - first < per ? N - first : per);
-    float* mine = out_full + (size_t)first * D;
+    if (one_sided && D == 24 && cnt >= 1) {
+        // wait for the rows + combine + push of the output slice + output flag in one kernel, then gather
+        rc = hept_p2p_combine_push(comm, head_groups, per, cnt, H, hg, aprec, out_weight, out_bias, lay, st);
+        if (rc) return rc;
+        return hept_p2p_wait_copy_out(comm, n_pad, D, lay, out_full, st);
+    }
+    if (one_sided) {
+        rc = hept_p2p_wait_rows(comm, head_groups, st);
+        if (rc) return rc;
+    }
+    // one-sided: the slice is produced in this rank's own output region, pushed to the others, and the gathered
+    // output is copied out once every rank's slice has arrived
+    float* gathered = one_sided ? reinterpret_cast<float*>(comm->p2p_local + lay.out_off) : out_full;
+    float* mine = gathered + (size_t)first * D;
     rc = hept_combine_groups(reinterpret_cast<const float*>(recv), aprec, world, per, H, D, 0, cnt, hg,
                              group_bytes / 4, out_weight, out_bias, mine, stream);
     if (rc) return rc;
     if (cnt < per && hipMemsetAsync(mine + (size_t)cnt * D, 0, (size_t)(per - cnt) * D * 4, st) != hipSuccess)
         return HEPT_ERR_LAUNCH;
+    if (one_sided) {
+        rc = hept_p2p_push_out(comm, per, D, lay, st);
+        if (rc) return rc;
+        return hept_p2p_wait_copy_out(comm, n_pad, D, lay, out_full, st);
+    }
     return hept_comm_all_gather_f32(comm, out_full, (size_t)per * D, st);
 }
 }  // namespace
@@ -410,11 +439,11 @@ extern "C" int hept_forward_sharded(hept_comm* comm, const float* q, const float
                                     const float* coords, const int64_t* codes, const float* w_rpe,
                                     const float* alpha, const float* out_weight, const float* out_bias, int N, int H,
                                     int D, int C, int K, int T, int t0, int Tl, int B, int precision, int head_groups,
-                                    void* workspace, size_t workspace_bytes, void* xbuf, size_t xbuf_bytes,
-                                    float* out_full, void* stream) {
+                                    int transport, void* workspace, size_t workspace_bytes, void* xbuf,
+                                    size_t xbuf_bytes, float* out_full, void* stream) {
     if (!codes) return HEPT_ERR_ARG;
     return forward_sharded_impl(comm, q, k, v, coords, codes, GeoShift{}, w_rpe, alpha, out_weight, out_bias, N, H, D,
-                                C, K, T, t0, Tl, B, precision, head_groups, workspace, workspace_bytes, xbuf,
+                                C, K, T, t0, Tl, B, precision, head_groups, transport, workspace, workspace_bytes, xbuf,
                                 xbuf_bytes, out_full, stream);
 }
 
@@ -423,13 +452,13 @@ extern "C" int hept_forward_sharded_src(hept_comm* comm, const float* q, const f
                                         const float* cfac, int raw_size, const float* w_rpe, const float* alpha,
                                         const float* out_weight, const float* out_bias, int N, int H, int D, int C,
                                         int K, int T, int t0, int Tl, int B, int precision, int head_groups,
-                                        void* workspace, size_t workspace_bytes, void* xbuf, size_t xbuf_bytes,
-                                        float* out_full, void* stream) {
+                                        int transport, void* workspace, size_t workspace_bytes, void* xbuf,
+                                        size_t xbuf_bytes, float* out_full, void* stream) {
     if (!eta_idx || !phi_idx || !cfac) return HEPT_ERR_ARG;
     if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
     return forward_sharded_impl(comm, q, k, v, coords, nullptr, GeoShift{eta_idx, phi_idx, cfac, raw_size}, w_rpe,
                                 alpha, out_weight, out_bias, N, H, D, C, K, T, t0, Tl, B, precision, head_groups,
-                                workspace, workspace_bytes, xbuf, xbuf_bytes, out_full, stream);
+                                transport, workspace, workspace_bytes, xbuf, xbuf_bytes, out_full, stream);
 }
 
 extern "C" int hept_attn_block_forward(const float* x, const float* coords, const int64_t* codes,

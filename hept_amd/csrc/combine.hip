@@ -12,6 +12,7 @@
 // denominator column and feeds the 32 x (H*32) tile straight to v_mfma_f32_32x32x2_f32 against
 // the LDS-resident, zero-padded transpose of out_linear.weight (exact fp32 fma chain).
 #include "common.h"
+#include "p2p_dev.h"
 
 namespace {
 
@@ -86,13 +87,19 @@ constexpr int FFN_D = 24, FFN_PITCH = 25, FFN_WFLOATS = 2 * FFN_D * FFN_D + 4 * 
 // SPLIT (few tiles: a 6k cloud, or the N/G points a table-sharded rank finishes): the four waves of a workgroup
 // share ONE tile, each reduces every fourth head pair, and the partial 32 x D products meet in LDS -- a quarter of
 // the serial chain per wave when there are not enough tiles to fill the machine anyway.
-template <bool P16, bool FFN = false, int DT = 0, bool SPLIT = false>
+// PUSH (one-sided table sharding, D = 24, p2p.hip): `part` is this rank's receive region -- the kernel first waits for
+// the arrival flags of every (head group, source rank) -- and the finished rows go to this rank's slice of the
+// gathered output in EVERY rank's exchange buffer: the 32 x D tile passes through LDS so that each lane stores 16-B
+// pieces of contiguous rows (a 4-byte scatter per accumulator register would put 4-byte writes on the xGMI links);
+// the last workgroup raises this rank's output flag everywhere.
+template <bool P16, bool FFN = false, int DT = 0, bool SPLIT = false, bool PUSH = false>
 __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
                                                                   int H, int D_rt, int n0, int n_count,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out, int HG, size_t gstride,
-                                                                  FfnIn ffn = FfnIn{}) {
+                                                                  FfnIn ffn = FfnIn{}, P2pDev px = P2pDev{}) {
+    static_assert(!PUSH || (DT == 24 && !FFN), "the pushing epilogue is built for D = 24 rows");
     constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
     extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H (even-padded)][28 (d)][32 (c, zero padded)]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
@@ -112,6 +119,12 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     float* ffn_s = wt_s + HP * 28 * WT_PITCH;                     // [w1 | w2 | b1 | b2 | ln_w | ln_b]
     float* stage_s = ffn_s + FFN_WFLOATS + w * 32 * FFN_PITCH;  // this wave's 32 x D tile
     float* stage_s_end = ffn_s + (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0);
+    if constexpr (PUSH) {
+        if (tid < px.wait_groups * px.world) {
+            const int g = tid / px.world, src = tid - g * px.world;
+            wait_flag(flag_word(px.local, g * HEPT_MAX_RANKS_DEV + src), px.epoch, px.status, 1u, px.timeout);
+        }
+    }
     if constexpr (FFN) {
         for (int i = tid; i < FFN_D * FFN_D; i += CMB_THREADS) {
             ffn_s[i] = ffn.w1[i];
@@ -131,6 +144,8 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     const int n_tiles = (n_count + 31) / 32;
     const int hp0 = SPLIT ? 2 * w : 0, hstep = SPLIT ? 2 * CMB_WAVES : 2;
     float* red_s = stage_s_end;  // SPLIT: [CMB_WAVES - 1][16][64] partial accumulators of waves 1..
+    // PUSH: this wave's 32 x 24 tile as a contiguous image of the output rows (wave 0 only under SPLIT)
+    float* push_s = red_s + (SPLIT ? (CMB_WAVES - 1) * 16 * 64 : 0) + (SPLIT ? 0 : w * 32 * 24);
     for (int tile = SPLIT ? blockIdx.x : blockIdx.x * CMB_WAVES + w; tile < n_tiles;
          tile += SPLIT ? gridDim.x : gridDim.x * CMB_WAVES) {
         const int i = tile * 32 + li;
@@ -266,6 +281,21 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                     dst[c4] = o;
                 }
             }
+        } else if constexpr (PUSH) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (li < 24) push_s[hept_acc_row(r, hh) * 24 + li] = acc[r] + bia;
+            // (one wave's LDS accesses execute in order: the tile is complete when the reads below are issued)
+            const int rows = n_count - tile * 32 < 32 ? n_count - tile * 32 : 32;
+            const size_t tile_off = px.slice_off + (size_t)tile * 32 * 24 * 4;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int c = lane + 64 * kk;            // 16-B piece c of the tile's 192: floats [4c, 4c + 4), row c / 6
+                if (c < rows * 6) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(push_s + 4 * c);
+                    for (int s = 0; s < px.world; ++s) store16_system(px.peers[s] + tile_off + (size_t)c * 16, v);
+                }
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -275,6 +305,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         }
         if constexpr (SPLIT) __syncthreads();
     }
+    if constexpr (PUSH) signal_when_all_done(px.counter, px.peers, px.world, OUT_FLAG_WORD + px.me, px.epoch);
 }
 
 // 16 consecutive columns [16*hh, 16*hh+16) of one partial row, widened to fp32 (reduce_tables)
@@ -571,22 +602,24 @@ extern "C" int hept_reduce_heads(const float* part, int part_precision, int Tl, 
 // few tiles: one tile per workgroup, head pairs split over its waves (SPLIT); else one tile per wave
 constexpr int CMB_SPLIT_BELOW = 1024;  // tiles; 1024 tiles = one wave per SIMD on 256 CUs
 
-template <bool P16, bool FFN, int DT>
+template <bool P16, bool FFN, int DT, bool PUSH = false>
 int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int D, int n0, int n_count, const float* W,
-                   const float* b, float* out, const FfnIn& ffn, int HG = 0, size_t gstride = 0) {
+                   const float* b, float* out, const FfnIn& ffn, int HG = 0, size_t gstride = 0,
+                   const P2pDev& px = P2pDev{}) {
     if (HG <= 0) HG = H;
     const int n_tiles = (n_count + 31) / 32;
     const bool split = n_tiles < CMB_SPLIT_BELOW;
     const size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * WT_PITCH +
                                         (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0) +
-                                        (split ? (CMB_WAVES - 1) * 16 * 64 : 0));
+                                        (split ? (CMB_WAVES - 1) * 16 * 64 : 0) +
+                                        (PUSH ? (split ? 1 : CMB_WAVES) * 32 * 24 : 0));
     if (split) {
-        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true>), dim3(n_tiles), dim3(CMB_THREADS), lds, st, part, Tl, N,
-                           H, D, n0, n_count, W, b, out, HG, gstride, ffn);
+        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true, PUSH>), dim3(n_tiles), dim3(CMB_THREADS), lds, st, part,
+                           Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px);
     } else {
         const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
-        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, false>), dim3(wgs < 2048 ? wgs : 2048), dim3(CMB_THREADS), lds,
-                           st, part, Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn);
+        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, false, PUSH>), dim3(wgs < 2048 ? wgs : 2048), dim3(CMB_THREADS),
+                           lds, st, part, Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px);
     }
     return hept_launch_status();
 }
@@ -610,6 +643,21 @@ extern "C" int hept_combine_groups(const float* part, int part_precision, int Tl
     if (D == 24) return combine_launch<false, false, 24>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none, HG, gs);
     if (D == 16) return combine_launch<false, false, 16>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none, HG, gs);
     return combine_launch<false, false, 0>(st, part, Tl, N, H, D, n0, n_count, out_weight, out_bias, out, none, HG, gs);
+}
+
+// one-sided table sharding: wait for the received rows, combine this rank's points, store them into every rank's
+// gathered output and raise the output flag (internal: called by hept_forward_sharded; D == 24, n_count >= 1)
+int hept_combine_push(const float* part, int part_precision, int Tl, int N, int H, int n_count, int HG,
+                      size_t group_stride, const float* out_weight, const float* out_bias, const P2pDev& px,
+                      hipStream_t st) {
+    const FfnIn none{};
+    if (part_precision == HEPT_PREC_BF16)
+        return combine_launch<true, false, 24, true>(st, part, Tl, N, H, 24, 0, n_count, out_weight, out_bias, nullptr, none,
+                                                     HG, group_stride, px);
+    if (part_precision == HEPT_PREC_F32)
+        return combine_launch<false, false, 24, true>(st, part, Tl, N, H, 24, 0, n_count, out_weight, out_bias, nullptr, none,
+                                                      HG, group_stride, px);
+    return HEPT_ERR_SHAPE;
 }
 
 extern "C" int hept_combine_out(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,

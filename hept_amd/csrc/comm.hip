@@ -80,7 +80,7 @@ extern "C" int hept_comm_unique_id(void* id128) {
 }
 
 extern "C" int hept_comm_create(const void* id128, int rank, int world, hept_comm** out) {
-    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return HEPT_ERR_ARG;
+    if (!id128 || !out || world < 1 || world > HEPT_MAX_RANKS || rank < 0 || rank >= world) return HEPT_ERR_ARG;
     Rccl* r = rccl();
     if (!r) return HEPT_ERR_COMM;
     hept_comm* c = new hept_comm();
@@ -99,11 +99,29 @@ extern "C" int hept_comm_create(const void* id128, int rank, int world, hept_com
         return rc;
     }
     c->nccl = comm;
+    if (hept_comm_init_streams(c)) {
+        hept_comm_destroy(c);
+        return HEPT_ERR_LAUNCH;
+    }
+    *out = c;
+    return HEPT_OK;
+}
+
+int hept_comm_init_streams(hept_comm* c) {
     bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < HEPT_MAX_HEAD_GROUPS; ++i)
         ok = hipEventCreateWithFlags(&c->fork[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->join, hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
+    return ok ? HEPT_OK : HEPT_ERR_LAUNCH;
+}
+
+// a communicator without RCCL: rank bookkeeping, side stream and the one-sided transport only
+extern "C" int hept_comm_create_local(int rank, int world, hept_comm** out) {
+    if (!out || world < 1 || world > HEPT_MAX_RANKS || rank < 0 || rank >= world) return HEPT_ERR_ARG;
+    hept_comm* c = new hept_comm();
+    c->rank = rank;
+    c->world = world;
+    if (hipGetDevice(&c->device) != hipSuccess || hept_comm_init_streams(c)) {
         hept_comm_destroy(c);
         return HEPT_ERR_LAUNCH;
     }
@@ -114,6 +132,7 @@ extern "C" int hept_comm_create(const void* id128, int rank, int world, hept_com
 extern "C" int hept_comm_destroy(hept_comm* c) {
     if (!c) return HEPT_OK;
     if (c->side) (void)hipStreamSynchronize(c->side);
+    hept_p2p_release(c);
     for (int i = 0; i < HEPT_MAX_HEAD_GROUPS; ++i)
         if (c->fork[i]) (void)hipEventDestroy(c->fork[i]);
     if (c->join) (void)hipEventDestroy(c->join);
@@ -127,15 +146,17 @@ extern "C" int hept_comm_destroy(hept_comm* c) {
 extern "C" int hept_comm_rank(const hept_comm* c) { return c ? c->rank : -1; }
 extern "C" int hept_comm_world(const hept_comm* c) { return c ? c->world : -1; }
 
+extern "C" int hept_comm_has_rccl(const hept_comm* c) { return c && c->nccl ? 1 : 0; }
+
 int hept_comm_all_to_all(hept_comm* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t st) {
     Rccl* r = rccl();
-    if (!r || !c) return HEPT_ERR_COMM;
+    if (!r || !c || !c->nccl) return HEPT_ERR_COMM;
     return nccl_rc(r, r->AllToAll(send, recv, bytes_per_peer, ncclUint8, static_cast<ncclComm_t>(c->nccl), st), "ncclAllToAll");
 }
 
 int hept_comm_all_gather_f32(hept_comm* c, float* buf, size_t count, hipStream_t st) {
     Rccl* r = rccl();
-    if (!r || !c) return HEPT_ERR_COMM;
+    if (!r || !c || !c->nccl) return HEPT_ERR_COMM;
     return nccl_rc(r, r->AllGather(buf + (size_t)c->rank * count, buf, count, ncclFloat, static_cast<ncclComm_t>(c->nccl), st),
                    "ncclAllGather");
 }

@@ -1,0 +1,338 @@
+// One-sided exchange of the table-sharded operator (the coupling it serves is the one line
+// `out = o.sum(0) / logits.sum(0)`, example/hept.py:79).
+//
+// Every rank owns an exchange buffer in *uncached* device memory (peers write it while it is being polled, so it must
+// never sit stale in an L2), exported as a HIP IPC handle and mapped by every other rank of the node:
+//     [ flags 4 KiB | recv (groups, world, per, hg, row) | out (world * per, D) f32 ]
+// Rows: the kernel that sums a rank's local tables stores each point's row straight into the buffer of the rank that
+// finishes that point (xGMI stores, 16 B per lane, runs of 64-B rows); the last workgroup to finish raises
+// flag[group][source] = epoch in every destination.  Output: the rank's finished (per, D) slice is stored into every
+// rank's `out` region, then flag_out[source] = epoch.  A flag is raised only after every store of its kernel has been
+// fenced at system scope; the consumer polls its own (local) flags with system-scope acquire loads.  One step is in
+// flight at a time: a rank leaves a step only when every rank's output slice has arrived, i.e. after every rank has
+// finished reading the rows it received, so single buffers are enough.  Polling is bounded (20 s, once: the
+// error is sticky): on a timeout the kernel records it in the communicator's status word and every later wait returns
+// at once, so a lost peer cannot hang the GPU; the host reads the word with hept_comm_status.
+#include "comm.h"
+#include "p2p_dev.h"
+
+#include <stdlib.h>
+
+namespace {
+
+// Rows of heads [h0, h0 + hg) summed over the local tables; the row of point n goes to rank s = n / per, slot
+// recv[g][me][n - s * per][h - h0].  One lane per 16-B piece of an output row (4 pieces per packed 64-B row, 8 per
+// f32 row), consecutive lanes = consecutive pieces: a store instruction covers whole 64-B lines, which is what both
+// uncached local memory and the xGMI links want (half-filled lines doubled the time of this kernel).  Same arithmetic
+// and row formats as reduce_heads_kernel: packed rows are widened to f32, summed in table order and rounded back.
+template <bool P16>
+__global__ __launch_bounds__(256) void reduce_push_kernel(const float* __restrict__ part, int Tl, int N, int H, int h0,
+                                                          int hg, int per, int world, int me, char* const* peers,
+                                                          size_t recv_off, size_t group_off, unsigned int epoch,
+                                                          unsigned int* counter, int flag_idx) {
+    constexpr int PIECES = P16 ? 4 : 8;        // 16-B pieces per row
+    constexpr int ROWB = PIECES * 16;
+    const unsigned int total = (unsigned int)N * hg * PIECES;   // < 2^31 (N * H * 8 pieces)
+    const size_t tstride = (size_t)N * H * ROWB;  // bytes between tables
+    const char* pbytes = reinterpret_cast<const char*>(part);
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned int orow = i / PIECES;
+        const int pc = (int)(i - orow * PIECES);
+        const int n = (int)(orow / (unsigned int)hg);
+        const int hl = (int)(orow - (unsigned int)n * hg);
+        const char* src = pbytes + ((size_t)n * H + h0 + hl) * ROWB + pc * 16;
+        u32x4 v = *reinterpret_cast<const u32x4*>(src);
+        if (Tl > 1) {
+            u32x4 x[2];
+            const int tpre = Tl - 1 < 2 ? Tl - 1 : 2;   // the usual three tables: all loads in flight at once
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (t < tpre) x[t] = *reinterpret_cast<const u32x4*>(src + (size_t)(t + 1) * tstride);
+            if (P16 && pc < 3) {  // 8 bf16 numerators
+                float s[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[2 * j] = hept_bf16_lo(v[j]); s[2 * j + 1] = hept_bf16_hi(v[j]); }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (t < tpre) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s[2 * j] += hept_bf16_lo(x[t][j]); s[2 * j + 1] += hept_bf16_hi(x[t][j]); }
+                    }
+                for (int t = 3; t < Tl; ++t) {
+                    const u32x4 y = *reinterpret_cast<const u32x4*>(src + (size_t)t * tstride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s[2 * j] += hept_bf16_lo(y[j]); s[2 * j + 1] += hept_bf16_hi(y[j]); }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = hept_pack_bf16(s[2 * j], s[2 * j + 1]);
+            } else {              // f32 words (a packed row's last piece: [denominator, 0, 0, 0])
+                float s[4] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (t < tpre) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(x[t][j]);
+                    }
+                for (int t = 3; t < Tl; ++t) {
+                    const u32x4 y = *reinterpret_cast<const u32x4*>(src + (size_t)t * tstride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(y[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(s[j]);
+                if (P16) v[1] = v[2] = v[3] = 0u;
+            }
+        }
+        const int dest = n / per;
+        char* row = peers[dest] + recv_off + group_off + (((size_t)me * per + (n - dest * per)) * hg + hl) * ROWB;
+        store16_system(row + pc * 16, v);
+    }
+    signal_when_all_done(counter, peers, world, flag_idx, epoch);
+}
+
+__global__ __launch_bounds__(256) void wait_rows_kernel(char* local, int head_groups, int world, unsigned int epoch,
+                                                        unsigned int* status, unsigned long long timeout) {
+    const int i = threadIdx.x;
+    if (i < head_groups * world) {
+        const int g = i / world, s = i - g * world;
+        wait_flag(flag_word(local, g * HEPT_MAX_RANKS + s), epoch, status, 1u, timeout);
+    }
+}
+
+// this rank's slice of the output (already in its own `out` region) -> the same place in every other rank's buffer
+__global__ __launch_bounds__(256) void push_out_kernel(char* const* peers, int world, int me, size_t slice_off,
+                                                       size_t slice_bytes, unsigned int epoch, unsigned int* counter) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(peers[me] + slice_off);
+    const size_t n16 = slice_bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 v = src[i];
+        for (int s = 0; s < world; ++s)
+            if (s != me) store16_system(peers[s] + slice_off + i * 16, v);
+    }
+    signal_when_all_done(counter, peers, world, OUT_FLAG_WORD + me, epoch);
+}
+
+__global__ __launch_bounds__(256) void wait_copy_out_kernel(char* local, int world, unsigned int epoch, size_t out_off,
+                                                            size_t bytes, float* __restrict__ dst,
+                                                            unsigned int* status, unsigned long long timeout) {
+    if (threadIdx.x < world) wait_flag(flag_word(local, OUT_FLAG_WORD + threadIdx.x), epoch, status, 2u, timeout);
+    __syncthreads();
+    const u32x4* src = reinterpret_cast<const u32x4*>(local + out_off);
+    u32x4* out = reinterpret_cast<u32x4*>(dst);
+    const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * blockDim.x;
+    // uncached reads have a long latency: four pieces in flight per thread
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) out[i + u * stride] = v[u];
+    }
+}
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr int CMB_WAIT_MAX = 256;  // threads of the combine that poll one arrival flag each
+
+}  // namespace
+
+P2pLayout hept_p2p_layout(int N, int H, int D, int world, int precision) {
+    const size_t per = ((size_t)N + world - 1) / world, n_pad = per * world;
+    const size_t row = hept_part_precision(precision, D) == HEPT_PREC_BF16 ? 64 : 128;
+    P2pLayout l;
+    l.recv_off = HEPT_P2P_FLAG_BYTES;
+    l.out_off = l.recv_off + up256(n_pad * H * row);
+    l.bytes = l.out_off + up256(n_pad * D * 4);
+    return l;
+}
+
+extern "C" size_t hept_p2p_bytes(int N, int H, int D, int world, int precision) {
+    if (N < 1 || H < 1 || D < 1 || world < 1) return 0;
+    return hept_p2p_layout(N, H, D, world, precision).bytes;
+}
+
+void hept_p2p_release(hept_comm* c) {
+    if (!c) return;
+    for (int s = 0; s < HEPT_MAX_RANKS; ++s) {
+        if (c->p2p_peer[s] && s != c->rank) (void)hipIpcCloseMemHandle(c->p2p_peer[s]);
+        c->p2p_peer[s] = nullptr;
+    }
+    if (c->p2p_local) (void)hipFree(c->p2p_local);
+    if (c->d_peer) (void)hipFree(c->d_peer);
+    if (c->d_state) (void)hipFree(c->d_state);
+    c->p2p_local = nullptr;
+    c->d_peer = nullptr;
+    c->d_state = nullptr;
+    c->p2p_bytes = 0;
+    c->p2p_open = false;
+}
+
+// Allocate this rank's exchange buffer (uncached device memory) and export it.  Collective by convention: every rank
+// allocates the same size, the HEPT_IPC_HANDLE_BYTES handles reach every rank by any host-side means, every rank
+// calls hept_comm_p2p_open with all of them (rank order).
+extern "C" int hept_comm_p2p_alloc(hept_comm* c, size_t bytes, void* handle_out) {
+    if (!c || !handle_out || bytes < HEPT_P2P_FLAG_BYTES) return HEPT_ERR_ARG;
+    static_assert(sizeof(hipIpcMemHandle_t) == HEPT_IPC_HANDLE_BYTES, "IPC handle size");
+    if (hipDeviceSynchronize() != hipSuccess) return HEPT_ERR_LAUNCH;  // nothing in flight may still use the old buffers
+    hept_p2p_release(c);
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            hept_comm_set_error("hipExtMallocWithFlags", "neither uncached nor fine-grained device memory is available");
+            return HEPT_ERR_COMM;
+        }
+    }
+    c->p2p_local = static_cast<char*>(p);
+    c->p2p_bytes = bytes;
+    bool ok = hipMemset(p, 0, HEPT_P2P_FLAG_BYTES) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->d_peer), sizeof(char*) * HEPT_MAX_RANKS) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c->d_state), sizeof(unsigned int) * 32) == hipSuccess;
+    ok = ok && hipMemset(c->d_state, 0, sizeof(unsigned int) * 32) == hipSuccess;
+    hipIpcMemHandle_t h;
+    __builtin_memset(&h, 0, sizeof(h));
+    if (ok && c->world > 1 && hipIpcGetMemHandle(&h, p) != hipSuccess) {
+        (void)hipGetLastError();
+        hept_comm_set_error("hipIpcGetMemHandle", "cannot export the exchange buffer (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+        ok = false;
+    }
+    if (!ok) {
+        hept_p2p_release(c);
+        return HEPT_ERR_COMM;
+    }
+    __builtin_memcpy(handle_out, &h, sizeof(h));
+    c->epoch = 0;
+    // wall_clock64 ticks at the device's constant wall clock rate (kHz); HEPT_P2P_TIMEOUT_S seconds, default 20
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    double secs = 20.0;
+    if (const char* e = getenv("HEPT_P2P_TIMEOUT_S")) secs = atof(e) > 0 ? atof(e) : secs;
+    c->timeout_ticks = (unsigned long long)(secs * 1e3 * khz);
+    return HEPT_OK;
+}
+
+extern "C" int hept_comm_p2p_open(hept_comm* c, const void* handles) {
+    if (!c || !handles || !c->p2p_local) return HEPT_ERR_ARG;
+    const char* hs = static_cast<const char*>(handles);
+    for (int s = 0; s < c->world; ++s) {
+        if (s == c->rank) {
+            c->p2p_peer[s] = c->p2p_local;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        __builtin_memcpy(&h, hs + (size_t)s * sizeof(h), sizeof(h));
+        void* p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            (void)hipGetLastError();
+            hept_comm_set_error("hipIpcOpenMemHandle", "cannot map a peer's exchange buffer");
+            return HEPT_ERR_COMM;
+        }
+        c->p2p_peer[s] = static_cast<char*>(p);
+    }
+    if (hipMemcpy(c->d_peer, c->p2p_peer, sizeof(char*) * HEPT_MAX_RANKS, hipMemcpyHostToDevice) != hipSuccess)
+        return HEPT_ERR_LAUNCH;
+    // first launch out of this library in a fresh process loads its code object (seconds on a cold box): do it now,
+    // not inside the first exchange, where the other ranks would be polling for this one
+    hipLaunchKernelGGL(wait_rows_kernel, dim3(1), dim3(64), 0, nullptr, c->p2p_local, 0, c->world, 0u, c->d_state + 16, 0ull);
+    if (hipDeviceSynchronize() != hipSuccess) return HEPT_ERR_LAUNCH;
+    c->p2p_open = true;
+    return HEPT_OK;
+}
+
+extern "C" int hept_comm_p2p_ready(const hept_comm* c, size_t bytes) { return c && c->p2p_open && c->p2p_bytes >= bytes ? 1 : 0; }
+
+// debugging aid: this rank's flag words (HEPT_P2P_FLAG_BYTES bytes) and its epoch
+extern "C" int hept_comm_p2p_flags(hept_comm* c, void* out_flags, unsigned int* epoch) {
+    if (!c || !out_flags || !epoch || !c->p2p_local) return HEPT_ERR_ARG;
+    if (hipMemcpy(out_flags, c->p2p_local, HEPT_P2P_FLAG_BYTES, hipMemcpyDeviceToHost) != hipSuccess) return HEPT_ERR_LAUNCH;
+    *epoch = c->epoch;
+    return HEPT_OK;
+}
+
+// 0 = healthy; bit 0: a wait for rows timed out, bit 1: a wait for the output timed out (synchronises the device)
+extern "C" int hept_comm_status(hept_comm* c, int* status) {
+    if (!c || !status) return HEPT_ERR_ARG;
+    *status = 0;
+    if (!c->d_state) return HEPT_OK;
+    unsigned int v = 0;
+    if (hipMemcpy(&v, c->d_state + 16, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return HEPT_ERR_LAUNCH;
+    *status = (int)v;
+    return HEPT_OK;
+}
+
+int hept_p2p_reduce_push(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0,
+                         int hg, int g, int acc_precision, const P2pLayout& lay, hipStream_t st) {
+    if (!c || !c->p2p_open || !part) return HEPT_ERR_ARG;
+    if (acc_precision != HEPT_PREC_F32 && !(acc_precision == HEPT_PREC_BF16 && part_precision == HEPT_PREC_BF16))
+        return HEPT_ERR_SHAPE;
+    if (part_precision == HEPT_PREC_BF16 && D != 24) return HEPT_ERR_SHAPE;
+    const int per = (N + c->world - 1) / c->world;
+    const size_t row = acc_precision == HEPT_PREC_BF16 ? 64 : 128;
+    const size_t group_off = (size_t)g * per * c->world * hg * row;
+    if (acc_precision != part_precision) return HEPT_ERR_SHAPE;  // the exchange keeps the row format of block_attn
+    const size_t blocks = ((size_t)N * hg * (row / 16) + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 4096 ? blocks : 4096)), block(256);
+    unsigned int* counter = c->d_state + g;
+    const int flag_idx = g * HEPT_MAX_RANKS + c->rank;
+    if (part_precision == HEPT_PREC_BF16)
+        hipLaunchKernelGGL((reduce_push_kernel<true>), grid, block, 0, st, part, Tl, N, H, h0, hg, per, c->world, c->rank,
+                           c->d_peer, lay.recv_off, group_off, c->epoch, counter, flag_idx);
+    else
+        hipLaunchKernelGGL((reduce_push_kernel<false>), grid, block, 0, st, part, Tl, N, H, h0, hg, per, c->world, c->rank,
+                           c->d_peer, lay.recv_off, group_off, c->epoch, counter, flag_idx);
+    return hept_launch_status();
+}
+
+int hept_p2p_wait_rows(hept_comm* c, int head_groups, hipStream_t st) {
+    if (!c || !c->p2p_open || head_groups * c->world > 256) return HEPT_ERR_ARG;
+    hipLaunchKernelGGL(wait_rows_kernel, dim3(1), dim3(256), 0, st, c->p2p_local, head_groups, c->world, c->epoch,
+                       c->d_state + 16, c->timeout_ticks);
+    return hept_launch_status();
+}
+
+int hept_p2p_push_out(hept_comm* c, int per, int D, const P2pLayout& lay, hipStream_t st) {
+    if (!c || !c->p2p_open) return HEPT_ERR_ARG;
+    const size_t slice_bytes = (size_t)per * D * 4;
+    if (slice_bytes % 16 != 0) return HEPT_ERR_SHAPE;
+    const size_t blocks = (slice_bytes / 16 + 255) / 256;
+    hipLaunchKernelGGL(push_out_kernel, dim3((unsigned)(blocks < 512 ? (blocks ? blocks : 1) : 512)), dim3(256), 0, st,
+                       c->d_peer, c->world, c->rank, lay.out_off + (size_t)c->rank * slice_bytes, slice_bytes, c->epoch,
+                       c->d_state + 8);
+    return hept_launch_status();
+}
+
+int hept_combine_push(const float* part, int part_precision, int Tl, int N, int H, int n_count, int HG,
+                      size_t group_stride, const float* out_weight, const float* out_bias, const P2pDev& px,
+                      hipStream_t st);   // combine.hip
+
+int hept_p2p_combine_push(hept_comm* c, int head_groups, int per, int cnt, int H, int hg, int acc_precision,
+                          const float* out_weight, const float* out_bias, const P2pLayout& lay, hipStream_t st) {
+    if (!c || !c->p2p_open || cnt < 1 || head_groups * c->world > CMB_WAIT_MAX) return HEPT_ERR_ARG;
+    static_assert(HEPT_MAX_RANKS == HEPT_MAX_RANKS_DEV, "flag table pitch");
+    const size_t row = acc_precision == HEPT_PREC_BF16 ? 64 : 128;
+    P2pDev px;
+    px.peers = c->d_peer;
+    px.local = c->p2p_local;
+    px.world = c->world;
+    px.me = c->rank;
+    px.epoch = c->epoch;
+    px.counter = c->d_state + 8;
+    px.status = c->d_state + 16;
+    px.timeout = c->timeout_ticks;
+    px.wait_groups = head_groups;
+    px.slice_off = lay.out_off + (size_t)c->rank * per * 24 * 4;
+    return hept_combine_push(reinterpret_cast<const float*>(c->p2p_local + lay.recv_off), acc_precision, c->world, per, H,
+                             cnt, hg, (size_t)per * c->world * hg * row / 4, out_weight, out_bias, px, st);
+}
+
+int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int D, const P2pLayout& lay, float* dst, hipStream_t st) {
+    if (!c || !c->p2p_open || !dst) return HEPT_ERR_ARG;
+    const size_t bytes = (size_t)n_pad * D * 4;
+    if (bytes % 16 != 0) return HEPT_ERR_SHAPE;
+    const size_t blocks = (bytes / 16 + 255) / 256;
+    hipLaunchKernelGGL(wait_copy_out_kernel, dim3((unsigned)(blocks < 1024 ? (blocks ? blocks : 1) : 1024)), dim3(256), 0,
+                       st, c->p2p_local, c->world, c->epoch, lay.out_off, bytes, dst, c->d_state + 16, c->timeout_ticks);
+    return hept_launch_status();
+}

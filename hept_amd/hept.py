@@ -157,14 +157,18 @@ class HEPTAttention(nn.Module):
         geo = (kwargs["region_indices"], kwargs["regions_h"], kwargs["raw_size"]) if src else None
         if sh.mode == "all_to_all" and (sh.world > 1 or sh.always_exchange):
             comm = sh.native_comm(q2.device)
+            one_sided = bool(comm) and sh.one_sided(ops.p2p_bytes(n, h, d, sh.world, self.precision), q2.device)
+            comm = sh.native_comm(q2.device)   # (a communicator without RCCL is dropped when the mapping failed)
             if comm:
-                # one C call: kernels on this stream, RCCL transfers of finished head groups on the communicator's
-                # side stream, combine of this rank's points, all-gather
-                xbuf = sh.exchange_buffer(ops.exchange_bytes(n, h, d, sh.world, self.precision), q2.device)
+                # one C call: kernels on this stream, finished head groups travel behind the block attention
+                # (one-sided xGMI stores, or RCCL on the communicator's side stream), combine of this rank's points,
+                # gather of the output
+                xbuf = None if one_sided else sh.exchange_buffer(
+                    ops.exchange_bytes(n, h, d, sh.world, self.precision), q2.device)
                 return ops.forward_sharded(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
                                            self.e2lsh.alpha, self.out_linear.weight, self.out_linear.bias, comm=comm,
                                            world=sh.world, t0=t0, tl=tl, head_groups=sh.groups_for(h), workspace=ws,
-                                           xbuf=xbuf, geo=geo, **common)
+                                           xbuf=xbuf, one_sided=one_sided, geo=geo, **common)
             # the same pipeline driven from Python over torch.distributed (gloo in the tests; fallback)
             dims = ops.partial_begin(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
                                      self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, geo=geo, **common)

@@ -81,6 +81,10 @@ def exchange_bytes(n, h, d, world, precision) -> int:
     return int(_lib.load().hept_exchange_bytes(n, h, d, world, precision_code(precision)))
 
 
+def p2p_bytes(n, h, d, world, precision) -> int:
+    return int(_lib.load().hept_p2p_bytes(n, h, d, world, precision_code(precision)))
+
+
 @_on_device
 def rpe_scale(w_rpe_weight: torch.Tensor, n_heads: int, head_dim: int, w_per_dist: int) -> torch.Tensor:
     lib = _lib.load()
@@ -621,10 +625,13 @@ def combine_groups(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: 
 @_on_device
 def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *, comm: int, world: int,
                     block_size: int, w_per_dist: int, t0: int, tl: int, head_groups: int, precision="fp32",
-                    workspace: torch.Tensor, xbuf: torch.Tensor, geo=None) -> torch.Tensor:
+                    workspace: torch.Tensor, xbuf: Optional[torch.Tensor] = None, one_sided: bool = False,
+                    geo=None) -> torch.Tensor:
     """Table-sharded operator in one C call (``hept_forward_sharded``): this rank's tables [t0, t0+tl), the RCCL
     exchange pipelined by head groups on the communicator's side stream, combine of this rank's points and the
-    all-gather; returns the full (N, D) output.  ``comm`` is a ``hept_comm*`` (see ``hept_amd.sharding``)."""
+    all-gather; returns the full (N, D) output.  ``comm`` is a ``hept_comm*`` (see ``hept_amd.sharding``);
+    ``one_sided`` selects the transport that stores rows straight into the peers' mapped exchange buffers
+    (``hept_comm_p2p_*``; ``xbuf`` is then not needed)."""
     lib = _lib.load()
     q, k, v, coords, codes, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, codes, w_rpe_weight, alpha,
                                                                 block_size, w_per_dist)
@@ -632,14 +639,16 @@ def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out
     _lib.check(lib.hept_check_shape(n, h, d, c, tl, block_size), "hept_check_shape")
     if workspace.numel() < int(lib.hept_workspace_bytes(n, h, d, c, tl, block_size, prec)):
         raise ValueError("workspace too small: size it with ops.workspace_bytes")
-    if xbuf.numel() < int(lib.hept_exchange_bytes(n, h, d, world, prec)):
+    if not one_sided and (xbuf is None or xbuf.numel() < int(lib.hept_exchange_bytes(n, h, d, world, prec))):
         raise ValueError("exchange buffer too small: size it with hept_exchange_bytes")
     ow = _f32c(out_weight, "out_linear.weight")
     ob = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
     per = (n + world - 1) // world
     out_full = torch.empty(per * world, d, device=q.device, dtype=torch.float32)
-    tail = (n, h, d, c, w_per_dist, t, t0, tl, block_size, prec, head_groups, workspace.data_ptr(), workspace.numel(),
-            xbuf.data_ptr(), xbuf.numel(), out_full.data_ptr(), _stream(q))
+    tail = (n, h, d, c, w_per_dist, t, t0, tl, block_size, prec, head_groups,
+            _lib.TRANSPORT_ONE_SIDED if one_sided else _lib.TRANSPORT_RCCL, workspace.data_ptr(), workspace.numel(),
+            xbuf.data_ptr() if xbuf is not None else None, xbuf.numel() if xbuf is not None else 0,
+            out_full.data_ptr(), _stream(q))
     if geo is None:
         rc = lib.hept_forward_sharded(comm, q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(),
                                       codes.data_ptr(), w.data_ptr(), alpha.data_ptr(), ow.data_ptr(),

@@ -64,6 +64,10 @@ class TableSharding:
         # the kernels and the collectives); None = not tried yet, 0 = unavailable (torch.distributed path)
         self._native = None
         self._xbuf = None
+        self._p2p_failed = False
+        # transport of the all-to-all exchange: "p2p" (one-sided xGMI stores; falls back to "rccl" when the peers'
+        # buffers cannot be mapped), "rccl" (RCCL called from the C library), "torch" (torch.distributed collectives)
+        self.exchange = os.environ.get("HEPT_EXCHANGE", "p2p")
         self.always_exchange = always_exchange  # run the collectives even on a 1-rank group (tests)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -78,48 +82,176 @@ class TableSharding:
 
     def describe(self) -> str:
         if self.mode == "all_to_all":
-            via = "RCCL from the C library" if self._native else "torch.distributed"
+            via = "torch.distributed"
+            if self._native:
+                via = "RCCL from the C library" if (self._p2p_failed or self.exchange == "rccl") else "one-sided xGMI stores"
             return f"all_to_all pipelined in {self.head_groups} head group(s) + all_gather ({via})"
         return self.mode
 
+    def _agree(self, ok: bool, device: torch.device) -> bool:
+        """True iff ``ok`` on every rank (a collective)."""
+        on = device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([1 if ok else 0], device=on, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t) == 1
+
     def native_comm(self, device: torch.device) -> int:
-        """``hept_comm*`` for the one-call exchange, or 0 when it is not available (backend other than RCCL,
-        ``HEPT_EXCHANGE=torch``, or communicator creation failed on some rank)."""
+        """``hept_comm*`` for the one-call exchange, or 0 when it is not available (``HEPT_EXCHANGE=torch``, CPU
+        tensors, or communicator creation failed on some rank).  On an RCCL process group the communicator carries
+        its own RCCL communicator; on any other backend (gloo: several ranks sharing one GPU in the tests) it has the
+        one-sided transport only."""
         if self._native is not None:
             return self._native
         self._native = 0
-        if (dist.get_backend(self.group) != "nccl" or self.mode != "all_to_all"
-                or os.environ.get("HEPT_EXCHANGE", "native") == "torch" or device.type != "cuda"):
+        if self.mode != "all_to_all" or self.exchange == "torch" or device.type != "cuda" or self.world > 16:
             return 0
         import ctypes
 
         from . import _lib
 
         lib = _lib.load()
-        ident = (ctypes.c_char * 128)()
-        box = [None]
-        if self.rank == 0 and lib.hept_comm_unique_id(ident) == 0:
-            box[0] = bytes(ident.raw)
-        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
-        dist.broadcast_object_list(box, src=src, group=self.group, device=device)
         handle = ctypes.c_void_p()
-        rc = 1
-        if box[0] is not None and any(box[0]):
-            with torch.cuda.device(device):
-                rc = lib.hept_comm_create(box[0], self.rank, self.world, ctypes.byref(handle))
-        ok = torch.tensor([1 if rc == 0 else 0], device=device, dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-        if int(ok) == 1:
+        with torch.cuda.device(device):
+            if dist.get_backend(self.group) == "nccl":
+                ident = (ctypes.c_char * 128)()
+                box = [None]
+                if self.rank == 0 and lib.hept_comm_unique_id(ident) == 0:
+                    box[0] = bytes(ident.raw)
+                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=self.group, device=device)
+                rc = 1
+                if box[0] is not None:
+                    rc = lib.hept_comm_create(box[0], self.rank, self.world, ctypes.byref(handle))
+            else:
+                rc = lib.hept_comm_create_local(self.rank, self.world, ctypes.byref(handle))
+        if self._agree(rc == 0, device):
             self._native = handle.value
         else:
             if rc == 0:
                 lib.hept_comm_destroy(handle)
             import warnings
 
-            warnings.warn("hept_amd: native RCCL communicator unavailable ("
+            warnings.warn("hept_amd: native communicator unavailable ("
                           + (lib.hept_comm_last_error() or b"").decode(errors="replace")
                           + "); table sharding falls back to torch.distributed collectives")
         return self._native
+
+    def one_sided(self, nbytes: int, device: torch.device) -> bool:
+        """Whether the one-sided transport is set up for exchange buffers of ``nbytes`` (sets it up on first use:
+        allocate, swap the IPC handles through the process group, map the peers -- a collective)."""
+        comm = self._native
+        if not comm or self.exchange == "rccl" or self._p2p_failed:
+            return False
+        from . import _lib
+
+        lib = _lib.load()
+        if lib.hept_comm_p2p_ready(comm, nbytes):
+            return True
+        import ctypes
+
+        handle = ctypes.create_string_buffer(64)
+        with torch.cuda.device(device):
+            rc = lib.hept_comm_p2p_alloc(comm, nbytes, handle)
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, (rc, handle.raw), group=self.group)
+            ok = all(r == 0 for r, _ in gathered)
+            if ok:
+                ok = lib.hept_comm_p2p_open(comm, b"".join(hb for _, hb in gathered)) == 0
+        if self._agree(ok, device):
+            # every rank's buffer (and its zeroed flags) exists before anybody stores into it
+            dist.barrier(group=self.group)
+            return True
+        self._p2p_failed = True
+        import warnings
+
+        warnings.warn("hept_amd: one-sided exchange unavailable ("
+                      + (lib.hept_comm_last_error() or b"").decode(errors="replace") + "); using "
+                      + ("RCCL collectives" if lib.hept_comm_has_rccl(comm) else "torch.distributed collectives"))
+        if not lib.hept_comm_has_rccl(comm):
+            lib.hept_comm_destroy(comm)
+            self._native = 0
+        return False
+
+    def downgrade(self) -> bool:
+        """Step down one rung of the transport ladder (one-sided stores -> RCCL from the C library -> torch.distributed
+        all-to-all -> reduce-scatter); False when there is nothing left.  Every rank must take the same step."""
+        from . import _lib
+
+        lib = _lib.load()
+        if self._native and self.exchange != "rccl" and not self._p2p_failed and lib.hept_comm_has_rccl(self._native):
+            self.exchange = "rccl"
+            return True
+        if self._native or self._native is None:
+            if self._native:
+                lib.hept_comm_destroy(self._native)
+            self._native, self.exchange = 0, "torch"
+            return True
+        if self.mode == "all_to_all" and dist.get_backend(self.group) == "nccl":
+            self.mode = "reduce_scatter"
+            return True
+        return False
+
+    def tune(self, step: Callable[[], object], device: torch.device, head_groups=(1, 2, 4), steps: int = 10):
+        """Pick the fastest (transport, head groups) for this machine: time ``step`` (one sharded forward) under every
+        candidate the communicator supports and keep the best.  Collective: all ranks time the same candidates, the
+        slowest rank's time counts, a candidate that fails or times out on any rank is dropped.  Returns the table
+        {(transport, groups): seconds per step}."""
+        import time
+
+        from . import _lib
+
+        lib = _lib.load()
+        if not self._native:
+            return {}
+        transports = []
+        if self.exchange == "p2p" and not self._p2p_failed:
+            transports.append("p2p")
+        if lib.hept_comm_has_rccl(self._native):
+            transports.append("rccl")
+        on = device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        table = {}
+        for tr in transports:
+            for g in head_groups:
+                self.exchange, self.head_groups = tr, g
+                bad = 0
+                try:
+                    for _ in range(3):
+                        step()
+                    torch.cuda.synchronize(device)
+                    dist.barrier(group=self.group)
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        step()
+                    torch.cuda.synchronize(device)
+                    dt = (time.perf_counter() - t0) / steps
+                    self.check()
+                except Exception:  # noqa: BLE001
+                    bad, dt = 1, 0.0
+                t = torch.tensor([dt, float(bad)], device=on, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                if t[1].item() == 0:
+                    table[(tr, g)] = t[0].item()
+        if table:
+            self.exchange, self.head_groups = min(table, key=table.get)
+        return table
+
+    def check(self) -> None:
+        """Raise if a one-sided wait has timed out (synchronises the device; call it outside timed regions)."""
+        if self._native:
+            import ctypes
+
+            from . import _lib
+
+            st = ctypes.c_int(0)
+            _lib.check(_lib.load().hept_comm_status(self._native, ctypes.byref(st)), "hept_comm_status")
+            if st.value:
+                flags = (ctypes.c_uint32 * 1024)()
+                epoch = ctypes.c_uint32(0)
+                _lib.load().hept_comm_p2p_flags(self._native, flags, ctypes.byref(epoch))
+                rows = [list(flags[g * 16:g * 16 + self.world]) for g in range(self.groups_for(8))]
+                raise RuntimeError(f"hept_amd: one-sided exchange timed out waiting for a peer (status {st.value}; "
+                                   f"rank {self.rank} epoch {epoch.value}, row flags {rows}, output flags "
+                                   f"{list(flags[512:512 + self.world])})")
 
     def exchange_buffer(self, nbytes: int, device: torch.device) -> torch.Tensor:
         if self._xbuf is None or self._xbuf.numel() < nbytes or self._xbuf.device != device:

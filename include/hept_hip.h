@@ -214,20 +214,46 @@ int hept_comm_create(const void* id128, int rank, int world, hept_comm** out);
 int hept_comm_destroy(hept_comm* comm);
 int hept_comm_rank(const hept_comm* comm);
 int hept_comm_world(const hept_comm* comm);
+int hept_comm_has_rccl(const hept_comm* comm);
 const char* hept_comm_last_error(void);
 size_t hept_exchange_bytes(int N, int H, int D, int world, int precision);
+
+/* Second transport of the same exchange: one-sided stores over xGMI, no collective launch on the critical path.
+ * Every rank allocates an exchange buffer of hept_p2p_bytes(...) bytes of uncached device memory
+ * (hept_comm_p2p_alloc), the HEPT_IPC_HANDLE_BYTES-byte HIP IPC handles reach every rank by any host-side means,
+ * and every rank maps the others' buffers (hept_comm_p2p_open, handles in rank order).  With transport
+ * HEPT_TRANSPORT_ONE_SIDED hept_forward_sharded then stores each table-summed row straight into the buffer of the
+ * rank that finishes its point, raises an epoch flag there when a head group is complete, polls its own flags before
+ * the combine, stores its finished output slice into every rank's buffer and copies the gathered output to out_full
+ * once every slice has arrived (xbuf is not used).  Calls are collective: every rank makes the same sequence.
+ * A wait is bounded (20 s, sticky): hept_comm_status reports bit 0 (rows) / bit 1 (output) after a timeout, and the
+ * results of that call are undefined -- fall back to HEPT_TRANSPORT_RCCL.  hept_comm_create_local makes a
+ * communicator without RCCL (one-sided transport only; at most 16 ranks). */
+#define HEPT_TRANSPORT_RCCL 0
+#define HEPT_TRANSPORT_ONE_SIDED 1
+#define HEPT_IPC_HANDLE_BYTES 64
+int hept_comm_create_local(int rank, int world, hept_comm** out);
+size_t hept_p2p_bytes(int N, int H, int D, int world, int precision);
+int hept_comm_p2p_alloc(hept_comm* comm, size_t bytes, void* handle_out);
+int hept_comm_p2p_open(hept_comm* comm, const void* handles);
+int hept_comm_p2p_ready(const hept_comm* comm, size_t bytes);
+int hept_comm_status(hept_comm* comm, int* status);
+/* debugging aid: this rank's HEPT_P2P_FLAG_BYTES bytes of arrival flags ([head group][source rank] u32 at byte 0,
+ * output flags [source rank] u32 at byte 2048; each holds the epoch of the last arrival) and its own epoch */
+#define HEPT_P2P_FLAG_BYTES 4096
+int hept_comm_p2p_flags(hept_comm* comm, void* out_flags, unsigned int* epoch);
 int hept_forward_sharded(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
                          const int64_t* codes, const float* w_rpe, const float* alpha,
                          const float* out_weight, const float* out_bias,
                          int N, int H, int D, int C, int K, int T, int t0, int Tl, int B, int precision,
-                         int head_groups, void* workspace, size_t workspace_bytes, void* xbuf, size_t xbuf_bytes,
-                         float* out_full, void* stream);
+                         int head_groups, int transport, void* workspace, size_t workspace_bytes, void* xbuf,
+                         size_t xbuf_bytes, float* out_full, void* stream);
 int hept_forward_sharded_src(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
                              const float* eta_idx, const float* phi_idx, const float* cfac, int raw_size,
                              const float* w_rpe, const float* alpha, const float* out_weight, const float* out_bias,
                              int N, int H, int D, int C, int K, int T, int t0, int Tl, int B, int precision,
-                             int head_groups, void* workspace, size_t workspace_bytes, void* xbuf, size_t xbuf_bytes,
-                             float* out_full, void* stream);
+                             int head_groups, int transport, void* workspace, size_t workspace_bytes, void* xbuf,
+                             size_t xbuf_bytes, float* out_full, void* stream);
 
 /* SURVEY.md §8 f-3 — the reference's src variant of the same operator (src/models/attention/hept.py:74-117, caller
  * src/models/baselines/transformer.py:43-57): no AND codes; the sort key is hash + get_geo_shift (see

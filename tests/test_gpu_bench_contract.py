@@ -55,7 +55,11 @@ def test_bench_line_with_the_exchange_forced_on(gpu_device):
 def test_bench_launches_its_own_ranks(ranks, gpu_device):
     """`python bench.py --gpus N` with WORLD_SIZE unset: the parent starts N ranks (here they share the one GPU through
     a gloo group: RCCL refuses two ranks per device), relays rank 0's line and exits 0."""
-    d = _run("--gpus", str(ranks), "--no-cpu-baseline", HEPT_BENCH_BACKEND="gloo", HEPT_BENCH_EXCHANGE="all_to_all")
+    # (HEPT_EXCHANGE=torch: the collectives go through gloo.  The one-sided transport polls arrival flags on the GPU,
+    # and N processes polling on ONE shared GPU crawl from time slice to time slice; it is covered on small inputs by
+    # tests/test_gpu_two_process.py.)
+    d = _run("--gpus", str(ranks), "--no-cpu-baseline", HEPT_BENCH_BACKEND="gloo", HEPT_BENCH_EXCHANGE="all_to_all",
+             HEPT_EXCHANGE="torch")
     assert KEYS <= set(d) and d["n_gpus"] == ranks and d["scaling"] == "weak"
     assert f"({3 * ranks} total)" in d["config"]["workload"] and "all_to_all" in d["config"]["parallelism"]
     assert abs(d["value"] - ranks * 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

@@ -30,12 +30,14 @@ def nccl_group(gpu_device):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["all_to_all", "all_to_all/1", "all_to_all/4", "all_to_all/8", "all_to_all/2/torch",
-                                  "all_to_all/4/torch", "reduce_scatter", "all_reduce"])
+@pytest.mark.parametrize("mode", ["all_to_all", "all_to_all/1", "all_to_all/4", "all_to_all/8", "all_to_all/2/rccl",
+                                  "all_to_all/1/rccl", "all_to_all/4/rccl", "all_to_all/2/torch", "all_to_all/4/torch",
+                                  "reduce_scatter", "all_reduce"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_sharded_module_equals_plain_module(mode, precision, nccl_group, gpu_device):
-    # all_to_all/G: the pipelined exchange with G head groups (default 2), driven by the C library's own RCCL
-    # communicator (hept_forward_sharded); .../torch: the same pipeline over torch.distributed collectives
+    # all_to_all/G: the pipelined exchange with G head groups (default 2) in one C call (hept_forward_sharded), rows
+    # stored one-sidedly into the (here: own) exchange buffer; .../rccl: the same call with RCCL collectives on the
+    # communicator's side stream; .../torch: the same pipeline driven from Python over torch.distributed
     mode, _, rest = mode.partition("/")
     groups, _, via = rest.partition("/")
     inp, _ = cases.load_case("g6_block100")
@@ -47,8 +49,8 @@ def test_sharded_module_equals_plain_module(mode, precision, nccl_group, gpu_dev
     shard = HEPTAttention(e, process_group=nccl_group, **kw)
     shard.sharding = TableSharding(t, nccl_group, mode=mode, always_exchange=True,
                                    head_groups=int(groups) if groups else None)
-    if via == "torch":
-        shard.sharding._native = 0
+    if via:
+        shard.sharding.exchange = via
     for m in (plain, shard):
         m.load_state_dict(sd, strict=True)
         m.to(gpu_device).eval()
@@ -62,6 +64,9 @@ def test_sharded_module_equals_plain_module(mode, precision, nccl_group, gpu_dev
         assert torch.equal(b, shard(*args, **kwargs))   # buffers reused across calls
     if mode == "all_to_all":
         assert bool(shard.sharding._native) == (via != "torch")
+        shard.sharding.check()
+        want = {"": "one-sided", "rccl": "RCCL from the C library", "torch": "torch.distributed"}[via]
+        assert want in shard.sharding.describe()
     # same kernels; the sharded path sums the tables before the divide (reduce_tables) instead of inside
     # combine_out, and for 16-bit tiles widens the packed partial rows first: fp32 round-off only
     if mode == "all_to_all" and precision == "bf16":

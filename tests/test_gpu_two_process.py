@@ -110,6 +110,63 @@ def test_sharded_training_matches_single_process(gpu_device):
             assert err < 2e-5, (r, key, err)
 
 
+def _synthetic_worker(rank, world, port, precision, exchange, ret):
+    """BASELINE config 4 in miniature: n_hashes = world, one table per rank, the production exchange."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HEPT_EXCHANGE"] = exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hept_amd import HEPTAttention
+        from hept_amd.sharding import TableSharding
+        from hept_amd.synthetic import make_inputs
+
+        dev = torch.device("cuda", 0)
+        inp = make_inputs([1500, 700], block_size=128, n_hashes=world, seed=5, cluster_size=8)
+        g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+        m = HEPTAttention(30, h_dim=24, num_heads=8, block_size=128, n_hashes=world, num_w_per_dist=10,
+                          precision=precision, process_group=dist.group.WORLD)
+        m.sharding = TableSharding(world, dist.group.WORLD, mode="all_to_all", head_groups=2)
+        m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
+                           "e2lsh.alpha": inp["alpha"]})
+        m = m.to(dev).eval()
+        w_rpe = torch.nn.Linear(50, 192).to(dev)
+        with torch.no_grad():
+            w_rpe.weight.copy_(g["w_rpe_weight"])
+            for _ in range(3):  # epochs advance, buffers are reused
+                out = m(g["q"], g["k"], g["v"], w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+        torch.cuda.synchronize()
+        m.sharding.check()
+        ret[rank] = (out.cpu(), m.sharding.describe())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_eight_ranks_one_table_each_match_the_unsharded_operator(precision, gpu_device):
+    """8 processes (sharing this GPU), n_hashes = 8, one table per rank, rows exchanged with the one-sided transport
+    (buffers mapped across processes through HIP IPC) -- against the plain operator on all 8 tables."""
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_synthetic_worker, args=(world, port, precision, "p2p", ret), nprocs=world, join=True)
+    assert all(torch.equal(ret[0][0], ret[r][0]) for r in range(1, world))
+    assert "one-sided" in ret[0][1]
+    from hept_amd import ops
+    from hept_amd.synthetic import make_inputs
+
+    inp = make_inputs([1500, 700], block_size=128, n_hashes=world, seed=5, cluster_size=8)
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    plain = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
+                        g["out_weight"], g["out_bias"], block_size=128, w_per_dist=10, precision=precision).cpu()
+    # one table per rank: block_attn's own rows travel (f32 rows, or packed rows without a second rounding); only the
+    # association of the table sum differs from the unsharded combine
+    torch.testing.assert_close(ret[0][0], plain, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("world,mode,precision", [(2, "all_reduce", "fp32"), (2, "all_reduce", "bf16"),
                                                   (2, "all_to_all", "fp32"), (2, "all_to_all", "bf16"),
                                                   (3, "all_to_all", "bf16"), (3, "all_to_all", "mixed16")])

@@ -1,5 +1,5 @@
 """A few forwards of one configuration, for `rocprofv3 --kernel-trace` timelines (tools/trace_summary.py reads the CSV).
-python tools/trace_step.py [plain|native|torch] [groups] [steps]"""
+python tools/trace_step.py [plain|p2p|rccl|torch] [groups] [steps]"""
 import os
 import sys
 
@@ -31,8 +31,8 @@ m = HEPTAttention(30, h_dim=24, num_heads=8, block_size=128, n_hashes=3, num_w_p
                   process_group=group)
 if group is not None:
     m.sharding = TableSharding(3, group, mode="all_to_all", always_exchange=True, head_groups=groups)
-    if how == "torch":
-        m.sharding._native = 0
+    if how in ("torch", "rccl"):
+        m.sharding.exchange = how
 m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"], "e2lsh.alpha": inp["alpha"]})
 m = m.to(dev).eval()
 with torch.no_grad():
