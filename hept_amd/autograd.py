@@ -116,8 +116,14 @@ class HeptPartialSums(torch.autograd.Function):
         # scaled coordinates s[n,h,c] = sqrt_w[h,c] * coords[n,c]: d sqrt_w = sum_n dcs * coords comes out of the
         # reduction kernel (as a torch einsum it was a 48 x N GEMM that rocBLAS ran in 320 us, as a product + column
         # sum two kernels of 27 us); rows at and after raw_size (src variant padding) get zero gradients there too
-        dq, dk, dv, dcs, dsw = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size,
-                                                  f32_mfma=ctx.f32_mfma, coords=coords, raw_size=ctx.raw_size)
+        h = qhat.shape[0]
+        if h * c <= 64:
+            dq, dk, dv, dcs, dsw = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size,
+                                                      f32_mfma=ctx.f32_mfma, coords=coords, raw_size=ctx.raw_size)
+        else:  # more (head, coordinate) columns than the reduction kernel's 64 lanes: the column sum in torch
+            dq, dk, dv, dcs = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size,
+                                                 f32_mfma=ctx.f32_mfma, raw_size=ctx.raw_size)
+            dsw = (dcs * coords[:, None, :]).sum(dim=0)
         if not ctx.needs_input_grad[4]:
             dsw = None
         dcoords = (dcs * sqrt_w[None]).sum(dim=1) if ctx.needs_input_grad[3] else None

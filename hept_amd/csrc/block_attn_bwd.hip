@@ -518,10 +518,12 @@ __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict
 }
 
 // d_sqrt_w[h][c] = sum_n dcs[n][h][c] * coords[n][c]: lane = (h, c) column of the H*C <= 64 wide rows, a wave walks
-// every fourth point of the workgroup's 256 (8 rows in flight), the four waves meet in LDS, one atomic per column
+// every fourth point of the workgroup's 256 (8 rows in flight), the four waves meet in LDS, and the workgroup's 64
+// sums go to partial[wg][64]; dsw_sum_kernel adds the workgroups in index order (a float atomicAdd per column made
+// the training gradients depend on the order in which workgroups retire)
 constexpr int DSW_POINTS = 256;
 __global__ __launch_bounds__(256) void dsw_kernel(const float* __restrict__ dcs, const float* __restrict__ coords, int N,
-                                                  int H, int C, float* __restrict__ d_sqrt_w) {
+                                                  int H, int C, float* __restrict__ partial) {
     __shared__ float red_s[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, HC = H * C;
     const int n_begin = blockIdx.x * DSW_POINTS, n_end = min(N, n_begin + DSW_POINTS);
@@ -543,7 +545,19 @@ __global__ __launch_bounds__(256) void dsw_kernel(const float* __restrict__ dcs,
     }
     red_s[w][lane] = acc;
     __syncthreads();
-    if (w == 0 && lane < HC) atomicAdd(d_sqrt_w + lane, red_s[0][lane] + red_s[1][lane] + red_s[2][lane] + red_s[3][lane]);
+    if (w == 0) partial[(size_t)blockIdx.x * 64 + lane] = lane < HC ? red_s[0][lane] + red_s[1][lane] + red_s[2][lane] + red_s[3][lane] : 0.f;
+}
+
+__global__ __launch_bounds__(64) void dsw_sum_kernel(const float* __restrict__ partial, int n_wgs, int HC,
+                                                     float* __restrict__ d_sqrt_w) {
+    const int lane = threadIdx.x;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};   // four interleaved chains (fixed association), folded at the end
+    for (int g = 0; g < n_wgs; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (g + u < n_wgs) a[u] += partial[(size_t)(g + u) * 64 + lane];
+    }
+    if (lane < HC) d_sqrt_w[lane] = (a[0] + a[1]) + (a[2] + a[3]);
 }
 
 template <bool FULL>
@@ -651,9 +665,12 @@ extern "C" int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int 
     hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dq_part, dkv_part, Tl,
                        N, H, D, C, raw_size, dq, dk, dv, dcs);
     if (d_sqrt_w) {
-        if (hipMemsetAsync(d_sqrt_w, 0, sizeof(float) * H * C, st) != hipSuccess) return HEPT_ERR_LAUNCH;
-        hipLaunchKernelGGL(dsw_kernel, dim3((unsigned)((N + DSW_POINTS - 1) / DSW_POINTS)), dim3(256), 0, st, dcs, coords,
-                           N, H, C, d_sqrt_w);
+        // per-workgroup partial sums live in dq_part: the reduction above was its last reader ((N+255)/256 * 64 floats
+        // of the Tl*N*H*32 it holds)
+        float* partial = const_cast<float*>(dq_part);
+        const int n_wgs = (N + DSW_POINTS - 1) / DSW_POINTS;
+        hipLaunchKernelGGL(dsw_kernel, dim3((unsigned)n_wgs), dim3(256), 0, st, dcs, coords, N, H, C, partial);
+        hipLaunchKernelGGL(dsw_sum_kernel, dim3(1), dim3(64), 0, st, partial, n_wgs, H * C, d_sqrt_w);
     }
     return hept_launch_status();
 }

@@ -86,13 +86,16 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
               int t0, int Tl, int precision, const Workspace& w, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     prof_mark(0, st);
-    int rc = hept_rpe_scale(w_rpe, H, D, C, K, w.sqrt_w, stream);
+    // K == 0: `w_rpe` already holds sqrt_w (H, C) -- the caller computed it once for constant weights
+    // (hept_rpe_scale); the 400 exponentials are their own 5 us launch otherwise
+    const float* sqrt_w = K == 0 ? w_rpe : w.sqrt_w;
+    int rc = K == 0 ? HEPT_OK : hept_rpe_scale(w_rpe, H, D, C, K, w.sqrt_w, stream);
     if (rc) return rc;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)Tl * H * N;
     for (int c0 = 0; c0 < Tl; c0 += HEPT_MAX_TABLES) {   // chunks of tables (the rows are rewritten identically)
         const int tc = Tl - c0 < HEPT_MAX_TABLES ? Tl - c0 : HEPT_MAX_TABLES;
-        rc = hept_prep_hash(q, k, v, coords, w.sqrt_w, alpha, codes, N, geo.eta ? geo.raw_size : N, H, D, C, T,
+        rc = hept_prep_hash(q, k, v, coords, sqrt_w, alpha, codes, N, geo.eta ? geo.raw_size : N, H, D, C, T,
                             t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream);
         if (rc) return rc;
         if (c0 == 0) prof_mark(1, st);
@@ -128,7 +131,7 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 12; }
+extern "C" int hept_abi_version(void) { return 13; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -136,10 +139,11 @@ extern "C" int hept_part_precision(int precision, int D) {
 
 extern "C" int hept_check_shape(int N, int H, int D, int C, int Tl, int B) {
     if (N < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0) return HEPT_ERR_SHAPE;
-    if (H != 8) return HEPT_ERR_SHAPE;
     if (Tl < 1) return HEPT_ERR_SHAPE;  // any number of tables: prep_hash and the sort run in chunks of HEPT_MAX_TABLES
-    const bool dc = (D == 24 && (C == 6 || C == 4 || C == 2)) || (D == 16 && (C == 6 || C == 4)) || (D == 8 && C == 4);
-    return dc ? HEPT_OK : HEPT_ERR_SHAPE;
+    // rows are 32 columns wide: [D features | C scaled coordinates | 0.. | norm], denominators ride at column D.
+    // (H = 8 with the shipped models' (D, C) pairs takes the tuned row builder, anything else the generic one.)
+    if (H < 1 || H > 16 || D < 1 || D > 27 || C < 2 || D + C > 30) return HEPT_ERR_SHAPE;  // (D <= 27: the combine reads the 28 leading floats of a row, denominator at column D)
+    return HEPT_OK;
 }
 
 extern "C" size_t hept_workspace_bytes(int N, int H, int D, int C, int Tl, int B, int precision) {
@@ -476,9 +480,10 @@ extern "C" int hept_attn_block_forward(const float* x, const float* coords, cons
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     prof_mark(0, st);
-    rc = hept_rpe_scale(p->w_rpe, H, D, C, K, w.sqrt_w, stream);
+    const float* sqrt_w = K == 0 ? p->w_rpe : w.sqrt_w;   // K == 0: params->w_rpe is sqrt_w (H, C), see hept_forward
+    rc = K == 0 ? HEPT_OK : hept_rpe_scale(p->w_rpe, H, D, C, K, w.sqrt_w, stream);
     if (rc) return rc;
-    rc = hept_prep_hash_fused(x, p->norm1_w, p->norm1_b, p->eps1, p->w_q, p->w_k, p->w_v, coords, w.sqrt_w, p->alpha,
+    rc = hept_prep_hash_fused(x, p->norm1_w, p->norm1_b, p->eps1, p->w_q, p->w_k, p->w_v, coords, sqrt_w, p->alpha,
                               codes, N, N, H, D, C, T, 0, T, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax,
                               stream);
     if (rc) return rc;

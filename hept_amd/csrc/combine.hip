@@ -425,7 +425,8 @@ __global__ __launch_bounds__(256) void reduce_heads_kernel(const float* __restri
 // Two kernels.  Rows: lane (point, head) recomputes per_head = numer / den, pulls g_out back through its head's
 // D x D weight slab (LDS, packed fp32 FMAs) and writes the gradient of the partial row [d numer | d den | 0].
 // Weight: one lane per output column (h, j) walks a slice of points and keeps the D partial sums of
-// dW[:, h*D + j] in registers; slices are merged with atomics (dW, db are zeroed by the entry point).
+// dW[:, h*D + j] in registers; every workgroup writes its sums to scratch and a second kernel adds the workgroups
+// in index order (float atomics made dW, db depend on the order in which workgroups retire).
 constexpr int CB_D = 24, CB_PITCH = CB_D * CB_D + 4;  // head pitch = 4 (mod 32): conflict-free 16-B reads for 8 heads
 
 __global__ __launch_bounds__(256) void combine_bwd_rows_kernel(const float* __restrict__ acc,
@@ -491,8 +492,7 @@ constexpr int CBW_GROUPS = 4;    // thread groups of H*D = 192 columns that shar
 // its 24 fma per point), fold through LDS, and one group adds the workgroup's sums to the output with atomics.
 __global__ __launch_bounds__(192 * CBW_GROUPS) void combine_bwd_weight_kernel(const float* __restrict__ acc,
                                                                               const float* __restrict__ g_out, int N,
-                                                                              int H, float* __restrict__ d_weight,
-                                                                              float* __restrict__ d_bias) {
+                                                                              int H, float* __restrict__ partial) {
     // one LDS region, used twice: the workgroup's g_out rows during the loop (every lane of a wave reads the same
     // word: an LDS broadcast instead of 24 scalar loads per point), then the fold of the thread groups
     __shared__ float red_s[CBW_GROUPS - 1][CB_D + 1][192];
@@ -543,10 +543,31 @@ __global__ __launch_bounds__(192 * CBW_GROUPS) void combine_bwd_weight_kernel(co
             for (int c = 0; c < CB_D; ++c) s[c] += red_s[g2][c][col];
             sb += red_s[g2][CB_D][col];
         }
+        float* mine = partial + (size_t)blockIdx.x * (CB_D + 1) * 192;   // [c][col], row CB_D = bias sums
 #pragma unroll
-        for (int c = 0; c < CB_D; ++c) atomicAdd(d_weight + (size_t)c * HD + col, s[c]);
-        if (col < CB_D && d_bias) atomicAdd(d_bias + col, sb);
+        for (int c = 0; c < CB_D; ++c) mine[c * 192 + col] = s[c];
+        mine[CB_D * 192 + col] = col < CB_D ? sb : 0.f;
     }
+}
+
+// d_weight[c][col] = sum over workgroups of partial[wg][c][col], d_bias[col] likewise from row CB_D: one thread per
+// output, workgroups added in index order (four interleaved chains)
+__global__ __launch_bounds__(256) void combine_bwd_weight_sum_kernel(const float* __restrict__ partial, int n_wgs, int HD,
+                                                                     float* __restrict__ d_weight,
+                                                                     float* __restrict__ d_bias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (CB_D + 1) * 192) return;
+    const int c = i / 192, col = i - c * 192;
+    if (col >= HD) return;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < n_wgs; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (g + u < n_wgs) a[u] += partial[(size_t)(g + u) * (CB_D + 1) * 192 + i];
+    }
+    const float tot = (a[0] + a[1]) + (a[2] + a[3]);
+    if (c < CB_D) d_weight[(size_t)c * HD + col] = tot;
+    else if (col < CB_D && d_bias) d_bias[col] = tot;
 }
 
 }  // namespace
@@ -613,6 +634,13 @@ int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int 
                                         (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0) +
                                         (split ? (CMB_WAVES - 1) * 16 * 64 : 0) +
                                         (PUSH ? (split ? 1 : CMB_WAVES) * 32 * 24 : 0));
+    if (lds > 65536) {   // many heads: the weight slab alone is 3.6 KiB per head
+        static LdsRaised raised_split, raised_flat;
+        if (hept_raise_lds(split ? raised_split : raised_flat,
+                           split ? reinterpret_cast<const void*>(&combine_out_kernel<P16, FFN, DT, true, PUSH>)
+                                 : reinterpret_cast<const void*>(&combine_out_kernel<P16, FFN, DT, false, PUSH>), lds))
+            return HEPT_ERR_LAUNCH;
+    }
     if (split) {
         hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true, PUSH>), dim3(n_tiles), dim3(CMB_THREADS), lds, st, part,
                            Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px);
@@ -628,7 +656,7 @@ extern "C" int hept_combine_groups(const float* part, int part_precision, int Tl
                                    int n_count, int HG, size_t group_stride, const float* out_weight,
                                    const float* out_bias, float* out, void* stream) {
     if (!part || !out_weight || !out) return HEPT_ERR_ARG;
-    if (Tl < 1 || N < 1 || H < 1 || H > 15 || D < 1 || D > 28 || n0 < 0 || n_count < 0 || n0 + n_count > N)
+    if (Tl < 1 || N < 1 || H < 1 || H > 16 || D < 1 || D > 27 || n0 < 0 || n_count < 0 || n0 + n_count > N)
         return HEPT_ERR_SHAPE;
     if (HG < 1 || HG > H || H % HG != 0) return HEPT_ERR_SHAPE;
     if (n_count == 0) return HEPT_OK;
@@ -672,7 +700,7 @@ extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, i
                                 const float* ff1_b, const float* ff2_w, const float* ff2_b, float* y, void* stream) {
     if (!part || !out_weight || !x || !norm_w || !norm_b || !ff1_w || !ff1_b || !ff2_w || !ff2_b || !y)
         return HEPT_ERR_ARG;
-    if (Tl < 1 || N < 1 || H < 1 || H > 15 || D != FFN_D || n0 < 0 || n_count < 0 || n0 + n_count > N)
+    if (Tl < 1 || N < 1 || H < 1 || H > 16 || D != FFN_D || n0 < 0 || n_count < 0 || n0 + n_count > N)
         return HEPT_ERR_SHAPE;
     if (n_count == 0) return HEPT_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -684,18 +712,25 @@ extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, i
     return HEPT_ERR_SHAPE;
 }
 
+extern "C" size_t hept_combine_bwd_scratch_bytes(int N) {
+    return N < 1 ? 0 : (size_t)((N + CBW_POINTS - 1) / CBW_POINTS) * (CB_D + 1) * 192 * sizeof(float);
+}
+
 extern "C" int hept_combine_bwd(const float* acc, const float* g_out, const float* out_weight, int N, int H, int D,
-                                float* gacc, float* d_weight, float* d_bias, void* stream) {
-    if (!acc || !g_out || !out_weight || !gacc || !d_weight) return HEPT_ERR_ARG;
+                                float* gacc, float* d_weight, float* d_bias, void* scratch, size_t scratch_bytes,
+                                void* stream) {
+    if (!acc || !g_out || !out_weight || !gacc || !d_weight || !scratch) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || H > 8 || D != CB_D) return HEPT_ERR_SHAPE;
+    if (scratch_bytes < hept_combine_bwd_scratch_bytes(N)) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(d_weight, 0, sizeof(float) * D * H * D, st) != hipSuccess) return HEPT_ERR_LAUNCH;
-    if (d_bias && hipMemsetAsync(d_bias, 0, sizeof(float) * D, st) != hipSuccess) return HEPT_ERR_LAUNCH;
     const size_t n_rows = (size_t)N * H;
     const size_t blocks = (n_rows + 255) / 256;
     hipLaunchKernelGGL(combine_bwd_rows_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, acc,
                        g_out, out_weight, N, H, gacc);
-    hipLaunchKernelGGL(combine_bwd_weight_kernel, dim3((N + CBW_POINTS - 1) / CBW_POINTS), dim3(192 * CBW_GROUPS), 0, st, acc, g_out, N,
-                       H, d_weight, d_bias);
+    const int n_wgs = (N + CBW_POINTS - 1) / CBW_POINTS;
+    float* partial = static_cast<float*>(scratch);
+    hipLaunchKernelGGL(combine_bwd_weight_kernel, dim3(n_wgs), dim3(192 * CBW_GROUPS), 0, st, acc, g_out, N, H, partial);
+    hipLaunchKernelGGL(combine_bwd_weight_sum_kernel, dim3(((CB_D + 1) * 192 + 255) / 256), dim3(256), 0, st, partial, n_wgs,
+                       H * D, d_weight, d_bias);
     return hept_launch_status();
 }

@@ -426,6 +426,157 @@ int launch_prep(const float* q, const float* k, const float* v, const float* coo
     return hept_launch_status();
 }
 
+// ---- any head count / head dimension -------------------------------------------------------------------------------
+// The reference takes any num_heads, h_dim and coords_dim (example/hept.py:34-41).  The kernels above are tuned for the
+// shipped models' H = 8 and six (D, C) pairs; everything else (1 <= H <= 16, D <= 28, C >= 1, D + C <= 30 -- the rows
+// are 32 columns wide) takes this kernel: the same arithmetic (ascending-e fmaf hash chain over the unrounded row,
+// norm of the rounded row for 16-bit tiles), one thread per (point, head) with plain loads, the same three roles and
+// the same outputs, including the per-workgroup hash-range partials the sort reduces.  Not tuned (its loads are
+// strided by the row length); correctness first.
+__device__ __forceinline__ unsigned int f32_ordered(float x) {
+    const unsigned int u = __float_as_uint(x);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_ordered(unsigned int u) {
+    return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+template <int TILE>
+__global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
+    const int64_t* __restrict__ codes, int N, int raw_size, int H, int D, int C, int T, int t0, int Tl,
+    void* __restrict__ qhat_, void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj,
+    float* __restrict__ minmax) {
+    constexpr bool BF16 = TILE != HEPT_PREC_F32;
+    constexpr bool F16QK = TILE == HEPT_PREC_MIXED16;
+    constexpr int QROW = BF16 ? 64 : 128;
+    __shared__ float alpha_s[16 * 30 * HEPT_MAX_TABLES];              // [h][e][t]
+    __shared__ unsigned int red_s[HEPT_MAX_TABLES * 16 * 3];          // ordered-uint min / max / code max per (t, h)
+    const int role = blockIdx.y, tid = threadIdx.x, E = D + C, HD = H * D;
+    const int ppw = PREP_THREADS / H;             // points per workgroup step; thread = (point slot, head), head fixed
+    const int h = tid % H, slot = tid / H;
+    const bool worker = slot < ppw;
+    if (role != 2) {
+        for (int i = tid; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
+            const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
+            alpha_s[i] = t < Tl ? alpha[(size_t)he * T + t0 + t] : 0.f;
+        }
+        for (int i = tid; i < HEPT_MAX_TABLES * 16 * 3; i += PREP_THREADS)
+            red_s[i] = (i % 3 == 0) ? f32_ordered(INFINITY) : (i % 3 == 1 ? f32_ordered(-INFINITY) : f32_ordered(0.f));
+        __syncthreads();
+    }
+    const float* x = role == 0 ? q : (role == 1 ? k : v);
+    char* out_rows = reinterpret_cast<char*>(role == 0 ? qhat_ : kvhat_);
+    const int rowb = role == 0 ? QROW : 2 * QROW, rowoff = role == 2 ? QROW : 0;
+    float* proj = role == 0 ? qproj : kproj;
+    float mn[HEPT_MAX_TABLES], mx[HEPT_MAX_TABLES], cm[HEPT_MAX_TABLES];
+#pragma unroll
+    for (int t = 0; t < HEPT_MAX_TABLES; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; cm[t] = 0.f; }
+    for (int n = blockIdx.x * ppw + slot; worker && n < N; n += gridDim.x * ppw) {
+        const bool is_pad = n >= raw_size;
+        float a[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) a[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 28; ++j)
+            if (j < D) a[j] = is_pad ? 0.f : x[(size_t)n * HD + h * D + j];
+        char* dst = out_rows + ((size_t)h * N + n) * rowb + rowoff;
+        if (role == 2) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j == D) a[j] = 1.f;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 30; ++c)
+                if (c < C) {
+                    const float val = is_pad ? 0.f : sqrt_w[h * C + c] * coords[(size_t)n * C + c];
+#pragma unroll
+                    for (int e = 1; e < 30; ++e)
+                        if (e == D + c) a[e] = val;
+                }
+            if (role == 0 && codes) {
+#pragma unroll
+                for (int t = 0; t < HEPT_MAX_TABLES; ++t)
+                    if (t < Tl) cm[t] = fmaxf(cm[t], __ll2float_ru(codes[((size_t)(t0 + t) * H + h) * N + n]));
+            }
+#pragma unroll
+            for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
+                if (t < Tl) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 30; ++e)
+                        if (e < E) acc = fmaf(a[e], alpha_s[(h * E + e) * HEPT_MAX_TABLES + t], acc);
+                    proj[((size_t)t * H + h) * N + n] = is_pad ? INFINITY : acc;
+                    mn[t] = fminf(mn[t], acc);
+                    mx[t] = fmaxf(mx[t], acc);
+                }
+            }
+        }
+        if (BF16) {
+            unsigned int wd[16];
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool f16 = F16QK && role != 2;
+                wd[i] = f16 ? hept_pack_f16(a[2 * i], a[2 * i + 1]) : hept_pack_bf16(a[2 * i], a[2 * i + 1]);
+                const float r0 = f16 ? hept_f16_lo(wd[i]) : hept_bf16_lo(wd[i]);
+                const float r1 = f16 ? hept_f16_hi(wd[i]) : hept_bf16_hi(wd[i]);
+                if (i < 15) { ss = fmaf(r0, r0, ss); ss = fmaf(r1, r1, ss); }   // columns 30, 31 are zero (E <= 30)
+            }
+            if (role != 2) wd[15] = __float_as_uint(-0.5f * ss);
+            u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d4[j] = u32x4{wd[4 * j], wd[4 * j + 1], wd[4 * j + 2], wd[4 * j + 3]};
+        } else {
+            if (role != 2) {
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 30; ++e) ss = fmaf(a[e], a[e], ss);   // zeros beyond E add nothing
+                a[31] = -0.5f * ss;
+            }
+            f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d4[j] = f32x4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
+        }
+    }
+    if (role == 2) return;
+    if (worker) {
+#pragma unroll
+        for (int t = 0; t < HEPT_MAX_TABLES; ++t)
+            if (t < Tl) {
+                atomicMin(&red_s[(t * 16 + h) * 3], f32_ordered(mn[t]));
+                atomicMax(&red_s[(t * 16 + h) * 3 + 1], f32_ordered(mx[t]));
+                atomicMax(&red_s[(t * 16 + h) * 3 + 2], f32_ordered(cm[t]));
+            }
+    }
+    __syncthreads();
+    const int pslot = (role == 0 ? 0 : HEPT_PREP_GRID / 2) + blockIdx.x;
+    for (int i = tid; i < Tl * H; i += PREP_THREADS) {
+        const int t = i / H, hh = i % H;
+        const unsigned int* r = red_s + (t * 16 + hh) * 3;
+        *reinterpret_cast<f32x4*>(minmax + (((size_t)t * H + hh) * HEPT_PREP_GRID + pslot) * 4) =
+            f32x4{f32_from_ordered(r[0]), f32_from_ordered(r[1]), f32_from_ordered(r[2]), 0.f};
+    }
+}
+
+int launch_prep_generic(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w,
+                        const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
+                        int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
+                        hipStream_t st) {
+    const dim3 grid(HEPT_PREP_GRID / 2, 3);   // q- and k-role workgroups each own one partial slot
+    if (precision == HEPT_PREC_BF16)
+        hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_BF16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
+                           alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+    else if (precision == HEPT_PREC_MIXED16)
+        hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_MIXED16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
+                           alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+    else
+        hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_F32>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
+                           alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+    return hept_launch_status();
+}
+
 }  // namespace
 
 extern "C" int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, float* sqrt_w, void* stream) {
@@ -451,13 +602,14 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
     if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
     if (!q || !k || !v || !coords || !sqrt_w || !alpha || !qhat || !kvhat || !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
-    if (H != 8 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (H < 1 || H > 16 || D < 1 || D > 28 || C < 1 || D + C > 30) return HEPT_ERR_SHAPE;
+    if (N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
     if (precision == HEPT_PREC_F32_MFMA) precision = HEPT_PREC_F32;  // same f32 tile rows, another block_attn kernel
     if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16 && precision != HEPT_PREC_MIXED16)
         return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
 #define HEPT_PREP_CASE(DD, CC)                                                                             \
-    if (D == DD && C == CC)                                                                                \
+    if (H == 8 && D == DD && C == CC)                                                                      \
         return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, precision, \
                                    qhat, kvhat, qproj, kproj, minmax, st);
     HEPT_PREP_CASE(24, 6)
@@ -467,7 +619,8 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
     HEPT_PREP_CASE(16, 4)
     HEPT_PREP_CASE(8, 4)
 #undef HEPT_PREP_CASE
-    return HEPT_ERR_SHAPE;
+    return launch_prep_generic(q, k, v, coords, sqrt_w, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, precision, qhat,
+                               kvhat, qproj, kproj, minmax, st);
 }
 
 extern "C" int hept_prep_hash_fused(const float* x, const float* norm_w, const float* norm_b, float eps,

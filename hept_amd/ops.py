@@ -316,9 +316,10 @@ def combine_bwd(acc: torch.Tensor, g_out: torch.Tensor, out_weight: torch.Tensor
     gacc = torch.empty_like(acc)
     dw = torch.empty_like(w)
     db = torch.empty(d, device=acc.device, dtype=torch.float32) if need_bias else None
+    scratch = torch.empty(int(lib.hept_combine_bwd_scratch_bytes(n)), device=acc.device, dtype=torch.uint8)
     _lib.check(lib.hept_combine_bwd(acc.data_ptr(), g_out.data_ptr(), w.data_ptr(), n, h, d, gacc.data_ptr(),
-                                    dw.data_ptr(), db.data_ptr() if db is not None else None, _stream(acc)),
-               "hept_combine_bwd")
+                                    dw.data_ptr(), db.data_ptr() if db is not None else None, scratch.data_ptr(),
+                                    scratch.numel(), _stream(acc)), "hept_combine_bwd")
     return gacc, dw, db
 
 
@@ -349,7 +350,10 @@ def _prepare(q, k, v, coords, codes, w_rpe_weight, alpha, block_size, w_per_dist
         raise ValueError(f"number of points {n} is not a multiple of block_size {block_size}")
     if codes is not None and (codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n)):
         raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}, got {codes.dtype} {tuple(codes.shape)}")
-    if w.shape != (h * d, (c - 1) * w_per_dist):
+    if w_per_dist == 0:  # precomputed sqrt_w (H, C) in place of the weight (hept_hip.h: K == 0)
+        if w.shape != (h, c):
+            raise ValueError(f"with w_per_dist=0 the weight argument is sqrt_w of shape {(h, c)}, got {tuple(w.shape)}")
+    elif w.shape != (h * d, (c - 1) * w_per_dist):
         raise ValueError(f"w_rpe.weight must have shape {(h * d, (c - 1) * w_per_dist)}, got {tuple(w.shape)}")
     return q, k, v, coords, codes.contiguous() if codes is not None else None, w, alpha, (n, h, d, c, t)
 

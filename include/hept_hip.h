@@ -159,6 +159,8 @@ int hept_combine_groups(const float* part, int part_precision, int Tl, int N, in
                         const float* out_bias, float* out, void* stream);
 
 /* Whole operator for tables [t0, t0+Tl): everything above in one call.
+ * K == 0 (every whole-operator entry point): `w_rpe` is not the (H*D, (C-1)*K) weight but the (H, C) result of
+ * hept_rpe_scale on it -- a caller whose w_rpe.weight is constant (inference) computes it once and saves the launch.
  * hept_forward writes out (N, D); hept_forward_partial stops at acc (N, H, row) in the row format
  * acc_precision (HEPT_PREC_F32, or hept_part_precision(precision, D)). */
 int hept_forward(const float* q, const float* k, const float* v, const float* coords,
@@ -328,7 +330,8 @@ int hept_block_attn_bwd_f32mfma(const float* qhat, const float* kvhat, const int
                                 float* dkv_part, void* stream);
 /* coords (N, C) + d_sqrt_w (H, C) (both may be NULL): also d_sqrt_w[h,c] = sum_n dcs[n,h,c] * coords[n,c], the
  * gradient that flows on into w_rpe.weight.  Rows at and after raw_size (the src variant's zero-filled padding,
- * raw_size = N otherwise) get zero gradients. */
+ * raw_size = N otherwise) get zero gradients.  With d_sqrt_w the head of dq_part is overwritten (it serves as
+ * scratch for the per-workgroup sums once it has been read; the sums are added in a fixed order). */
 int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
                     const float* coords, int raw_size, float* dq, float* dk, float* dv, float* dcs,
                     float* d_sqrt_w, void* stream);
@@ -338,8 +341,12 @@ int hept_rpe_scale_bwd(const float* w_rpe, const float* d_sqrt_w, int H, int D, 
 /* backward of hept_combine_out on table-summed f32 rows acc (N, H, 32) (example/hept.py:79-80 under autograd):
  * given g_out (N, D) writes gacc (N, H, 32) = gradient of acc, d_weight (D, H*D) and d_bias (D, may be NULL).
  * D == 24, H <= 8. */
+/* scratch: hept_combine_bwd_scratch_bytes(N) bytes (per-workgroup partial sums of d_weight / d_bias, added in a
+ * fixed order by a second kernel: the gradients are bit-identical from run to run). */
+size_t hept_combine_bwd_scratch_bytes(int N);
 int hept_combine_bwd(const float* acc, const float* g_out, const float* out_weight, int N, int H, int D,
-                     float* gacc, float* d_weight, float* d_bias, void* stream);
+                     float* gacc, float* d_weight, float* d_bias, void* scratch, size_t scratch_bytes,
+                     void* stream);
 
 /* SURVEY.md §8 f-1 — replaces prepare_input (example/transformer.py:35-63: per-cloud argsorts of eta / phi,
  * quantile_partition example/hept_utils.py:6-14, bit_shift x2 :10-13, pad_and_unpad :16-32 and the gathers by

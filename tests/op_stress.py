@@ -16,15 +16,21 @@ from hept_amd.synthetic import make_inputs  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 g = torch.Generator().manual_seed(99)
 dev = torch.device("cuda", 0)
-pairs = [(24, 6), (24, 4), (24, 2), (16, 6), (16, 4), (8, 4)]
+pairs = [(24, 6), (24, 4), (24, 2), (16, 6), (16, 4), (8, 4)]   # H = 8 with these: the tuned row builder
+# the reference takes any num_heads / h_dim / coords_dim (example/hept.py:34-41): every third shape draws them freely
+# (1 <= H <= 16, D <= 27, D + C <= 30), which runs the generic row builder and the generic-D combine
+free = [(4, 24, 6), (16, 24, 6), (16, 12, 3), (2, 27, 3), (5, 20, 5), (12, 8, 4), (1, 24, 6), (3, 10, 6), (16, 16, 4), (7, 17, 3)]
 bad = 0
 for it in range(iters):
     d, c = pairs[it % len(pairs)]
+    nh = 8
+    if it % 3 == 2:
+        nh, d, c = free[(it // 3) % len(free)]
     b = int(torch.randint(8, 257, (1,), generator=g))
     t = int(torch.randint(1, 9, (1,), generator=g))
     n_clouds = int(torch.randint(1, 4, (1,), generator=g))
     sizes = [int(torch.randint(b, 4 * b + 40, (1,), generator=g)) for _ in range(n_clouds)]
-    inp = make_inputs(sizes, block_size=b, n_hashes=t, coords_dim=c, h_dim=d, seed=1000 + it)
+    inp = make_inputs(sizes, block_size=b, n_hashes=t, coords_dim=c, h_dim=d, num_heads=nh, seed=1000 + it)
     scale = 0.3
     inp["q"], inp["k"] = inp["q"] * scale, inp["k"] * scale
     inp["coords"] = inp["coords"] * 0.2
@@ -44,6 +50,6 @@ for it in range(iters):
             ok = float((err <= 8e-3 * (want.abs().amax(-1) + 1e-2)).float().mean())
         if not (ok >= 0.97 and bool(torch.isfinite(got).all())):
             bad += 1
-            print(f"MISMATCH it={it} D={d} C={c} B={b} T={t} sizes={sizes} {prec}: rows ok {ok:.4f}", flush=True)
+            print(f"MISMATCH it={it} H={nh} D={d} C={c} B={b} T={t} sizes={sizes} {prec}: rows ok {ok:.4f}", flush=True)
 print(f"{iters} shapes, {bad} mismatches")
 sys.exit(1 if bad else 0)

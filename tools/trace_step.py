@@ -22,15 +22,18 @@ if how != "plain":
     os.environ.setdefault("MASTER_PORT", "29534")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     group = dist.group.WORLD
-inp = workload_inputs("tracking-60k", seed=0, n_hashes=3)
+wl = os.environ.get("HEPT_TRACE_WORKLOAD", "tracking-60k")
+inp = workload_inputs(wl, seed=0)
+from hept_amd.synthetic import WORKLOADS  # noqa: E402
 g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
-w_rpe = torch.nn.Linear(50, 192).to(dev)
+w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], 192).to(dev)
 with torch.no_grad():
     w_rpe.weight.copy_(g["w_rpe_weight"])
-m = HEPTAttention(30, h_dim=24, num_heads=8, block_size=128, n_hashes=3, num_w_per_dist=10, precision=prec,
-                  process_group=group)
+T = inp["alpha"].shape[2]
+m = HEPTAttention(inp["alpha"].shape[1], h_dim=24, num_heads=8, block_size=WORKLOADS[wl]["block_size"], n_hashes=T,
+                  num_w_per_dist=10, precision=prec, process_group=group)
 if group is not None:
-    m.sharding = TableSharding(3, group, mode="all_to_all", always_exchange=True, head_groups=groups)
+    m.sharding = TableSharding(T, group, mode="all_to_all", always_exchange=True, head_groups=groups)
     if how in ("torch", "rccl"):
         m.sharding.exchange = how
 m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"], "e2lsh.alpha": inp["alpha"]})
