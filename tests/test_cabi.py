@@ -48,11 +48,15 @@ def test_shape_checks_are_host_side(lib):
     assert ok(5120, 8, 24, 4, 3, 256) == 0
     assert ok(2400, 8, 24, 6, 3, 100) == 0
     assert ok(60000, 8, 24, 6, 3, 128) == 1      # N % B != 0 (the reference raises EinopsError)
-    assert ok(4096, 4, 24, 6, 3, 128) == 1       # heads
+    assert ok(4096, 4, 24, 6, 3, 128) == 0       # any head count up to 16 ...
+    assert ok(4096, 16, 20, 5, 3, 128) == 0      # ... and any head / coordinate dims that fit the 32-column rows
+    assert ok(4096, 17, 24, 6, 3, 128) == 1
+    assert ok(4096, 8, 28, 2, 3, 128) == 1       # head dim > 27
+    assert ok(4096, 8, 26, 6, 3, 128) == 1       # D + C > 30
     assert ok(4096, 8, 24, 6, 9, 128) == 0       # any number of tables (walked in chunks of HEPT_MAX_TABLES)
     assert ok(4096, 8, 24, 6, 0, 128) == 1
     assert ok(4096, 8, 24, 6, 3, 512) == 1       # block too large
-    assert ok(4096, 8, 20, 6, 3, 128) == 1       # head dim
+    assert ok(4096, 8, 20, 6, 3, 128) == 0
 
 
 def test_workspace_size_model(lib):
