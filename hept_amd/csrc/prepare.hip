@@ -144,9 +144,81 @@ __global__ __launch_bounds__(PT) void pad_gather_kernel(const int* __restrict__ 
     }
 }
 
+// ---- the src variant's caller side (src/models/baselines/transformer.py:43-57): ONE cloud, padded once at its end
+// keys[a][n] = coordinate a of point n, +inf for the padding slots (they sort last, in index order); the padded
+// coordinate rows (zero rows for the padding, :57) and the padded feature rows (zero rows, :46) are written here too
+__global__ __launch_bounds__(PT) void src_pad_keys_kernel(const float* __restrict__ x, int F,
+                                                          const float* __restrict__ coords, int C, int raw_size, int N,
+                                                          float* __restrict__ keys, float* __restrict__ x_pad,
+                                                          float* __restrict__ coords_pad) {
+    const size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    const int part = blockIdx.y;
+    if (part == 0) {
+        if (i < (size_t)N) {
+            const bool real = i < (size_t)raw_size;
+            keys[i] = real ? coords[i * C] : INFINITY;
+            keys[(size_t)N + i] = real ? coords[i * C + 1] : INFINITY;
+            for (int a = 0; a < C; ++a) coords_pad[i * C + a] = real ? coords[i * C + a] : 0.f;
+        }
+    } else if (x_pad) {
+        const size_t total = (size_t)N * F, j = ((size_t)(part - 1) * gridDim.x + blockIdx.x) * PT + threadIdx.x;
+        const size_t step = (size_t)(gridDim.y - 1) * gridDim.x * PT;
+        for (size_t e = j; e < total; e += step) x_pad[e] = e < (size_t)raw_size * F ? x[e] : 0.f;
+    }
+}
+
+// rank[a][point] = position of the point in the ascending order of coordinate a
+__global__ __launch_bounds__(PT) void src_rank_kernel(const int* __restrict__ pos, int N, int* __restrict__ rank) {
+    const int a = blockIdx.y, r = blockIdx.x * PT + threadIdx.x;
+    if (r < N) rank[(size_t)a * N + pos[(size_t)a * N + r]] = r;
+}
+
+// region_indices[a][(t, h)][n] = rank // ceil(N / regions[t][a][h]) + 1 as float (quantile_partition,
+// src/models/model_utils/hash_utils.py:14-22, with torch's reciprocal-times-n evaluation of `int / tensor`)
+__global__ __launch_bounds__(PT) void src_region_kernel(const int* __restrict__ rank, int N,
+                                                        const float* __restrict__ regions, int T, int H,
+                                                        float* __restrict__ eta, float* __restrict__ phi) {
+    const int row = blockIdx.y % (T * H), a = blockIdx.y / (T * H), t = row / H, h = row % H;
+    const int n = blockIdx.x * PT + threadIdx.x;
+    if (n >= N) return;
+    const int id = region_of(rank[(size_t)a * N + n], N, regions[((size_t)t * 2 + a) * H + h]);
+    (a ? phi : eta)[(size_t)row * N + n] = (float)id;
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
+
+extern "C" size_t hept_prepare_src_workspace_bytes(int N) {
+    if (N < 1) return 0;
+    return al256((size_t)2 * N * 4) * 3 + al256(hept_argsort_workspace_bytes(2, N));
+}
+
+// x (raw_size, F) f32 or NULL (then x_pad is not written); coords (raw_size, C); regions (T, 2, H).
+// Outputs: x_pad (N, F), coords_pad (N, C), eta / phi (T*H, N) f32 = kwargs["region_indices"]; N = raw_size rounded up
+// to a multiple of the block size by the caller.
+extern "C" int hept_prepare_input_src(const float* x, int F, const float* coords, int C, int raw_size, int N,
+                                      const float* regions, int T, int H, void* workspace, size_t workspace_bytes,
+                                      float* x_pad, float* coords_pad, float* eta_idx, float* phi_idx, void* stream) {
+    if (!coords || !regions || !workspace || !coords_pad || !eta_idx || !phi_idx) return HEPT_ERR_ARG;
+    if (x && !x_pad) return HEPT_ERR_ARG;
+    if (C < 2 || raw_size < 1 || N < raw_size || T < 1 || H < 1 || (x && F < 1)) return HEPT_ERR_SHAPE;
+    if (workspace_bytes < hept_prepare_src_workspace_bytes(N)) return HEPT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* keys = reinterpret_cast<float*>(ws);
+    int* pos = reinterpret_cast<int*>(ws + al256((size_t)2 * N * 4));
+    int* rank = reinterpret_cast<int*>(ws + 2 * al256((size_t)2 * N * 4));
+    void* sort_ws = ws + 3 * al256((size_t)2 * N * 4);
+    const unsigned nb = (unsigned)((N + PT - 1) / PT);
+    hipLaunchKernelGGL(src_pad_keys_kernel, dim3(nb, x ? 5 : 1), dim3(PT), 0, st, x, F, coords, C, raw_size, N, keys,
+                       x ? x_pad : nullptr, coords_pad);
+    int rc = hept_segmented_argsort(keys, 2, N, sort_ws, pos, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(src_rank_kernel, dim3(nb, 2), dim3(PT), 0, st, pos, N, rank);
+    hipLaunchKernelGGL(src_region_kernel, dim3(nb, 2 * T * H), dim3(PT), 0, st, rank, N, regions, T, H, eta_idx, phi_idx);
+    return hept_launch_status();
+}
 
 extern "C" size_t hept_prepare_workspace_bytes(int n_raw, int n_clouds, int max_cloud, int T, int H) {
     const size_t S = (size_t)2 * n_clouds;

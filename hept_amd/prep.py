@@ -27,7 +27,7 @@ from typing import Dict, Tuple
 import torch
 
 __all__ = ["get_regions", "quantile_partition", "bit_shift", "pad_and_unpad", "prepare_input", "prepare_input_hip",
-           "prepare_input_src"]
+           "prepare_input_src", "prepare_input_src_hip"]
 
 
 def get_regions(num_regions, num_or_hashes, num_heads, num_and_hashes=2, generator=None) -> torch.Tensor:
@@ -206,6 +206,8 @@ def prepare_input_src(x, coords, helper_funcs) -> Tuple[torch.Tensor, Dict]:
     ascending index (the reference's ``argsort`` leaves them undefined); runs on the device of its inputs.
     """
     block_size, regions = int(helper_funcs["block_size"]), helper_funcs["regions"]
+    if coords.is_cuda:
+        return prepare_input_src_hip(x, coords, block_size, regions)
     with torch.no_grad():
         raw_size = x.shape[0]
         n_pad = (-raw_size) % block_size
@@ -218,3 +220,40 @@ def prepare_input_src(x, coords, helper_funcs) -> Tuple[torch.Tensor, Dict]:
         region_indices = [quantile_partition(order[axis], regions_h[axis][:, None]) for axis in (0, 1)]
         coords_p[raw_size:] = 0.0
     return x_p, {"raw_size": raw_size, "coords": coords_p, "region_indices": region_indices, "regions_h": regions_h}
+
+
+def prepare_input_src_hip(x, coords, block_size: int, regions) -> Tuple[torch.Tensor, Dict]:
+    """:func:`prepare_input_src` for GPU tensors in ONE C call (``hept_prepare_input_src``): padding of features and
+    coordinates, the two stable ranks (padding last), the float region ids of every (table, head) and the zeroing
+    of the padded coordinates.  Bit-exact against the torch implementation above (tests/test_gpu_src.py)."""
+    from . import _lib
+    from .ops import _stream
+
+    lib = _lib.load()
+    raw_size = x.shape[0]
+    n = raw_size + (-raw_size) % block_size
+    n_tables, _, num_heads = regions.shape
+    dev = coords.device
+    regions_f = regions.to(device=dev, dtype=torch.float32).contiguous()
+    coords_f = coords.float().contiguous()
+    feat = int(x[0].numel()) if raw_size else 0
+    x_is_f32 = x.is_cuda and x.dtype == torch.float32 and feat > 0
+    x_f = x.reshape(raw_size, feat).contiguous() if x_is_f32 else None
+    x_pad = torch.empty((n, feat), device=dev, dtype=torch.float32) if x_is_f32 else None
+    coords_pad = torch.empty((n, coords.shape[1]), device=dev, dtype=torch.float32)
+    eta = torch.empty((n_tables * num_heads, n), device=dev, dtype=torch.float32)
+    phi = torch.empty_like(eta)
+    ws = torch.empty(int(lib.hept_prepare_src_workspace_bytes(n)), device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _lib.check(lib.hept_prepare_input_src(x_f.data_ptr() if x_is_f32 else None, feat, coords_f.data_ptr(),
+                                              coords.shape[1], raw_size, n, regions_f.data_ptr(), n_tables, num_heads,
+                                              ws.data_ptr(), ws.numel(), x_pad.data_ptr() if x_is_f32 else None,
+                                              coords_pad.data_ptr(), eta.data_ptr(), phi.data_ptr(), _stream(coords)),
+                   "hept_prepare_input_src")
+    if x_is_f32:
+        x_p = x_pad.reshape((n,) + tuple(x.shape[1:]))
+    else:  # other dtypes / devices of x: pad with torch (the reference pads whatever it is given)
+        x_p = torch.cat([x, x.new_zeros((n - raw_size,) + tuple(x.shape[1:]))]) if n != raw_size else x
+    regions_h = regions_f.permute(1, 0, 2).reshape(2, n_tables * num_heads)  # "c a h -> a (c h)"
+    return x_p, {"raw_size": raw_size, "coords": coords_pad.to(coords.dtype), "region_indices": [eta, phi],
+                 "regions_h": regions_h}

@@ -362,6 +362,18 @@ int hept_prepare_input(const float* coords, int C, const int32_t* cloud_start, c
                        int B, void* workspace, size_t workspace_bytes, int64_t* pad_seq, unsigned char* unpad,
                        float* coords_pad, int64_t* codes_pad, void* stream);
 
+/* SURVEY.md §8 f-3, caller side — replaces the preparation of the reference's src variant
+ * (src/models/baselines/transformer.py:43-57: pad_to_multiple x2, argsort(eta), argsort(phi), quantile_partition x2
+ * src/models/model_utils/hash_utils.py:14-22, zeroing of the padded coordinates) for its single cloud.
+ *   x (raw_size, F) f32 or NULL; coords (raw_size, C) f32; regions (T, 2, H) f32; N = raw_size padded to a block multiple.
+ * Outputs: x_pad (N, F) (zero rows after raw_size; skipped when x is NULL), coords_pad (N, C) (zero rows after
+ * raw_size), eta_idx / phi_idx (T*H, N) f32 = kwargs["region_indices"] (rows ordered (table, head)); the padding
+ * slots rank last in index order.  Ties between equal coordinates are broken by ascending index. */
+size_t hept_prepare_src_workspace_bytes(int N);
+int hept_prepare_input_src(const float* x, int F, const float* coords, int C, int raw_size, int N,
+                           const float* regions, int T, int H, void* workspace, size_t workspace_bytes,
+                           float* x_pad, float* coords_pad, float* eta_idx, float* phi_idx, void* stream);
+
 /* Optional stage timing with HIP events recorded on the caller's stream inside hept_forward /
  * hept_forward_partial (nothing like it exists in the reference; used by bench.py for the roofline).
  * mode 0: off (default).  mode 1: bracket the block_attn kernel only (2 events per call).

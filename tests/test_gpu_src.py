@@ -107,6 +107,30 @@ def test_src_partial_tables_sum_to_the_whole(gpu_device):
     torch.testing.assert_close(two, acc, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("raw,block,feat", [(1000, 128, 24), (5000, 100, 7), (4096, 128, 3), (60000, 128, 24), (37, 64, 1)])
+def test_prepare_input_src_one_hip_call_is_bit_exact(raw, block, feat, gpu_device):
+    """hept_prepare_input_src (pad x / coords, two stable ranks with the padding last, float region ids of every
+    (table, head), zeroed padding coordinates) against the torch implementation of the same function on CPU tensors,
+    which tests/test_oracle_src_golden.py pins on the reference's own kwargs.  Duplicate coordinates included."""
+    from hept_amd.prep import get_regions
+
+    gen = torch.Generator().manual_seed(raw)
+    x = torch.randn(raw, feat, generator=gen)
+    coords = torch.randn(raw, 4, generator=gen)
+    coords[::7, 0] = coords[0, 0]          # ties: broken by ascending index on both sides
+    coords[1::5, 1] = 0.25
+    regions = get_regions(140, 3, 8, generator=gen)
+    hp = {"block_size": block, "regions": regions}
+    xc, kc = prepare_input_src(x, coords, hp)
+    xg, kg = prepare_input_src(x.to(gpu_device), coords.to(gpu_device), {"block_size": block, "regions": regions.to(gpu_device)})
+    assert kg["raw_size"] == kc["raw_size"] == raw
+    assert torch.equal(xg.cpu(), xc) and torch.equal(kg["coords"].cpu(), kc["coords"])
+    assert torch.equal(kg["regions_h"].cpu(), kc["regions_h"])
+    for a in (0, 1):
+        assert kg["region_indices"][a].dtype == torch.float32
+        assert torch.equal(kg["region_indices"][a].cpu(), kc["region_indices"][a].float())
+
+
 @pytest.mark.parametrize("name", ["s1_src1000", "s3_src_pileup"])
 def test_src_module_forward_backward(name, gpu_device):
     """nn.Module with the src variant's kwargs, built by the GPU-side prepare_input_src; inference and training."""
