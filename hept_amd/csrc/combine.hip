@@ -124,6 +124,27 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             const int g = tid / px.world, src = tid - g * px.world;
             wait_flag(flag_word(px.local, g * HEPT_MAX_RANKS_DEV + src), px.epoch, px.status, 1u, px.timeout);
         }
+        __syncthreads();   // nobody reads a received row before every flag has been seen
+    }
+    // The first tile's rows are requested BEFORE the weights are staged: every wave of the launch is resident at once
+    // (one tile per wave at tracking-60k), so without this the whole chip spends the staging prologue (~3 us) with
+    // no row in flight.
+    const size_t tstride = (size_t)N * HG * ROWF;
+    const int n_tiles = (n_count + 31) / 32;
+    const int hp0 = SPLIT ? 2 * w : 0, hstep = SPLIT ? 2 * CMB_WAVES : 2;
+    const int tpre = Tl < 3 ? Tl : 3;
+    auto row_at = [&](int tile, int hp) {
+        const int i = tile * 32 + li;
+        const int n = n0 + (i < n_count ? i : n_count - 1);
+        const int head = hp + hh < H ? hp + hh : 0, g = head / HG;
+        return part + (size_t)n * HG * ROWF + (size_t)g * gstride + (size_t)(head - g * HG) * ROWF;
+    };
+    const int tile_first = SPLIT ? blockIdx.x : blockIdx.x * CMB_WAVES + w;
+    RawRow<P16> pre[3];
+    if (tile_first < n_tiles && hp0 < HP) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < tpre) pre[t].load(row_at(tile_first, hp0) + (size_t)t * tstride);
     }
     if constexpr (FFN) {
         for (int i = tid; i < FFN_D * FFN_D; i += CMB_THREADS) {
@@ -140,29 +161,21 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     __syncthreads();
     // rows of head group g = head / HG live in their own (Tl, N, HG, row) buffer at part + g * gstride (table
     // sharding receives the head groups one exchange at a time); HG == H: the plain (Tl, N, H, row) layout
-    const size_t tstride = (size_t)N * HG * ROWF;
-    const int n_tiles = (n_count + 31) / 32;
-    const int hp0 = SPLIT ? 2 * w : 0, hstep = SPLIT ? 2 * CMB_WAVES : 2;
     float* red_s = stage_s_end;  // SPLIT: [CMB_WAVES - 1][16][64] partial accumulators of waves 1..
     // PUSH: this wave's 32 x 24 tile as a contiguous image of the output rows (wave 0 only under SPLIT)
     float* push_s = red_s + (SPLIT ? (CMB_WAVES - 1) * 16 * 64 : 0) + (SPLIT ? 0 : w * 32 * 24);
-    for (int tile = SPLIT ? blockIdx.x : blockIdx.x * CMB_WAVES + w; tile < n_tiles;
-         tile += SPLIT ? gridDim.x : gridDim.x * CMB_WAVES) {
+    for (int tile = tile_first; tile < n_tiles; tile += SPLIT ? gridDim.x : gridDim.x * CMB_WAVES) {
         const int i = tile * 32 + li;
-        const int n = n0 + (i < n_count ? i : n_count - 1);
-        const float* prow = part + (size_t)n * HG * ROWF;
-        auto row_of = [&](int hp) {
-            const int head = hp + hh < H ? hp + hh : 0, g = head / HG;
-            return prow + (size_t)g * gstride + (size_t)(head - g * HG) * ROWF;
-        };
+        auto row_of = [&](int hp) { return row_at(tile, hp); };
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         RawRow<P16> cur[3], nxt[3];  // up to 3 tables in flight; more tables are loaded in place below
-        const int tpre = Tl < 3 ? Tl : 3;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-            if (t < tpre && hp0 < HP) cur[t].load(row_of(hp0) + (size_t)t * tstride);
+        for (int t = 0; t < 3; ++t) {
+            if (tile == tile_first) cur[t] = pre[t];
+            else if (t < tpre && hp0 < HP) cur[t].load(row_of(hp0) + (size_t)t * tstride);
+        }
         for (int hp = hp0; hp < HP; hp += hstep) {
             const bool more = hp + hstep < HP;
 #pragma unroll
@@ -621,7 +634,13 @@ extern "C" int hept_reduce_heads(const float* part, int part_precision, int Tl, 
 }
 
 // few tiles: one tile per workgroup, head pairs split over its waves (SPLIT); else one tile per wave
-constexpr int CMB_SPLIT_BELOW = 1024;  // tiles; 1024 tiles = one wave per SIMD on 256 CUs
+#ifndef HEPT_CMB_SPLIT_BELOW
+#define HEPT_CMB_SPLIT_BELOW 1024
+#endif
+#ifndef HEPT_CMB_SPLIT_GRID
+#define HEPT_CMB_SPLIT_GRID (1 << 30)
+#endif
+constexpr int CMB_SPLIT_BELOW = HEPT_CMB_SPLIT_BELOW;  // tiles; 1024 tiles = one wave per SIMD on 256 CUs
 
 template <bool P16, bool FFN, int DT, bool PUSH = false>
 int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int D, int n0, int n_count, const float* W,
@@ -642,7 +661,7 @@ int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int 
             return HEPT_ERR_LAUNCH;
     }
     if (split) {
-        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true, PUSH>), dim3(n_tiles), dim3(CMB_THREADS), lds, st, part,
+        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true, PUSH>), dim3(n_tiles < HEPT_CMB_SPLIT_GRID ? n_tiles : HEPT_CMB_SPLIT_GRID), dim3(CMB_THREADS), lds, st, part,
                            Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px);
     } else {
         const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
