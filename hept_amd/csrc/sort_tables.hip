@@ -196,6 +196,15 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
 // buckets of their segment (any order inside a bucket: K4 ranks full pairs).  A chunk of 4096 keys is bucket-sorted
 // inside LDS first (local slot = LDS atomic on the digit counter), so that the global writes are runs of
 // consecutive pairs instead of single 8-byte scatters.
+// EMBED (segments of at most 2^20 keys): the pair carries the low id bits next to the point index,
+//     pair = key << 32 | low id << 20 | index,
+// so that K4 reads a pair's group with a shift instead of recomputing the float id map (K4 is bound by VALU issue:
+// three id evaluations per pair were 40 % of its instructions).  The order of the pairs as u64 is unchanged: the id is
+// a monotone function of the key, equal keys carry equal ids.
+constexpr int EMBED_SHIFT = 20;
+constexpr unsigned int EMBED_INDEX_MASK = (1u << EMBED_SHIFT) - 1u;
+static_assert(TOP_SHIFT + EMBED_SHIFT <= 32, "low id bits + index fit the low word of a pair");
+template <bool EMBED>
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned int* __restrict__ keys0,
                                                                const SegParams* __restrict__ seg_params,
                                                                const unsigned int* __restrict__ hist, int N,
@@ -254,12 +263,14 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
         if (chunk == 0) bstart[(size_t)seg * RADIX + tid] = excl;
     }
     __syncthreads();
-    unsigned short rank[SORT_ITEMS];
+    unsigned short rank[SORT_ITEMS], lowid[SORT_ITEMS];
     unsigned char dig[SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int n = base + r * SORT_THREADS + tid;
-        const unsigned int dg = bucket_id(key[r], rg.kmin, rg.scale) >> TOP_SHIFT;
+        const unsigned int id = bucket_id(key[r], rg.kmin, rg.scale);
+        const unsigned int dg = id >> TOP_SHIFT;
+        lowid[r] = (unsigned short)(id & (unsigned int)(LOBINS - 1));
         dig[r] = (unsigned char)dg;
         rank[r] = n < len ? (unsigned short)atomicAdd(&cnt_s[dg], 1u) : (unsigned short)0;
     }
@@ -283,7 +294,9 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int n = base + r * SORT_THREADS + tid;
-        if (n < len) stage_s[start_s[dig[r]] + rank[r]] = ((unsigned long long)key[r] << 32) | (unsigned int)n;
+        if (n < len)
+            stage_s[start_s[dig[r]] + rank[r]] = ((unsigned long long)key[r] << 32) |
+                                                 (EMBED ? ((unsigned int)lowid[r] << EMBED_SHIFT) | (unsigned int)n : (unsigned int)n);
     }
     __syncthreads();
     // write out: consecutive local positions of one digit are consecutive global positions
@@ -314,7 +327,7 @@ constexpr int BKT_THREADS = HEPT_BKT_THREADS;
 constexpr int BKT_WAVES = BKT_THREADS / HEPT_WAVE;
 constexpr int BKT_BINS_PER_THREAD = LOBINS / BKT_THREADS;
 static_assert(LOBINS % BKT_THREADS == 0, "every thread owns the same number of bins");
-template <int CAP>
+template <int CAP, bool EMBED>
 __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned long long* __restrict__ pairs,
                                                                   unsigned long long* __restrict__ scratch,
                                                                   const SegParams* __restrict__ seg_params,
@@ -345,7 +358,9 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     bool in_lds = nb <= 2 * CAP;                 // workgroup-uniform
     unsigned long long* spl_s = tile_s;          // the streaming path groups in global scratch, its tile is free
     auto lo_of = [&](unsigned long long p) -> unsigned int {
-        if (in_lds) return bucket_id((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
+        if (in_lds)
+            return EMBED ? ((unsigned int)p >> EMBED_SHIFT) & (unsigned int)(LOBINS - 1)
+                         : bucket_id((unsigned int)(p >> 32), rg.kmin, rg.scale) & (unsigned int)(LOBINS - 1);
         int lo = 0, hi = LOBINS;  // number of splitters <= p
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -438,14 +453,16 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
             const unsigned int d = lo_of(p);
             const int g0 = (int)cur_s[d] - off, g1 = (int)cur_s[d + 1] - off;  // = bin_s[d - 1], bin_s[d]
             int smaller = 0;
-            for (int j = g0; j < g1; j += 4) {  // 4 independent reads per round trip
+            // (a pair alone in its id group -- most of them -- needs no look at the tile: the kernel is bound by LDS
+            //  instruction throughput, every skipped read counts)
+            for (int j = g0; g1 - g0 > 1 && j < g1; j += 4) {  // 4 independent reads per round trip
                 unsigned long long q[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) q[u] = grouped[min(j + u, g1 - 1)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) smaller += (j + u < g1) && (q[u] < p);
             }
-            out[off + g0 + smaller] = (int)(unsigned int)p;
+            out[off + g0 + smaller] = (int)(EMBED ? (unsigned int)p & EMBED_INDEX_MASK : (unsigned int)p);
         }
     };
     if (in_lds) {
@@ -779,17 +796,23 @@ SortBuffers carve_sort(void* sort_ws, int segs, int N) {
 }
 constexpr int BKT_CAP_SMALL = HEPT_BKT_CAP;  // LDS tile: the average bucket is N/NTOP
 constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segments (average bucket up to ~3000 pairs)
-void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const int* seg_len = nullptr) {
+template <bool EMBED>
+void run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const int* seg_len) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const dim3 grid(n_chunks, segs), block(SORT_THREADS);
-    hipLaunchKernelGGL(scatter_kernel, grid, block, 0, st, b.keys0, b.params, b.hist, N, n_chunks, b.bstart, b.pa, seg_len);
+    hipLaunchKernelGGL(scatter_kernel<EMBED>, grid, block, 0, st, b.keys0, b.params, b.hist, N, n_chunks, b.bstart, b.pa,
+                       seg_len);
     const dim3 grid4(NTOP, segs);
     if ((size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2))
-        hipLaunchKernelGGL(bucket_sort_kernel<BKT_CAP_SMALL>, grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
+        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
                            b.bstart, N, pos, seg_len);
     else
-        hipLaunchKernelGGL(bucket_sort_kernel<BKT_CAP_LARGE>, grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
+        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_LARGE, EMBED>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
                            b.bstart, N, pos, seg_len);
+}
+void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const int* seg_len = nullptr) {
+    if (N <= (1 << EMBED_SHIFT)) run_passes_impl<true>(b, segs, N, pos, st, seg_len);
+    else run_passes_impl<false>(b, segs, N, pos, st, seg_len);
 }
 
 }  // namespace
