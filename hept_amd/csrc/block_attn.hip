@@ -29,6 +29,7 @@
 // blockIdx % H = head: with H = 8 every XCD (round-robin dispatch) gathers from one head's
 // qhat/kvhat slab only (speed only; nothing depends on placement).
 #include "common.h"
+#include "p2p_dev.h"
 
 namespace {
 
@@ -44,7 +45,14 @@ void block_attn_kernel(const char* __restrict__ qhat,
                                                               const int* __restrict__ qpos,
                                                               const int* __restrict__ kpos,
                                                               float* __restrict__ part, int N, int H, int D, int B,
-                                                              int nb, HeadRange hr) {
+                                                              int nb, HeadRange hr, PushArgs pa) {
+    // one-sided table sharding: the first pa.push_wgs workgroups of the launch do not compute attention but sum and
+    // send the rows of the PREVIOUS head group (p2p_dev.h); they sit at the front of the grid so that they start
+    // with the kernel and run beside the attention workgroups for its whole length
+    if (pa.push_wgs > 0 && (int)blockIdx.x < pa.push_wgs) {
+        reduce_push_body<P16>(pa, (int)blockIdx.x);
+        return;
+    }
     constexpr int NT = 64 * NKT;
     constexpr int KEYS = 32 * NKT;
     constexpr int ESZ = BF16 ? 2 : 4;
@@ -61,7 +69,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
     int* qidx_s = reinterpret_cast<int*>(smem + 2 * KEYS * QROW + KEYS * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
-    const int bid = blockIdx.x;
+    const int bid = (int)blockIdx.x - pa.push_wgs;
     const int h = hr.h0 + bid % hr.hg;
     const int rest = bid / hr.hg;
     const int b = rest % nb, t = rest / nb;
@@ -241,7 +249,11 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
                                                                     const int* __restrict__ qpos,
                                                                     const int* __restrict__ kpos,
                                                                     float* __restrict__ part, int N, int H, int D,
-                                                                    int B, int nb, HeadRange hr) {
+                                                                    int B, int nb, HeadRange hr, PushArgs pa) {
+    if (pa.push_wgs > 0 && (int)blockIdx.x < pa.push_wgs) {   // see block_attn_kernel
+        reduce_push_body<false>(pa, (int)blockIdx.x);
+        return;
+    }
     constexpr int NT = 64 * NKT;
     constexpr int KEYS = 32 * NKT;
     constexpr int PROW = 64;                    // bytes of one 32-column bf16 plane row
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     char* v_s = smem + 3 * CK * PROW;   // VP planes [CK][32 bf16], read transposed
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
-    const int bid = blockIdx.x;
+    const int bid = (int)blockIdx.x - pa.push_wgs;
     const int h = hr.h0 + bid % hr.hg;
     const int rest = bid / hr.hg;
     const int b = rest % nb, t = rest / nb;
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
 
 template <bool FULL, int VP>
 int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, const float* kvhat, const int* qpos,
-                      const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr) {
+                      const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
 #define HEPT_SPLIT_CASE(K)                                                                                       \
     case K: {                                                                                                    \
         constexpr size_t lds = (size_t)(3 + VP) * (K >= 2 ? 64 : 32) * 64;                                       \
@@ -428,7 +440,7 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
                 return HEPT_ERR_LAUNCH;                                                                          \
         }                                                                                                        \
         hipLaunchKernelGGL((block_attn_split_kernel<K, FULL, VP>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,   \
-                           kpos, part, N, H, D, B, nb, hr);                                                        \
+                           kpos, part, N, H, D, B, nb, hr, pa);                                                        \
         break;                                                                                                   \
     }
     switch (nkt) {
@@ -449,7 +461,7 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
 
 template <bool BF16, bool P16, bool F16QK, bool FULL>
 int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
-                const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr) {
+                const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
 #define HEPT_ATTN_CASE(K)                                                                                    \
     case K: {                                                                                                \
         constexpr size_t lds = (size_t)2 * 32 * K * 32 * (BF16 ? 2 : 4) + 32 * K * 8;                        \
@@ -459,7 +471,7 @@ int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const
                 return HEPT_ERR_LAUNCH;                                                                      \
         }                                                                                                    \
         hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16, F16QK, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
-                           kpos, part, N, H, D, B, nb, hr);                                                    \
+                           kpos, part, N, H, D, B, nb, hr, pa);                                                    \
         break;                                                                                               \
     }
     switch (nkt) {
@@ -480,17 +492,18 @@ int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const
 
 template <bool BF16, bool P16, bool F16QK>
 int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
-                const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr) {
+                const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
     if (B == 32 * nkt)
-        return launch_attn_full<BF16, P16, F16QK, true>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr);
-    return launch_attn_full<BF16, P16, F16QK, false>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr);
+        return launch_attn_full<BF16, P16, F16QK, true>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr, pa);
+    return launch_attn_full<BF16, P16, F16QK, false>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr, pa);
 }
 
 }  // namespace
 
 namespace {
 int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N, int H, int D,
-                    int Tl, int B, int precision, const HeadRange& hr, float* part, void* stream) {
+                    int Tl, int B, int precision, const HeadRange& hr, float* part, void* stream,
+                    const PushArgs* push = nullptr) {
     if (!qhat || !kvhat || !qpos || !kpos || !part) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
         return HEPT_ERR_SHAPE;
@@ -499,30 +512,45 @@ int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, co
         return HEPT_ERR_SHAPE;
 
     const int nb = N / B, nkt = (B + 31) / 32;
-    const dim3 grid((unsigned)((size_t)Tl * nb * hr.hg));
+    PushArgs pa{};
+    if (push) {
+        pa = *push;
+        // the rows being sent must be in the format this launch's kernels write (the previous group's launch wrote them)
+        if (pa.push_wgs < 1) return HEPT_ERR_ARG;
+    }
+    const dim3 grid((unsigned)((size_t)Tl * nb * hr.hg + pa.push_wgs));
     hipStream_t st = (hipStream_t)stream;
     // bf16 tiles with D == 24 write packed 64-B partial rows (HEPT_PART_PACKED), everything else 128-B f32 rows
     const char* qh = (const char*)qhat;
     const char* kv = (const char*)kvhat;
     if (precision == HEPT_PREC_BF16 && D == 24)
-        return launch_attn<true, true, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
+        return launch_attn<true, true, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
     if (precision == HEPT_PREC_BF16)
-        return launch_attn<true, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
+        return launch_attn<true, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
     if (precision == HEPT_PREC_MIXED16 && D == 24)
-        return launch_attn<true, true, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
+        return launch_attn<true, true, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
     if (precision == HEPT_PREC_MIXED16)
-        return launch_attn<true, false, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
+        return launch_attn<true, false, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
     if (precision == HEPT_PREC_F32) {
         const float* qf = (const float*)qhat;
         const float* kf = (const float*)kvhat;
-        if (B == 32 * nkt) return launch_attn_split<true, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr);
-        return launch_attn_split<false, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr);
+        if (B == 32 * nkt) return launch_attn_split<true, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr, pa);
+        return launch_attn_split<false, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr, pa);
     }
     if (precision == HEPT_PREC_F32_MFMA)
-        return launch_attn<false, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr);
+        return launch_attn<false, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
     return HEPT_ERR_SHAPE;
 }
 }  // namespace
+
+// internal: hept_block_attn_heads whose launch also carries the one-sided push of another head group (comm.h)
+int hept_block_attn_heads_push(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
+                               int H, int D, int Tl, int B, int precision, int h0, int hg, int hout, int hsub,
+                               int n_rows_out, float* part, const PushArgs* push, void* stream) {
+    if (n_rows_out < N) return HEPT_ERR_SHAPE;
+    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout};
+    return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, hr, part, stream, push);
+}
 
 extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
                                int H, int D, int Tl, int B, int precision, float* part, void* stream) {

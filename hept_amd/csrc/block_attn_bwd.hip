@@ -548,16 +548,12 @@ __global__ __launch_bounds__(256) void dsw_kernel(const float* __restrict__ dcs,
     if (w == 0) partial[(size_t)blockIdx.x * 64 + lane] = lane < HC ? red_s[0][lane] + red_s[1][lane] + red_s[2][lane] + red_s[3][lane] : 0.f;
 }
 
-__global__ __launch_bounds__(64) void dsw_sum_kernel(const float* __restrict__ partial, int n_wgs, int HC,
-                                                     float* __restrict__ d_sqrt_w) {
-    const int lane = threadIdx.x;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};   // four interleaved chains (fixed association), folded at the end
-    for (int g = 0; g < n_wgs; g += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (g + u < n_wgs) a[u] += partial[(size_t)(g + u) * 64 + lane];
-    }
-    if (lane < HC) d_sqrt_w[lane] = (a[0] + a[1]) + (a[2] + a[3]);
+__global__ __launch_bounds__(256) void dsw_sum_kernel(const float* __restrict__ partial, int n_wgs, int HC,
+                                                      float* __restrict__ d_sqrt_w) {
+    __shared__ float red_s[HEPT_FSUM_SLICES * HEPT_FSUM_OUT];
+    const int o = blockIdx.x * HEPT_FSUM_OUT + threadIdx.x % HEPT_FSUM_OUT;
+    const float tot = hept_fixed_sum(partial, n_wgs, 64, o, o < 64, red_s);
+    if (threadIdx.x < HEPT_FSUM_OUT && o < HC) d_sqrt_w[o] = tot;
 }
 
 template <bool FULL>
@@ -670,7 +666,7 @@ extern "C" int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int 
         float* partial = const_cast<float*>(dq_part);
         const int n_wgs = (N + DSW_POINTS - 1) / DSW_POINTS;
         hipLaunchKernelGGL(dsw_kernel, dim3((unsigned)n_wgs), dim3(256), 0, st, dcs, coords, N, H, C, partial);
-        hipLaunchKernelGGL(dsw_sum_kernel, dim3(1), dim3(64), 0, st, partial, n_wgs, H * C, d_sqrt_w);
+        hipLaunchKernelGGL(dsw_sum_kernel, dim3(64 / HEPT_FSUM_OUT), dim3(256), 0, st, partial, n_wgs, H * C, d_sqrt_w);
     }
     return hept_launch_status();
 }

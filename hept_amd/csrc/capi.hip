@@ -2,6 +2,7 @@
 // Replaces HEPTAttention.forward, reference example/hept.py:43-81.
 #include "common.h"
 #include "comm.h"
+#include "p2p_dev.h"
 
 namespace {
 
@@ -359,16 +360,42 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
     if (one_sided) ++comm->epoch;
     rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
     if (rc) return rc;
-    // Caller's stream: the block attention of the head groups back to back.  Side stream: for every group but the
-    // last, wait for its attention, sum the local tables into the send buffer and put it on the links.  The last
-    // group has nothing left to hide behind: its table sum and transfer run on the caller's stream (a cross-stream
-    // hand-over costs ~15 us each way), which then joins the side stream and combines.
     const int pprec = hept_part_precision(precision, D);
     const bool direct = Tl == 1 && !one_sided;   // one local table: block_attn scatters straight into the send buffer
     const int32_t* qpos = w.pos;
     const int32_t* kpos = w.pos + (size_t)Tl * H * N;
     const bool rec = g_prof.mode == 1;
-    for (int g = 0; g < head_groups; ++g) {
+    if (one_sided) {
+        // ONE stream, no events: the launch that computes head group g also carries, as its first workgroups, the
+        // table sum + one-sided push of group g - 1 (link-bound work beside gather-bound work); the last group's
+        // push has nothing left to ride on and runs alone.
+        constexpr int PUSH_WGS = 256;   // one per CU: enough to keep the seven links busy (multiple of 8: XCD map)
+        for (int g = 0; g < head_groups; ++g) {
+            PushArgs pa;
+            const bool carry = g > 0;
+            if (carry) {
+                rc = hept_p2p_push_args(comm, w.part, pprec, Tl, N, H, D, (g - 1) * hg, hg, g - 1, aprec, lay, PUSH_WGS,
+                                        &pa);
+                if (rc) return rc;
+            }
+            if (rec) prof_mark(2, st);
+            rc = hept_block_attn_heads_push(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, g * hg, hg, H, 0, N,
+                                            w.part, carry ? &pa : nullptr, stream);
+            if (rec) {
+                prof_mark(3, st);
+                prof_call_done();
+            }
+            if (rc) return rc;
+        }
+        rc = hept_p2p_reduce_push(comm, w.part, pprec, Tl, N, H, D, (head_groups - 1) * hg, hg, head_groups - 1, aprec,
+                                  lay, st);
+        if (rc) return rc;
+    }
+    // RCCL transport.  Caller's stream: the block attention of the head groups back to back.  Side stream: for every
+    // group but the last, wait for its attention, sum the local tables into the send buffer and put it on the links.
+    // The last group has nothing left to hide behind: its table sum and transfer run on the caller's stream (a
+    // cross-stream hand-over costs ~15 us each way), which then joins the side stream and combines.
+    for (int g = 0; !one_sided && g < head_groups; ++g) {
         const bool last = g == head_groups - 1;
         float* dst = reinterpret_cast<float*>(send + g * group_bytes);
         if (rec) prof_mark(2, st);
@@ -392,12 +419,6 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
         if (!last && (hipEventRecord(comm->fork[g], st) != hipSuccess ||
                       hipStreamWaitEvent(comm->side, comm->fork[g], 0) != hipSuccess))
             return HEPT_ERR_LAUNCH;
-        if (one_sided) {
-            // the table sum stores every row straight into the receive buffer of the rank that finishes its point
-            rc = hept_p2p_reduce_push(comm, w.part, pprec, Tl, N, H, D, g * hg, hg, g, aprec, lay, xs);
-            if (rc) return rc;
-            continue;
-        }
         if (!direct) {
             rc = hept_reduce_heads(w.part, pprec, Tl, N, H, D, g * hg, hg, n_pad, dst, aprec, xs);
             if (rc) return rc;
@@ -405,7 +426,7 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
         rc = hept_comm_all_to_all(comm, dst, recv + g * group_bytes, (size_t)per * hg * row, xs);
         if (rc) return rc;
     }
-    if (head_groups > 1 &&
+    if (!one_sided && head_groups > 1 &&
         (hipEventRecord(comm->join, comm->side) != hipSuccess || hipStreamWaitEvent(st, comm->join, 0) != hipSuccess))
         return HEPT_ERR_LAUNCH;
     // this rank's points [rank * per, ...): the `world` received slices are the "tables" of the combine

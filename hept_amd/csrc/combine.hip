@@ -563,24 +563,21 @@ __global__ __launch_bounds__(192 * CBW_GROUPS) void combine_bwd_weight_kernel(co
     }
 }
 
-// d_weight[c][col] = sum over workgroups of partial[wg][c][col], d_bias[col] likewise from row CB_D: one thread per
-// output, workgroups added in index order (four interleaved chains)
+// d_weight[c][col] = sum over workgroups of partial[wg][c][col], d_bias[col] likewise from row CB_D: workgroups added
+// in a fixed order (hept_fixed_sum)
 __global__ __launch_bounds__(256) void combine_bwd_weight_sum_kernel(const float* __restrict__ partial, int n_wgs, int HD,
                                                                      float* __restrict__ d_weight,
                                                                      float* __restrict__ d_bias) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (CB_D + 1) * 192) return;
+    __shared__ float red_s[HEPT_FSUM_SLICES * HEPT_FSUM_OUT];
+    constexpr int TOTAL = (CB_D + 1) * 192;
+    const int i = blockIdx.x * HEPT_FSUM_OUT + threadIdx.x % HEPT_FSUM_OUT;
     const int c = i / 192, col = i - c * 192;
-    if (col >= HD) return;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < n_wgs; g += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (g + u < n_wgs) a[u] += partial[(size_t)(g + u) * (CB_D + 1) * 192 + i];
+    const bool valid = i < TOTAL && col < HD;
+    const float tot = hept_fixed_sum(partial, n_wgs, TOTAL, i, valid, red_s);
+    if (threadIdx.x < HEPT_FSUM_OUT && valid) {
+        if (c < CB_D) d_weight[(size_t)c * HD + col] = tot;
+        else if (col < CB_D && d_bias) d_bias[col] = tot;
     }
-    const float tot = (a[0] + a[1]) + (a[2] + a[3]);
-    if (c < CB_D) d_weight[(size_t)c * HD + col] = tot;
-    else if (col < CB_D && d_bias) d_bias[col] = tot;
 }
 
 }  // namespace
@@ -749,7 +746,7 @@ extern "C" int hept_combine_bwd(const float* acc, const float* g_out, const floa
     const int n_wgs = (N + CBW_POINTS - 1) / CBW_POINTS;
     float* partial = static_cast<float*>(scratch);
     hipLaunchKernelGGL(combine_bwd_weight_kernel, dim3(n_wgs), dim3(192 * CBW_GROUPS), 0, st, acc, g_out, N, H, partial);
-    hipLaunchKernelGGL(combine_bwd_weight_sum_kernel, dim3(((CB_D + 1) * 192 + 255) / 256), dim3(256), 0, st, partial, n_wgs,
-                       H * D, d_weight, d_bias);
+    hipLaunchKernelGGL(combine_bwd_weight_sum_kernel, dim3((CB_D + 1) * 192 / HEPT_FSUM_OUT), dim3(256), 0, st, partial,
+                       n_wgs, H * D, d_weight, d_bias);
     return hept_launch_status();
 }

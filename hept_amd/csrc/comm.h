@@ -45,6 +45,13 @@ P2pLayout hept_p2p_layout(int N, int H, int D, int world, int precision);
 // sum over the local tables of heads [h0, h0 + hg) -> rows stored into the owners' receive buffers, then flags
 int hept_p2p_reduce_push(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0,
                          int hg, int g, int acc_precision, const P2pLayout& lay, hipStream_t st);
+// the same work described as kernel arguments, for a block-attention launch that carries it as extra workgroups
+struct PushArgs;
+int hept_p2p_push_args(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0, int hg,
+                       int g, int acc_precision, const P2pLayout& lay, int push_wgs, PushArgs* out);
+int hept_block_attn_heads_push(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
+                               int H, int D, int Tl, int B, int precision, int h0, int hg, int hout, int hsub,
+                               int n_rows_out, float* part, const PushArgs* push, void* stream);   // block_attn.hip
 int hept_p2p_wait_rows(hept_comm* c, int head_groups, hipStream_t st);
 // this rank's finished (cnt, D) rows (already in its slice of the local output region) -> every other rank, then flags
 int hept_p2p_push_out(hept_comm* c, int per, int D, const P2pLayout& lay, hipStream_t st);

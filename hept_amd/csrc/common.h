@@ -41,6 +41,25 @@ static inline int hept_raise_lds(LdsRaised& flags, const void* fn, size_t bytes)
     return HEPT_OK;
 }
 
+// Deterministic second stage of a two-stage reduction: out[o] = sum_g partial[g * pitch + o] with a FIXED association
+// (slice s of 16 takes g = s, s + 16, ... in ascending order, the 16 slice sums are added in ascending order), so the
+// result does not depend on how the first stage's workgroups were scheduled.  256 threads = 16 outputs x 16 slices.
+#define HEPT_FSUM_OUT 16
+#define HEPT_FSUM_SLICES 16
+__device__ __forceinline__ float hept_fixed_sum(const float* __restrict__ partial, int n_parts, size_t pitch, int o,
+                                               bool valid, float* red_s /* [SLICES][OUT] */) {
+    const int ol = threadIdx.x % HEPT_FSUM_OUT, sl = threadIdx.x / HEPT_FSUM_OUT;
+    float acc = 0.f;
+    if (valid)
+        for (int g = sl; g < n_parts; g += HEPT_FSUM_SLICES) acc += partial[(size_t)g * pitch + o];
+    red_s[sl * HEPT_FSUM_OUT + ol] = acc;
+    __syncthreads();
+    float tot = 0.f;
+    if (sl == 0)
+        for (int s2 = 0; s2 < HEPT_FSUM_SLICES; ++s2) tot += red_s[s2 * HEPT_FSUM_OUT + ol];
+    return tot;
+}
+
 // float -> bf16, round to nearest even, on the hardware converter (v_cvt_pk_bf16_f32)
 typedef __attribute__((ext_vector_type(2))) float hept_f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 hept_bf16x2;

@@ -20,74 +20,9 @@
 
 namespace {
 
-// Rows of heads [h0, h0 + hg) summed over the local tables; the row of point n goes to rank s = n / per, slot
-// recv[g][me][n - s * per][h - h0].  One lane per 16-B piece of an output row (4 pieces per packed 64-B row, 8 per
-// f32 row), consecutive lanes = consecutive pieces: a store instruction covers whole 64-B lines, which is what both
-// uncached local memory and the xGMI links want (half-filled lines doubled the time of this kernel).  Same arithmetic
-// and row formats as reduce_heads_kernel: packed rows are widened to f32, summed in table order and rounded back.
 template <bool P16>
-__global__ __launch_bounds__(256) void reduce_push_kernel(const float* __restrict__ part, int Tl, int N, int H, int h0,
-                                                          int hg, int per, int world, int me, char* const* peers,
-                                                          size_t recv_off, size_t group_off, unsigned int epoch,
-                                                          unsigned int* counter, int flag_idx) {
-    constexpr int PIECES = P16 ? 4 : 8;        // 16-B pieces per row
-    constexpr int ROWB = PIECES * 16;
-    const unsigned int total = (unsigned int)N * hg * PIECES;   // < 2^31 (N * H * 8 pieces)
-    const size_t tstride = (size_t)N * H * ROWB;  // bytes between tables
-    const char* pbytes = reinterpret_cast<const char*>(part);
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const unsigned int orow = i / PIECES;
-        const int pc = (int)(i - orow * PIECES);
-        const int n = (int)(orow / (unsigned int)hg);
-        const int hl = (int)(orow - (unsigned int)n * hg);
-        const char* src = pbytes + ((size_t)n * H + h0 + hl) * ROWB + pc * 16;
-        u32x4 v = *reinterpret_cast<const u32x4*>(src);
-        if (Tl > 1) {
-            u32x4 x[2];
-            const int tpre = Tl - 1 < 2 ? Tl - 1 : 2;   // the usual three tables: all loads in flight at once
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                if (t < tpre) x[t] = *reinterpret_cast<const u32x4*>(src + (size_t)(t + 1) * tstride);
-            if (P16 && pc < 3) {  // 8 bf16 numerators
-                float s[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { s[2 * j] = hept_bf16_lo(v[j]); s[2 * j + 1] = hept_bf16_hi(v[j]); }
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    if (t < tpre) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { s[2 * j] += hept_bf16_lo(x[t][j]); s[2 * j + 1] += hept_bf16_hi(x[t][j]); }
-                    }
-                for (int t = 3; t < Tl; ++t) {
-                    const u32x4 y = *reinterpret_cast<const u32x4*>(src + (size_t)t * tstride);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { s[2 * j] += hept_bf16_lo(y[j]); s[2 * j + 1] += hept_bf16_hi(y[j]); }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = hept_pack_bf16(s[2 * j], s[2 * j + 1]);
-            } else {              // f32 words (a packed row's last piece: [denominator, 0, 0, 0])
-                float s[4] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    if (t < tpre) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(x[t][j]);
-                    }
-                for (int t = 3; t < Tl; ++t) {
-                    const u32x4 y = *reinterpret_cast<const u32x4*>(src + (size_t)t * tstride);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(y[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(s[j]);
-                if (P16) v[1] = v[2] = v[3] = 0u;
-            }
-        }
-        const int dest = n / per;
-        char* row = peers[dest] + recv_off + group_off + (((size_t)me * per + (n - dest * per)) * hg + hl) * ROWB;
-        store16_system(row + pc * 16, v);
-    }
-    signal_when_all_done(counter, peers, world, flag_idx, epoch);
+__global__ __launch_bounds__(256) void reduce_push_kernel(PushArgs a) {
+    reduce_push_body<P16>(a, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void wait_rows_kernel(char* local, int head_groups, int world, unsigned int epoch,
@@ -262,26 +197,40 @@ extern "C" int hept_comm_status(hept_comm* c, int* status) {
     return HEPT_OK;
 }
 
-int hept_p2p_reduce_push(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0,
-                         int hg, int g, int acc_precision, const P2pLayout& lay, hipStream_t st) {
-    if (!c || !c->p2p_open || !part) return HEPT_ERR_ARG;
-    if (acc_precision != HEPT_PREC_F32 && !(acc_precision == HEPT_PREC_BF16 && part_precision == HEPT_PREC_BF16))
-        return HEPT_ERR_SHAPE;
+int hept_p2p_push_args(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0, int hg,
+                       int g, int acc_precision, const P2pLayout& lay, int push_wgs, PushArgs* out) {
+    if (!c || !c->p2p_open || !part || !out) return HEPT_ERR_ARG;
+    if (acc_precision != part_precision) return HEPT_ERR_SHAPE;  // the exchange keeps the row format of block_attn
     if (part_precision == HEPT_PREC_BF16 && D != 24) return HEPT_ERR_SHAPE;
     const int per = (N + c->world - 1) / c->world;
     const size_t row = acc_precision == HEPT_PREC_BF16 ? 64 : 128;
-    const size_t group_off = (size_t)g * per * c->world * hg * row;
-    if (acc_precision != part_precision) return HEPT_ERR_SHAPE;  // the exchange keeps the row format of block_attn
+    PushArgs a;
+    a.part = part;
+    a.Tl = Tl; a.N = N; a.H = H; a.h0 = h0; a.hg = hg;
+    a.per = per; a.world = c->world; a.me = c->rank;
+    a.peers = c->d_peer;
+    a.recv_off = lay.recv_off;
+    a.group_off = (size_t)g * per * c->world * hg * row;
+    a.epoch = c->epoch;
+    a.counter = c->d_state + g;
+    a.flag_idx = g * HEPT_MAX_RANKS + c->rank;
+    a.push_wgs = push_wgs;
+    *out = a;
+    return HEPT_OK;
+}
+
+int hept_p2p_reduce_push(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0,
+                         int hg, int g, int acc_precision, const P2pLayout& lay, hipStream_t st) {
+    const size_t row = acc_precision == HEPT_PREC_BF16 ? 64 : 128;
     const size_t blocks = ((size_t)N * hg * (row / 16) + 255) / 256;
-    const dim3 grid((unsigned)(blocks < 4096 ? blocks : 4096)), block(256);
-    unsigned int* counter = c->d_state + g;
-    const int flag_idx = g * HEPT_MAX_RANKS + c->rank;
+    PushArgs a;
+    int rc = hept_p2p_push_args(c, part, part_precision, Tl, N, H, D, h0, hg, g, acc_precision, lay,
+                                (int)(blocks < 4096 ? blocks : 4096), &a);
+    if (rc) return rc;
     if (part_precision == HEPT_PREC_BF16)
-        hipLaunchKernelGGL((reduce_push_kernel<true>), grid, block, 0, st, part, Tl, N, H, h0, hg, per, c->world, c->rank,
-                           c->d_peer, lay.recv_off, group_off, c->epoch, counter, flag_idx);
+        hipLaunchKernelGGL((reduce_push_kernel<true>), dim3(a.push_wgs), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((reduce_push_kernel<false>), grid, block, 0, st, part, Tl, N, H, h0, hg, per, c->world, c->rank,
-                           c->d_peer, lay.recv_off, group_off, c->epoch, counter, flag_idx);
+        hipLaunchKernelGGL((reduce_push_kernel<false>), dim3(a.push_wgs), dim3(256), 0, st, a);
     return hept_launch_status();
 }
 

@@ -18,6 +18,22 @@ struct P2pDev {
     size_t slice_off;            // bytes from a buffer's start to this rank's slice of the gathered output
 };
 
+// One head group's table sum + one-sided push (p2p.hip: reduce_push_kernel), as a body that can also ride in the
+// block-attention launch of the NEXT head group (block_attn.hip): the pushing workgroups mostly wait on the xGMI links,
+// the attention workgroups on HBM gathers -- one launch overlaps the two on one stream, with no second stream and no
+// event between them (a cross-stream hand-over costs ~7 us of bubble on the forking stream and ~15 us to the other).
+struct PushArgs {
+    const float* part;        // (Tl, N, H, row) per-table partial rows
+    int Tl, N, H, h0, hg;     // heads [h0, h0 + hg) are summed and sent
+    int per, world, me;
+    char* const* peers;
+    size_t recv_off, group_off;
+    unsigned int epoch;
+    unsigned int* counter;
+    int flag_idx;
+    int push_wgs;             // workgroups of the launch that push (the first ones of the grid); 0: none
+};
+
 namespace {
 
 constexpr int OUT_FLAG_WORD = HEPT_P2P_OUT_FLAG_WORD;
@@ -61,11 +77,12 @@ __device__ __forceinline__ bool wait_flag(const unsigned int* flag, unsigned int
 // flags.  (A system-scope fence in every thread was the first build: thousands of L2 write-backs per launch while the
 // block attention keeps the L2 dirty -- 153 us for a kernel that moves 12 us of data.)
 __device__ __forceinline__ void signal_when_all_done(unsigned int* counter, char* const* peers, int world, int flag_idx,
-                                                     unsigned int epoch) {
+                                                     unsigned int epoch, unsigned int n_workgroups = 0) {
+    if (n_workgroups == 0) n_workgroups = gridDim.x;   // every workgroup of the launch takes part
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == gridDim.x - 1) {
+        if (prev == n_workgroups - 1) {
             __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();
             for (int s = 0; s < world; ++s)
@@ -74,5 +91,73 @@ __device__ __forceinline__ void signal_when_all_done(unsigned int* counter, char
     }
 }
 
+
+// Rows of heads [h0, h0 + hg) summed over the local tables; the row of point n goes to rank s = n / per, slot
+// recv[g][me][n - s * per][h - h0].  One lane per 16-B piece of an output row (4 pieces per packed 64-B row, 8 per
+// f32 row), consecutive lanes = consecutive pieces: a store instruction covers whole 64-B lines, which is what both
+// uncached local memory and the xGMI links want.  Same arithmetic and row formats as reduce_heads_kernel: packed rows
+// are widened to f32, summed in table order and rounded back.
+template <bool P16>
+__device__ __forceinline__ void reduce_push_body(const PushArgs& a, int wg_index) {
+    constexpr int PIECES = P16 ? 4 : 8;        // 16-B pieces per row
+    constexpr int ROWB = PIECES * 16;
+    const unsigned int total = (unsigned int)a.N * a.hg * PIECES;   // < 2^31 (N * H * 8 pieces)
+    const size_t tstride = (size_t)a.N * a.H * ROWB;  // bytes between tables
+    const char* pbytes = reinterpret_cast<const char*>(a.part);
+    const int Tl = a.Tl;
+    for (unsigned int i = wg_index * blockDim.x + threadIdx.x; i < total; i += a.push_wgs * blockDim.x) {
+        const unsigned int orow = i / PIECES;
+        const int pc = (int)(i - orow * PIECES);
+        const int n = (int)(orow / (unsigned int)a.hg);
+        const int hl = (int)(orow - (unsigned int)n * a.hg);
+        const char* src = pbytes + ((size_t)n * a.H + a.h0 + hl) * ROWB + pc * 16;
+        u32x4 v = *reinterpret_cast<const u32x4*>(src);
+        if (Tl > 1) {
+            u32x4 x[2];
+            const int tpre = Tl - 1 < 2 ? Tl - 1 : 2;   // the usual three tables: all loads in flight at once
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (t < tpre) x[t] = *reinterpret_cast<const u32x4*>(src + (size_t)(t + 1) * tstride);
+            if (P16 && pc < 3) {  // 8 bf16 numerators
+                float s[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[2 * j] = hept_bf16_lo(v[j]); s[2 * j + 1] = hept_bf16_hi(v[j]); }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (t < tpre) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s[2 * j] += hept_bf16_lo(x[t][j]); s[2 * j + 1] += hept_bf16_hi(x[t][j]); }
+                    }
+                for (int t = 3; t < Tl; ++t) {
+                    const u32x4 y = *reinterpret_cast<const u32x4*>(src + (size_t)t * tstride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s[2 * j] += hept_bf16_lo(y[j]); s[2 * j + 1] += hept_bf16_hi(y[j]); }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = hept_pack_bf16(s[2 * j], s[2 * j + 1]);
+            } else {              // f32 words (a packed row's last piece: [denominator, 0, 0, 0])
+                float s[4] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (t < tpre) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(x[t][j]);
+                    }
+                for (int t = 3; t < Tl; ++t) {
+                    const u32x4 y = *reinterpret_cast<const u32x4*>(src + (size_t)t * tstride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(y[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(s[j]);
+                if (P16) v[1] = v[2] = v[3] = 0u;
+            }
+        }
+        const int dest = n / a.per;
+        char* row = a.peers[dest] + a.recv_off + a.group_off + (((size_t)a.me * a.per + (n - dest * a.per)) * a.hg + hl) * ROWB;
+        store16_system(row + pc * 16, v);
+    }
+    signal_when_all_done(a.counter, a.peers, a.world, a.flag_idx, a.epoch, (unsigned int)a.push_wgs);
+}
 
 }  // namespace

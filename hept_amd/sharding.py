@@ -56,8 +56,11 @@ class TableSharding:
     def __init__(self, n_tables: int, group=None, mode: Optional[str] = None, always_exchange: bool = False,
                  head_groups: Optional[int] = None):
         self.group = group
-        # head groups of the pipelined all-to-all (2: the second half of the block attention hides the first transfer)
-        self.head_groups = int(os.environ.get("HEPT_HEAD_GROUPS", "2")) if head_groups is None else int(head_groups)
+        # head groups of the pipelined all-to-all; None = by transport (one-sided stores: 4 -- a group's push rides in
+        # the next group's attention launch at no extra cost, and the last, exposed push is a quarter of the rows;
+        # collectives: 2 -- every further group is another collective launch and cross-stream hand-over)
+        env = os.environ.get("HEPT_HEAD_GROUPS")
+        self.head_groups = int(head_groups) if head_groups is not None else (int(env) if env else None)
         self._bufs = {}
         self._comm = None
         # hept_comm* of the native exchange (hept_forward_sharded: RCCL called from the C library, no Python between
@@ -85,7 +88,7 @@ class TableSharding:
             via = "torch.distributed"
             if self._native:
                 via = "RCCL from the C library" if (self._p2p_failed or self.exchange == "rccl") else "one-sided xGMI stores"
-            return f"all_to_all pipelined in {self.head_groups} head group(s) + all_gather ({via})"
+            return f"all_to_all pipelined in {self.head_groups or 'auto'} head group(s) + all_gather ({via})"
         return self.mode
 
     def _agree(self, ok: bool, device: torch.device) -> bool:
@@ -191,7 +194,7 @@ class TableSharding:
             return True
         return False
 
-    def tune(self, step: Callable[[], object], device: torch.device, head_groups=(1, 2, 4), steps: int = 10):
+    def tune(self, step: Callable[[], object], device: torch.device, head_groups=(1, 2, 4, 8), steps: int = 10):
         """Pick the fastest (transport, head groups) for this machine: time ``step`` (one sharded forward) under every
         candidate the communicator supports and keep the best.  Collective: all ranks time the same candidates, the
         slowest rank's time counts, a candidate that fails or times out on any rank is dropped.  Returns the table
@@ -273,7 +276,10 @@ class TableSharding:
 
     def groups_for(self, n_heads: int) -> int:
         """Head groups actually used for ``n_heads`` heads (equal groups only)."""
-        g = max(1, min(self.head_groups, n_heads))
+        want = self.head_groups
+        if want is None:
+            want = 4 if (self._native and self.exchange == "p2p" and not self._p2p_failed) else 2
+        g = max(1, min(want, n_heads))
         while n_heads % g != 0:
             g -= 1
         return g

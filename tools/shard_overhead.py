@@ -25,7 +25,7 @@ w_rpe = torch.nn.Linear(50, 192).to(dev)
 with torch.no_grad():
     w_rpe.weight.copy_(g["w_rpe_weight"])
 kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
-for mode in (None, "all_to_all/1/p2p", "all_to_all/2/p2p", "all_to_all/4/p2p", "all_to_all/1/rccl", "all_to_all/2/rccl",
+for mode in (None, "all_to_all/1/p2p", "all_to_all/2/p2p", "all_to_all/4/p2p", "all_to_all/8/p2p", "all_to_all/1/rccl", "all_to_all/2/rccl",
              "all_to_all/2/torch", "reduce_scatter", "all_reduce"):
     mode, _, rest = (mode or "").partition("/")
     groups, _, via = rest.partition("/")

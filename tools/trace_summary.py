@@ -5,7 +5,7 @@ import glob
 import sys
 
 root = sys.argv[1]
-first = sys.argv[2] if len(sys.argv) > 2 else "rpe_scale"
+first = sys.argv[2] if len(sys.argv) > 2 else "prep_hash"
 rows = []
 for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
