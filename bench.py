@@ -288,7 +288,9 @@ def worker(args) -> int:
         Returns (elapsed s, mean block_attn ms per step, event samples)."""
         for _ in range(warmup):
             step()
-        stride = max(1, min(16, steps // 32)) if steps >= 64 else max(1, steps // 8)
+        # 4 ... 32 bracketed steps: an event pair is a barrier packet on either side of the kernel (~7 us of bubble
+        # each on this stack), so a 20-step region keeps 16 of its steps bare
+        stride = max(1, steps // max(4, min(32, steps // 5)))
         ops.profile_enable(1, steps * launches, stride=stride * launches + (1 if launches > 1 else 0))
         fence()
         t0 = time.perf_counter()

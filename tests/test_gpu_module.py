@@ -155,3 +155,19 @@ def test_forward_is_hip_graph_capturable(gpu_device):
         graph.replay()
         torch.cuda.synchronize()
         torch.testing.assert_close(out, m(g["q"], g["k"], g["v"], **kw), rtol=0, atol=0)
+
+
+def test_module_on_a_device_that_is_not_current(gpu_device):
+    """The C ABI launches on the thread's current HIP device; the front end makes the tensors' device current for the
+    call.  Needs two visible GPUs (the driver's 8-GPU box); on a 1-GPU box the guard is exercised with the same device."""
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", 1 if n_dev > 1 else 0)
+    inp, fx = cases.load_case("g4_pileup")   # block 256 with f32 tiles: a kernel that needs the > 64 KiB LDS attribute
+    m, w_rpe = _module(inp, dev)
+    g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+    torch.cuda.set_device(0)
+    with torch.no_grad():
+        out = m(g["q"], g["k"], g["v"], w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+    assert out.device == dev and torch.cuda.current_device() == 0
+    ref = torch.from_numpy(fx["out"])
+    assert ((out.cpu() - ref).abs() <= 1e-5 + 1e-4 * ref.abs()).all(-1).float().mean() >= 0.98
