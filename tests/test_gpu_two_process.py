@@ -110,6 +110,11 @@ def test_sharded_training_matches_single_process(gpu_device):
             assert err < 2e-5, (r, key, err)
 
 
+# HEPT_TEST_BIG=<points>: the 8-rank test at a larger size (slow on a shared GPU: every rank polls its flags
+# from time slice to time slice; a one-off check, not part of the default suite's sizes)
+_SIZES = [int(os.environ["HEPT_TEST_BIG"])] if os.environ.get("HEPT_TEST_BIG") else [1500, 700]
+
+
 def _synthetic_worker(rank, world, port, precision, exchange, ret):
     """BASELINE config 4 in miniature: n_hashes = world, one table per rank, the production exchange."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -122,7 +127,7 @@ def _synthetic_worker(rank, world, port, precision, exchange, ret):
         from hept_amd.synthetic import make_inputs
 
         dev = torch.device("cuda", 0)
-        inp = make_inputs([1500, 700], block_size=128, n_hashes=world, seed=5, cluster_size=8)
+        inp = make_inputs(_SIZES, block_size=128, n_hashes=world, seed=5, cluster_size=8)
         g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
         m = HEPTAttention(30, h_dim=24, num_heads=8, block_size=128, n_hashes=world, num_w_per_dist=10,
                           precision=precision, process_group=dist.group.WORLD)
@@ -158,7 +163,7 @@ def test_eight_ranks_one_table_each_match_the_unsharded_operator(precision, gpu_
     from hept_amd import ops
     from hept_amd.synthetic import make_inputs
 
-    inp = make_inputs([1500, 700], block_size=128, n_hashes=world, seed=5, cluster_size=8)
+    inp = make_inputs(_SIZES, block_size=128, n_hashes=world, seed=5, cluster_size=8)
     g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
     plain = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
                         g["out_weight"], g["out_bias"], block_size=128, w_per_dist=10, precision=precision).cpu()
