@@ -204,29 +204,47 @@ __global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
 constexpr int EMBED_SHIFT = 20;
 constexpr unsigned int EMBED_INDEX_MASK = (1u << EMBED_SHIFT) - 1u;
 static_assert(TOP_SHIFT + EMBED_SHIFT <= 32, "low id bits + index fit the low word of a pair");
+// SCT threads per workgroup (the chunk stays 4096 keys): the launch is a single round of workgroups (720 at
+// tracking-60k on 1024 resident slots), so its length is one workgroup's dependent chain; 512 threads halve the
+// per-thread item loops of that chain and double the waves that hide its latencies.  The RADIX digit counters are
+// owned by the first RADIX threads.
+#ifndef HEPT_SCATTER_THREADS
+#define HEPT_SCATTER_THREADS 512
+#endif
+constexpr int SCT = HEPT_SCATTER_THREADS;
+constexpr int SCT_ITEMS = SORT_CHUNK / SCT;
+static_assert(SCT >= RADIX && SCT % RADIX == 0 && SORT_CHUNK % SCT == 0, "digit ownership / items per thread");
 template <bool EMBED>
-__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned int* __restrict__ keys0,
-                                                               const SegParams* __restrict__ seg_params,
-                                                               const unsigned int* __restrict__ hist, int N,
-                                                               int n_chunks, unsigned int* __restrict__ bstart,
-                                                               unsigned long long* __restrict__ dst_pairs,
-                                                               const int* __restrict__ seg_len) {
+__global__ __launch_bounds__(SCT) void scatter_kernel(const unsigned int* __restrict__ keys0,
+                                                      const SegParams* __restrict__ seg_params,
+                                                      const unsigned int* __restrict__ hist, int N, int n_chunks,
+                                                      unsigned int* __restrict__ bstart,
+                                                      unsigned long long* __restrict__ dst_pairs,
+                                                      const int* __restrict__ seg_len) {
     __shared__ unsigned long long stage_s[SORT_CHUNK];   // the chunk, digit-sorted (32 KiB)
     __shared__ unsigned int cnt_s[RADIX];                // keys of the chunk per digit
     __shared__ unsigned int start_s[RADIX];              // first local position of a digit
     __shared__ unsigned int goff_s[RADIX];               // global offset of the digit's first key of this chunk
-    __shared__ unsigned int wsum_s[SORT_WAVES];
+    __shared__ unsigned int wsum_s[RADIX / HEPT_WAVE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool digit = tid < RADIX;                      // this thread owns digit `tid`
     const int seg = blockIdx.y, chunk = blockIdx.x;
     const SegParams rg = seg_params[seg];
     const size_t seg_off = (size_t)seg * N;        // N = segment stride; len = keys that take part (ragged argsort)
     const int len = seg_len ? seg_len[seg] : N;
-    cnt_s[tid] = 0;
+    if (digit) cnt_s[tid] = 0;
+    unsigned int key[SCT_ITEMS];
+    const int base = chunk * SORT_CHUNK;
+#pragma unroll
+    for (int r = 0; r < SCT_ITEMS; ++r) {
+        const int n = base + r * SCT + tid;
+        key[r] = n < len ? keys0[seg_off + n] : 0u;
+    }
     // global offset of digit `tid` for this chunk = (keys of the segment with a smaller digit) + (same digit in
     // earlier chunks): every workgroup reduces the segment's chunk histograms itself (a few KiB from L2) instead
     // of waiting for a separate scan kernel
     unsigned int own = 0, tot = 0;
-    {
+    if (digit) {
         const unsigned int* hseg = hist + (size_t)seg * n_chunks * RADIX + tid;
         for (int c0 = 0; c0 < n_chunks; c0 += 8) {
             unsigned int x[8];
@@ -239,13 +257,6 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
             }
         }
     }
-    unsigned int key[SORT_ITEMS];
-    const int base = chunk * SORT_CHUNK;
-#pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int n = base + r * SORT_THREADS + tid;
-        key[r] = n < len ? keys0[seg_off + n] : 0u;
-    }
     {
         unsigned int incl = tot;
 #pragma unroll
@@ -253,21 +264,23 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
             const unsigned int y = __shfl_up(incl, off);
             if (lane >= off) incl += y;
         }
-        if (lane == 63) wsum_s[w] = incl;
+        if (digit && lane == 63) wsum_s[w] = incl;
         __syncthreads();
-        unsigned int excl = incl - tot;
+        if (digit) {
+            unsigned int excl = incl - tot;
 #pragma unroll
-        for (int ww = 0; ww < SORT_WAVES; ++ww)
-            if (ww < w) excl += wsum_s[ww];
-        goff_s[tid] = excl + own;
-        if (chunk == 0) bstart[(size_t)seg * RADIX + tid] = excl;
+            for (int ww = 0; ww < RADIX / HEPT_WAVE; ++ww)
+                if (ww < w) excl += wsum_s[ww];
+            goff_s[tid] = excl + own;
+            if (chunk == 0) bstart[(size_t)seg * RADIX + tid] = excl;
+        }
     }
     __syncthreads();
-    unsigned short rank[SORT_ITEMS], lowid[SORT_ITEMS];
-    unsigned char dig[SORT_ITEMS];
+    unsigned short rank[SCT_ITEMS], lowid[SCT_ITEMS];
+    unsigned char dig[SCT_ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int n = base + r * SORT_THREADS + tid;
+    for (int r = 0; r < SCT_ITEMS; ++r) {
+        const int n = base + r * SCT + tid;
         const unsigned int id = bucket_id(key[r], rg.kmin, rg.scale);
         const unsigned int dg = id >> TOP_SHIFT;
         lowid[r] = (unsigned short)(id & (unsigned int)(LOBINS - 1));
@@ -276,24 +289,26 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
     }
     __syncthreads();
     // digit `tid`: exclusive prefix over the digits -> first local position of the digit
-    const unsigned int total = cnt_s[tid];
+    const unsigned int total = digit ? cnt_s[tid] : 0u;
     unsigned int incl = total;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned int y = __shfl_up(incl, off);
         if (lane >= off) incl += y;
     }
-    if (lane == 63) wsum_s[w] = incl;
+    if (digit && lane == 63) wsum_s[w] = incl;
     __syncthreads();
-    unsigned int first = incl - total;
+    if (digit) {
+        unsigned int first = incl - total;
 #pragma unroll
-    for (int ww = 0; ww < SORT_WAVES; ++ww)
-        if (ww < w) first += wsum_s[ww];
-    start_s[tid] = first;
+        for (int ww = 0; ww < RADIX / HEPT_WAVE; ++ww)
+            if (ww < w) first += wsum_s[ww];
+        start_s[tid] = first;
+    }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int n = base + r * SORT_THREADS + tid;
+    for (int r = 0; r < SCT_ITEMS; ++r) {
+        const int n = base + r * SCT + tid;
         if (n < len)
             stage_s[start_s[dig[r]] + rank[r]] = ((unsigned long long)key[r] << 32) |
                                                  (EMBED ? ((unsigned int)lowid[r] << EMBED_SHIFT) | (unsigned int)n : (unsigned int)n);
@@ -302,8 +317,8 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const unsigned in
     // write out: consecutive local positions of one digit are consecutive global positions
     const int n_valid = min(SORT_CHUNK, len - base);
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const int lp = r * SORT_THREADS + tid;
+    for (int r = 0; r < SCT_ITEMS; ++r) {
+        const int lp = r * SCT + tid;
         if (lp < n_valid) {
             const unsigned long long p = stage_s[lp];
             const unsigned int dg = bucket_id((unsigned int)(p >> 32), rg.kmin, rg.scale) >> TOP_SHIFT;
@@ -799,7 +814,7 @@ constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segme
 template <bool EMBED>
 void run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const int* seg_len) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
-    const dim3 grid(n_chunks, segs), block(SORT_THREADS);
+    const dim3 grid(n_chunks, segs), block(SCT);
     hipLaunchKernelGGL(scatter_kernel<EMBED>, grid, block, 0, st, b.keys0, b.params, b.hist, N, n_chunks, b.bstart, b.pa,
                        seg_len);
     const dim3 grid4(NTOP, segs);
