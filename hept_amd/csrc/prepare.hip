@@ -102,10 +102,22 @@ __global__ __launch_bounds__(64) void row_bits_kernel(const int* __restrict__ cl
     }
 }
 
-__global__ __launch_bounds__(PT) void code_keys_kernel(const int64_t* __restrict__ codes_row0, int n_raw,
+// Sort key of the table-0 / head-0 codes.  A bare float(code) would hand the sort ~150 distinct values for 60 000
+// points: tie groups of 400, which its in-group ranking pays for quadratically (60 us for this one segment).  The
+// stable order wanted is (code, index), so the key carries the leading index bits below the code,
+//     key = code << k | index >> s,      k = 24 - bits(code),  s = bits(index) - k   (both >= 0),
+// exact in fp32 (< 2^24), monotone in (code, index): equal keys are now runs of at most 2^s consecutive indices and
+// the final order is unchanged.
+__global__ __launch_bounds__(PT) void code_keys_kernel(const int64_t* __restrict__ codes_row0, int n_raw, int n_clouds,
+                                                       const int* __restrict__ row_max, int rows,
                                                        float* __restrict__ keys) {
     const int n = blockIdx.x * PT + threadIdx.x;
-    if (n < n_raw) keys[n] = (float)codes_row0[n];  // codes < 2^24 (checked by the caller): exact
+    if (n >= n_raw) return;
+    const int code_bits = bit_length(n_clouds - 1) + bit_length(row_max[rows]);   // codes < 2^24 (checked by the caller)
+    const int k = code_bits < 24 ? 24 - code_bits : 0;
+    const int idx_bits = bit_length(n_raw - 1);
+    const int sh = idx_bits > k ? idx_bits - k : 0;
+    keys[n] = (float)((codes_row0[n] << k) | (int64_t)(n >> sh));
 }
 
 // one thread per padded slot: gather index, un-pad mask, padded coords; blockIdx.y > 0: padded codes of one row
@@ -275,7 +287,8 @@ extern "C" int hept_prepare_input(const float* coords, int C, const int32_t* clo
     hipLaunchKernelGGL(row_bits_kernel, dim3(rows), dim3(64), 0, st, cloud_start, n_clouds, regions, T, H, row_max);
     hipLaunchKernelGGL(codes_kernel, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
                        codes_raw);
-    hipLaunchKernelGGL(code_keys_kernel, dim3((n_raw + PT - 1) / PT), dim3(PT), 0, st, codes_raw, n_raw, ckeys);
+    hipLaunchKernelGGL(code_keys_kernel, dim3((n_raw + PT - 1) / PT), dim3(PT), 0, st, codes_raw, n_raw, n_clouds, row_max,
+                       rows, ckeys);
     rc = hept_segmented_argsort(ckeys, 1, n_raw, sort_ws, by_code, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(pad_gather_kernel, dim3((n_pad + PT - 1) / PT, rows + 1), dim3(PT), 0, st, cloud_start, pad_start,

@@ -105,6 +105,9 @@ def _rank_within_cloud(values: torch.Tensor, batch: torch.Tensor, raw_start: tor
     return rank - raw_start[batch]
 
 
+_REGION_BITS: Dict[str, object] = {}
+
+
 def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """``prepare_input`` on the GPU through the C ABI (``hept_prepare_input``, ``csrc/prepare.hip``).
 
@@ -121,25 +124,34 @@ def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Di
         raise ValueError("regions must have shape (n_hashes, 2, num_heads)")
     coords_c = coords.contiguous().float()
     n_raw, c_dim = coords_c.shape
-    sizes = torch.bincount(batch).cpu()
-    n_clouds = sizes.numel()
+    dev = coords.device
+    # Two host round trips, both needed to size the outputs: the last cloud id, then the cloud boundaries (`batch`
+    # is sorted, so they are a searchsorted; the device copy of the boundaries is the kernel's cloud_start as it is).
+    n_clouds = int(batch[-1]) + 1
+    edges = torch.searchsorted(batch.contiguous(), torch.arange(n_clouds + 1, device=dev, dtype=batch.dtype))
+    cloud_start = edges.to(torch.int32)
+    sizes = edges.cpu().diff()
     if int(sizes.min()) < 1:
         raise ValueError("every cloud id in [0, batch.max()] must own at least one point")
     padded = ((sizes + block_size - 1) // block_size) * block_size
     max_cloud, n_pad = int(sizes.max()), int(padded.sum())
-    # packed codes must stay below 2^24 (they are sorted as exact fp32 keys)
-    reg_hi = regions.amax(dim=(0, 2)).cpu()
-    bits = sum(int(torch.ceil(reg_hi[a]).item() + 1).bit_length() for a in (0, 1))
+    # packed codes must stay below 2^24 (they are sorted as exact fp32 keys); the region counts are constants of the
+    # model: their maxima are read back once per tensor version, not per call
+    src = helper_params["regions"]
+    key = (src.data_ptr(), src._version, tuple(src.shape), src.device)
+    if _REGION_BITS.get("key") != key:
+        reg_hi = src.float().amax(dim=(0, 2)).cpu()
+        _REGION_BITS["key"] = key
+        _REGION_BITS["bits"] = sum(int(torch.ceil(reg_hi[a]).item() + 1).bit_length() for a in (0, 1))
+    bits = _REGION_BITS["bits"]
     if (n_clouds << bits) >= (1 << 24):
         raise ValueError("AND codes would exceed 2^24: too many clouds x regions for the fp32-keyed pad sort")
-    zero = torch.zeros(1, dtype=torch.int64)
-    cloud_start = torch.cat([zero, sizes.cumsum(0)]).to(torch.int32).to(coords.device)
-    pad_start = torch.cat([zero, padded.cumsum(0)]).to(torch.int32).to(coords.device)
+    pad_start = torch.cat([torch.zeros(1, dtype=torch.int64), padded.cumsum(0)]).to(torch.int32).to(dev, non_blocking=True)
     dev = coords.device
     ws = torch.empty(int(lib.hept_prepare_workspace_bytes(n_raw, n_clouds, max_cloud, n_tables, num_heads)),
                      device=dev, dtype=torch.uint8)
     pad_seq = torch.empty(n_pad, device=dev, dtype=torch.int64)
-    unpad = torch.empty(n_pad, device=dev, dtype=torch.uint8)
+    unpad = torch.empty(n_pad, device=dev, dtype=torch.bool)   # one byte per slot, written as 0 / 1
     coords_pad = torch.empty(n_pad, c_dim, device=dev, dtype=torch.float32)
     codes_pad = torch.empty(n_tables, num_heads, n_pad, device=dev, dtype=torch.int64)
     _lib.check(lib.hept_prepare_input(coords_c.data_ptr(), c_dim, cloud_start.data_ptr(), pad_start.data_ptr(),
