@@ -155,7 +155,9 @@ __device__ __forceinline__ void reduce_push_body(const PushArgs& a, int wg_index
         }
         const int dest = n / a.per;
         char* row = a.peers[dest] + a.recv_off + a.group_off + (((size_t)a.me * a.per + (n - dest * a.per)) * a.hg + hl) * ROWB;
-        store16_system(row + pc * 16, v);
+        // own rows: the buffer is this rank's uncached memory (write-through as it is): one 16-B store
+        if (dest == a.me) *reinterpret_cast<u32x4*>(row + pc * 16) = v;
+        else store16_system(row + pc * 16, v);
     }
     signal_when_all_done(a.counter, a.peers, a.world, a.flag_idx, a.epoch, (unsigned int)a.push_wgs);
 }
