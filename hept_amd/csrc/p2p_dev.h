@@ -72,13 +72,17 @@ __device__ __forceinline__ bool wait_flag(const unsigned int* flag, unsigned int
 // The last workgroup of a kernel to get here raises `flag_idx` = epoch in every rank's buffer.
 // Ordering: every store into an exchange buffer is a system-scope store (store16_system): written through, and the
 // wave's vmcnt reaches zero only when it has been acknowledged.  __syncthreads() makes every wave of the workgroup wait
-// for exactly that (workgroup-scope release = s_waitcnt vmcnt(0), no cache maintenance); the workgroup then counts
-// itself in.  Only the single thread that sees the count complete pays for a system-scope fence before it writes the
+// wave's vmcnt reaches zero only when it has been acknowledged: every wave waits for that explicitly (s_waitcnt
+// vmcnt(0), no cache maintenance), the workgroup meets at a barrier and counts itself in.  Only the single thread that sees the count complete pays for a system-scope fence before it writes the
 // flags.  (A system-scope fence in every thread was the first build: thousands of L2 write-backs per launch while the
 // block attention keeps the L2 dirty -- 153 us for a kernel that moves 12 us of data.)
 __device__ __forceinline__ void signal_when_all_done(unsigned int* counter, char* const* peers, int world, int flag_idx,
                                                      unsigned int epoch, unsigned int n_workgroups = 0) {
     if (n_workgroups == 0) n_workgroups = gridDim.x;   // every workgroup of the launch takes part
+    // every wave waits for the acknowledgement of its own stores: vmcnt counts loads AND stores on gfx9, and the
+    // workgroup barrier below does not wait for it (its fence is workgroup scope: s_waitcnt lgkmcnt(0) only -- checked
+    // in the ISA), so without this line the flag could overtake stores that are still in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
