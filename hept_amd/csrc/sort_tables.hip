@@ -640,6 +640,22 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
     const int N = seg_len ? seg_len[seg] : N_stride;  // keys that take part (ragged argsort); N_stride = segment pitch
     for (int i = tid; i < SMALL_BINS + 1; i += SMALL_THREADS) cur_s[i] = 0;
 
+    // MODE 0: the hashes and codes of this thread's keys are requested first -- they do not depend on the key range,
+    // and the launch is one workgroup per segment: its length is this chain of dependent loads
+    float pj0[SMALL_ITEMS];
+    long long cd0[SMALL_ITEMS];
+    if (MODE == 0) {
+        const int th = seg % (Tl * H);
+        const float* pr = (seg >= Tl * H ? kproj : qproj) + (size_t)th * N_stride;
+        const int64_t* cr = codes + ((size_t)(t0 + th / H) * H + th % H) * N_stride;
+#pragma unroll
+        for (int u = 0; u < SMALL_ITEMS; ++u) {
+            const int n = u * SMALL_THREADS + tid;
+            pj0[u] = n < N ? pr[n] : 0.f;
+            cd0[u] = n < N ? cr[n] : 0;
+        }
+    }
+
     // ---- key range of the segment
     float lo = INFINITY, hi = -INFINITY, cmax = 0.f;
     const float* proj;
@@ -703,9 +719,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
         if (n < N) {
             float key;
             if (MODE == 0) {
-                float off = (float)codes[row_off + n] * span;   // two separately rounded ops, as in K1
+                float off = (float)cd0[u] * span;   // two separately rounded ops, as in K1
                 asm volatile("" : "+v"(off));
-                key = proj[n] + off;
+                key = pj0[u] + off;
             } else if (MODE == 1) {
                 float t1 = eta_idx[row_off + n] * span;
                 asm volatile("" : "+v"(t1));
