@@ -83,6 +83,7 @@ SIGNATURES = {
     "hept_comm_p2p_ready": (c_int, [_P, c_size_t]),
     "hept_comm_status": (c_int, [_P, _P]),
     "hept_comm_p2p_flags": (c_int, [_P, _P, _P]),
+    "hept_comm_reset_status": (c_int, [_P]),
     "hept_prepare_src_workspace_bytes": (c_size_t, [c_int]),
     "hept_prepare_input_src": (c_int, [_P, c_int, _P] + [c_int] * 3 + [_P, c_int, c_int, _P, c_size_t] + [_P] * 5),
     "hept_profile_enable": (c_int, [c_int, c_int]),

@@ -197,6 +197,14 @@ extern "C" int hept_comm_status(hept_comm* c, int* status) {
     return HEPT_OK;
 }
 
+// forget a recorded timeout (the caller has stopped using the one-sided transport, or wants to try again)
+extern "C" int hept_comm_reset_status(hept_comm* c) {
+    if (!c) return HEPT_ERR_ARG;
+    if (!c->d_state) return HEPT_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return HEPT_ERR_LAUNCH;
+    return hipMemset(c->d_state + 16, 0, sizeof(unsigned int)) == hipSuccess ? HEPT_OK : HEPT_ERR_LAUNCH;
+}
+
 int hept_p2p_push_args(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0, int hg,
                        int g, int acc_precision, const P2pLayout& lay, int push_wgs, PushArgs* out) {
     if (!c || !c->p2p_open || !part || !out) return HEPT_ERR_ARG;

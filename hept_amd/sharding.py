@@ -79,8 +79,8 @@ class TableSharding:
         self.mode = mode or ("all_to_all" if backend == "nccl" else "all_reduce")
         if self.mode not in ("all_to_all", "reduce_scatter", "all_reduce"):
             raise ValueError(f"unknown mode {self.mode}")
-        if self.mode == "all_to_all" and self.world > 8:
-            raise ValueError("all_to_all mode sums at most 8 received slices (one node)")
+        if self.mode == "all_to_all" and self.world > 16:
+            raise ValueError("all_to_all mode serves the ranks of one node (at most 16)")
         table_slice(n_tables, self.rank, self.world)  # validate
 
     def describe(self) -> str:
@@ -181,8 +181,8 @@ class TableSharding:
         from . import _lib
 
         lib = _lib.load()
-        if self._native and self.exchange != "rccl" and not self._p2p_failed and lib.hept_comm_has_rccl(self._native):
-            self.exchange = "rccl"
+        if self._native and self.exchange != "rccl" and lib.hept_comm_has_rccl(self._native):
+            self.exchange = "rccl"   # (also after a one-sided timeout: the communicator's RCCL half is intact)
             return True
         if self._native or self._native is None:
             if self._native:
@@ -234,6 +234,10 @@ class TableSharding:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 if t[1].item() == 0:
                     table[(tr, g)] = t[0].item()
+                elif tr == "p2p":
+                    self._p2p_failed = True   # on every rank (the flag was reduced): no further one-sided candidates
+                    lib.hept_comm_reset_status(self._native)
+                    break
         if table:
             self.exchange, self.head_groups = min(table, key=table.get)
         return table
@@ -252,6 +256,10 @@ class TableSharding:
                 epoch = ctypes.c_uint32(0)
                 _lib.load().hept_comm_p2p_flags(self._native, flags, ctypes.byref(epoch))
                 rows = [list(flags[g * 16:g * 16 + self.world]) for g in range(self.groups_for(8))]
+                # the transport is not used again by this object, and the recorded timeout is forgotten so that the
+                # transports further down the ladder are not blamed for it
+                self._p2p_failed = True
+                _lib.load().hept_comm_reset_status(self._native)
                 raise RuntimeError(f"hept_amd: one-sided exchange timed out waiting for a peer (status {st.value}; "
                                    f"rank {self.rank} epoch {epoch.value}, row flags {rows}, output flags "
                                    f"{list(flags[512:512 + self.world])})")

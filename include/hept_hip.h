@@ -240,6 +240,7 @@ int hept_comm_p2p_alloc(hept_comm* comm, size_t bytes, void* handle_out);
 int hept_comm_p2p_open(hept_comm* comm, const void* handles);
 int hept_comm_p2p_ready(const hept_comm* comm, size_t bytes);
 int hept_comm_status(hept_comm* comm, int* status);
+int hept_comm_reset_status(hept_comm* comm);   /* forget a recorded timeout (synchronises the device) */
 /* debugging aid: this rank's HEPT_P2P_FLAG_BYTES bytes of arrival flags ([head group][source rank] u32 at byte 0,
  * output flags [source rank] u32 at byte 2048; each holds the epoch of the last arrival) and its own epoch */
 #define HEPT_P2P_FLAG_BYTES 4096

@@ -66,6 +66,15 @@ def test_bench_launches_its_own_ranks(ranks, gpu_device):
     assert f"n_hashes={ranks}" in d["c4"]["workload"]
 
 
+def test_bench_walks_down_the_transport_ladder(gpu_device):
+    """A one-sided wait that times out (here: a 1-microsecond bound with two ranks sharing the GPU) must not hang or
+    poison the run: the status word reports it, every rank steps down to the next transport together, and the line
+    names the exchange that actually ran."""
+    d = _run("--gpus", "2", "--no-cpu-baseline", "--no-extra", HEPT_BENCH_BACKEND="gloo",
+             HEPT_BENCH_EXCHANGE="all_to_all", HEPT_P2P_TIMEOUT_S="0.000001")
+    assert d["n_gpus"] == 2 and "torch.distributed" in d["config"]["parallelism"]
+
+
 def test_bench_launcher_reports_a_failing_rank(gpu_device):
     env = dict(os.environ, HEPT_BENCH_BACKEND="gloo", HEPT_BENCH_FAIL_RANK="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
