@@ -140,11 +140,11 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         return part + (size_t)n * HG * ROWF + (size_t)g * gstride + (size_t)(head - g * HG) * ROWF;
     };
     const int tile_first = SPLIT ? blockIdx.x : blockIdx.x * CMB_WAVES + w;
-    RawRow<P16> pre[3];
+    RawRow<P16> cur[3], nxt[3];  // up to 3 tables in flight; more tables are loaded in place below
     if (tile_first < n_tiles && hp0 < HP) {
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-            if (t < tpre) pre[t].load(row_at(tile_first, hp0) + (size_t)t * tstride);
+            if (t < tpre) cur[t].load(row_at(tile_first, hp0) + (size_t)t * tstride);
     }
     if constexpr (FFN) {
         for (int i = tid; i < FFN_D * FFN_D; i += CMB_THREADS) {
@@ -170,17 +170,22 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        RawRow<P16> cur[3], nxt[3];  // up to 3 tables in flight; more tables are loaded in place below
+        if (tile != tile_first) {   // (the first tile's rows were requested before the weight staging)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (tile == tile_first) cur[t] = pre[t];
-            else if (t < tpre && hp0 < HP) cur[t].load(row_of(hp0) + (size_t)t * tstride);
+            for (int t = 0; t < 3; ++t)
+                if (t < tpre && hp0 < HP) cur[t].load(row_of(hp0) + (size_t)t * tstride);
         }
         for (int hp = hp0; hp < HP; hp += hstep) {
             const bool more = hp + hstep < HP;
+            // packed rows: the next head pair's rows are requested before the current pair is unpacked.  f32 rows are
+            // 21 x 16 B per head pair and lane: holding two sets put the kernel at 256 VGPRs + 120 AGPRs, ONE wave per
+            // SIMD and therefore two rounds of workgroups; there the current set is summed first and the next set is
+            // loaded into the same registers, still ahead of the 24 MFMAs (see below)
+            if constexpr (P16) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                if (more && t < tpre) nxt[t].load(row_of(hp + hstep) + (size_t)t * tstride);
+                for (int t = 0; t < 3; ++t)
+                    if (more && t < tpre) nxt[t].load(row_of(hp + hstep) + (size_t)t * tstride);
+            }
             // this head's weight column, requested before the rows are unpacked (LDS latency hides under the VALU work)
             float wv[28];
             {
@@ -201,12 +206,19 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                 extra.load(row_of(hp) + (size_t)t * tstride);
                 den += extra.add_to(s, D);
             }
+            if constexpr (!P16) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (more && t < tpre) cur[t].load(row_of(hp + hstep) + (size_t)t * tstride);
+            }
             const float inv = 1.0f / den;
 #pragma unroll
             for (int u = 0; u < 28; ++u)
                 if (u < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[u] * inv, wv[u], acc, 0, 0, 0);
+            if constexpr (P16) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) cur[t] = nxt[t];
+                for (int t = 0; t < 3; ++t) cur[t] = nxt[t];
+            }
         }
         if constexpr (SPLIT) {
             if (w != 0) {
