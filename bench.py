@@ -250,9 +250,13 @@ def worker(args) -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
+    host_inputs = []   # kept to the end: returning ~150 MB of host pages to the OS takes the CPU ~17 ms, which is
+                       # 17 ms of idle device right in front of the next timed region if it happens between two
+
     def build(tables_per_gpu, precision):
         n_tables = tables_per_gpu * world
         inp = workload_inputs(WORKLOAD, seed=0, n_hashes=n_tables)
+        host_inputs.append(inp)
         g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
         c = inp["coords"].shape[1]
         attn = HEPTAttention(D + c, h_dim=D, num_heads=H, block_size=B, n_hashes=n_tables, num_w_per_dist=10,
@@ -260,6 +264,7 @@ def worker(args) -> int:
         attn.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
                               "e2lsh.alpha": inp["alpha"]}, strict=True)
         attn = attn.to(dev).eval()
+        attn.reserve(inp["q"].shape[0], c, dev)   # workspace now, not inside the first warm-up step
         if args.force_dist and world == 1:
             attn.sharding.always_exchange = True
         if multi and os.environ.get("HEPT_BENCH_EXCHANGE"):
@@ -282,16 +287,26 @@ def worker(args) -> int:
             return sh.groups_for(H)
         return 1
 
+    NO_SAMPLES = 1 << 30   # a stride no run reaches: the pool stays allocated, nothing is bracketed
+    # (several ranks: up to HEPT_MAX_HEAD_GROUPS = 8 block_attn launches per step)
+    sub_cap = 200   # steps of a sub-record
+    ops.profile_enable(1, (max(args.steps, sub_cap) + 2) * (8 if multi else 1), stride=NO_SAMPLES)
+
     def measure(step, steps, warmup, launches=1):
         """W untimed steps, then exactly K steps between fences; HIP events around block_attn on the launch stream for
         a sample of the steps (an event pair costs stream time, so the stride keeps >= 90 % of the steps bare).
         Returns (elapsed s, mean block_attn ms per step, event samples)."""
+        # 4 ... 32 bracketed steps: an event pair is a barrier packet on either side of the kernel (~4 us of bubble
+        # on this stack, tools/event_cost.py), so a 20-step region keeps 16 of its steps bare.  The event pool is the
+        # process-wide one made at start-up: creating or destroying hundreds of events takes the host milliseconds,
+        # and a device left idle that long starts the next region below its steady clocks.
+        stride = max(1, steps // max(4, min(32, steps // 5)))
+        call_stride = stride * launches + (1 if launches > 1 else 0)
+        ops.profile_stride(call_stride)
         for _ in range(warmup):
             step()
-        # 4 ... 32 bracketed steps: an event pair is a barrier packet on either side of the kernel (~7 us of bubble
-        # each on this stack), so a 20-step region keeps 16 of its steps bare
-        stride = max(1, steps // max(4, min(32, steps // 5)))
-        ops.profile_enable(1, steps * launches, stride=stride * launches + (1 if launches > 1 else 0))
+        ops.profile_read()             # drops the warm-up samples
+        ops.profile_stride(call_stride)
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -299,7 +314,7 @@ def worker(args) -> int:
         fence()
         elapsed = time.perf_counter() - t0
         stage_ms, n_rec = ops.profile_read()
-        ops.profile_enable(0)
+        ops.profile_stride(NO_SAMPLES)
         if multi:
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -321,7 +336,6 @@ def worker(args) -> int:
                 "mfma_busy_frac": busy,
                 "algorithmic_tflops": flops / (attn_ms * 1e-3) / 1e12, "mfma_bf16_peak_tflops": MFMA_BF16_PEAK_TF}
 
-    # ---------------------------------------------------------------------------------------------- headline region
     tables_per_gpu = args.tables_per_gpu
     inp, attn, step = build(tables_per_gpu, args.precision)
     n, n_raw, C = inp["q"].shape[0], inp["n_raw"], inp["coords"].shape[1]
@@ -355,6 +369,45 @@ def worker(args) -> int:
 
     if multi:
         settle(attn, step)
+
+    # ------------------------------------------------------------------------------------------------- sub-records
+    def sub_records():
+        """The f32-tile record (N = 1) and BASELINE config 4 (one table per GPU) on the same workload"""
+        sub = {}
+        if not args.no_extra:
+            # one process: long enough (60 + 25 ms of device time) to leave the device in its steady state
+            sub_steps = sub_cap if not multi else max(20, min(args.steps, sub_cap))
+            sub_warm = max(3, min(args.warmup, 10))
+            if world == 1 and not args.force_dist and args.precision == "bf16":
+                # reference precision (f32 tiles) on the same workload, same process
+                _, attn32, step32 = build(tables_per_gpu, "fp32")
+                el, ams, nrec = measure(step32, sub_steps, sub_warm)
+                sub["fp32"] = {"ms_per_step": el / sub_steps * 1e3, "value": n_raw / (el / sub_steps), "unit": "points/s",
+                               "steps": sub_steps, "dtype": "f32", "roofline": roofline(n, C, tables_per_gpu, "fp32", ams, nrec)}
+                del attn32, step32
+            if tables_per_gpu != 1:
+                # BASELINE config 4: n_hashes = #GPUs, one table per GPU (at N = 1 a single table)
+                _, attn4, step4 = build(1, args.precision)
+                if multi:
+                    settle(attn4, step4)
+                el, ams, nrec = measure(step4, sub_steps, sub_warm, launches_per_step(attn4))
+                if multi:
+                    attn4.sharding.check()
+                sub["c4"] = {"workload": f"{WORKLOAD}, n_hashes={world} sharded 1 per GPU over {world} GPU(s)",
+                             "ms_per_step": el / sub_steps * 1e3, "value": world * n_raw / (el / sub_steps),
+                             "unit": "points/s (N_gpus * N_raw / step time, one table pass per point and GPU)",
+                             "steps": sub_steps, "block_attn_ms": ams}
+                del attn4, step4
+        return sub
+
+    # One process: the sub-records run BEFORE the headline region -- they are part of every default run anyway, and
+    # after them the device is in its steady state (clocks up, code objects and workspaces resident), which W = 5
+    # steps (1 ms) alone do not reach on a GPU that idled while the process started (tools/event_cost.py, DESIGN.md
+    # section 6).  Several ranks: settle() has already run hundreds of steps, and the headline module's exchange
+    # buffers are released before config 4 builds its own.
+    sub = sub_records() if not multi else {}
+
+    # ---------------------------------------------------------------------------------------------- headline region
     elapsed, attn_ms, n_rec = measure(step, args.steps, args.warmup, launches_per_step(attn))
     ms_per_step = elapsed / args.steps * 1e3
     if multi:
@@ -366,7 +419,7 @@ def worker(args) -> int:
             step()
         torch.cuda.synchronize()
         all_ms, cnt = ops.profile_read()
-        ops.profile_enable(0)
+        ops.profile_enable(1, (max(args.steps, sub_cap) + 2) * (8 if multi else 1), stride=NO_SAMPLES)
         print("stage ms/step:", {k: round(v / cnt, 4) for k, v in all_ms.items()}, file=sys.stderr)
 
     line = None
@@ -397,33 +450,10 @@ def worker(args) -> int:
             "roofline": roof,
         }
     del attn, step
-
-    # ------------------------------------------------------------------------------------------------- sub-records
-    if not args.no_extra:
-        sub_steps = max(20, min(args.steps, 200))
-        sub_warm = max(3, min(args.warmup, 10))
-        if world == 1 and not args.force_dist and args.precision == "bf16":
-            # reference precision (f32 tiles) on the same workload, same process
-            _, attn32, step32 = build(tables_per_gpu, "fp32")
-            el, ams, nrec = measure(step32, sub_steps, sub_warm)
-            line["fp32"] = {"ms_per_step": el / sub_steps * 1e3, "value": n_raw / (el / sub_steps), "unit": "points/s",
-                            "steps": sub_steps, "dtype": "f32", "roofline": roofline(n, C, tables_per_gpu, "fp32", ams, nrec)}
-            del attn32, step32
-        if tables_per_gpu != 1:
-            # BASELINE config 4: n_hashes = #GPUs, one table per GPU (at N = 1 a single table)
-            _, attn4, step4 = build(1, args.precision)
-            if multi:
-                settle(attn4, step4)
-            el, ams, nrec = measure(step4, sub_steps, sub_warm, launches_per_step(attn4))
-            if multi:
-                attn4.sharding.check()
-            if rank == 0:
-                line["c4"] = {"workload": f"{WORKLOAD}, n_hashes={world} sharded 1 per GPU over {world} GPU(s)",
-                              "ms_per_step": el / sub_steps * 1e3, "value": world * n_raw / (el / sub_steps),
-                              "unit": "points/s (N_gpus * N_raw / step time, one table pass per point and GPU)",
-                              "steps": sub_steps,
-                              "block_attn_ms": ams}
-            del attn4, step4
+    if multi:
+        sub = sub_records()
+    if rank == 0:
+        line.update(sub)
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

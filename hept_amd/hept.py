@@ -94,6 +94,17 @@ class HEPTAttention(nn.Module):
             self._workspace = ws
         return ws
 
+    def reserve(self, n_points: int, n_coords: int, device) -> None:
+        """Allocate the inference workspace for clouds of up to ``n_points`` (padded) points now, so the first forward
+        does not pay for a device allocation (tens of milliseconds for the 60k-point workspace); optional -- forward()
+        grows the workspace on demand."""
+        tl = self.n_hashes if self.sharding is None else self.sharding.local_tables()[1]
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._scratch(ops.workspace_bytes(int(n_points), self.num_heads, self.dim_per_head, int(n_coords), tl,
+                                          self.block_size, self.precision), device)
+
     def _rpe_scale_cached(self, weight: torch.Tensor) -> torch.Tensor:
         """sqrt_w (H, C) of ``w_rpe.weight`` (reference ``example/hept.py:22-23,25``).  In inference the weight is
         constant, so its 400 exponentials are computed once and reused until the tensor changes (in-place updates bump

@@ -676,6 +676,11 @@ def profile_enable(mode: int, max_calls: int = 0, stride: int = 1) -> None:
     _lib.check(lib.hept_profile_stride(stride), "hept_profile_stride")
 
 
+def profile_stride(stride: int) -> None:
+    """Bracket every ``stride``-th call from the next call on (restarts the count)."""
+    _lib.check(_lib.load().hept_profile_stride(stride), "hept_profile_stride")
+
+
 def profile_read() -> Tuple[Dict[str, float], int]:
     """Summed milliseconds per stage over the recorded calls, and the number of calls; resets the pool."""
     import ctypes
