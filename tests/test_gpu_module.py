@@ -171,3 +171,23 @@ def test_module_on_a_device_that_is_not_current(gpu_device):
     assert out.device == dev and torch.cuda.current_device() == 0
     ref = torch.from_numpy(fx["out"])
     assert ((out.cpu() - ref).abs() <= 1e-5 + 1e-4 * ref.abs()).all(-1).float().mean() >= 0.98
+
+
+def test_reserve_sizes_the_workspace_before_the_first_call(gpu_device):
+    """reserve(): the first forward finds its workspace in place (no device allocation inside the call), and a smaller
+    cloud keeps using it; the values are those of a module that grew its workspace on demand"""
+    inp, _ = cases.load_case("g1_rand512")
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    m, w_rpe = _module(inp, gpu_device)
+    plain, _ = _module(inp, gpu_device)
+    assert m._workspace is None
+    m.reserve(4 * inp["q"].shape[0], g["coords"].shape[1], "cuda")
+    ptr, size = m._workspace.data_ptr(), m._workspace.numel()
+    assert m._workspace.device == g["q"].device
+    kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+    with torch.no_grad():
+        out = m(g["q"], g["k"], g["v"], **kw)
+        ref = plain(g["q"], g["k"], g["v"], **kw)
+    assert (m._workspace.data_ptr(), m._workspace.numel()) == (ptr, size)
+    assert plain._workspace.numel() < size
+    assert torch.equal(out, ref)
