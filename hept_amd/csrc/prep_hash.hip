@@ -23,9 +23,9 @@ constexpr int PREP_THREADS = 256;
 // 8 chunks + one pad slot per head
 constexpr int PREP_WAVE_SLOTS = 64 * 8 + 8;
 constexpr int PREP_POINTS = 8;   // points per wave iteration; lane = (point = lane >> 3, head = lane & 7)
-// LDS pitch (floats) of one head's alpha slab [e][HEPT_MAX_TABLES]: = 4 (mod 32), so that the 8 heads of a wave read
+// LDS pitch (floats) of one head's alpha slab [e][TMAX] (TMAX = 4 or 8 table slots, template parameter): = 4 (mod 32), so that the 8 heads of a wave read
 // 8 disjoint bank groups (a plain E * 8 pitch put them on two groups: 4-way conflicts, 60 % of the LDS cycles)
-constexpr int alpha_pitch(int E) { return ((E * HEPT_MAX_TABLES + 27) / 32) * 32 + 4; }
+constexpr int alpha_pitch(int E, int TMAX) { return ((E * TMAX + 27) / 32) * 32 + 4; }
 
 // sqrt_w[h][c] = sqrt(2 * sum_k exp(min(sum_d w[h*D+d][r*K+k], 50))), column 0 duplicated (eta, phi share dR).
 // One thread per (h, r, k) term (coalesced over k), then a K-term sum per (h, r).
@@ -103,7 +103,7 @@ struct FusedIn {
 };
 constexpr int FUSED_WPITCH = 24 * 24 + 4;  // head pitch = 4 (mod 32) dwords: the 8 heads' 16-B reads hit 8 distinct bank groups
 
-template <int D, int C, int TILE, int ROLE, bool FUSED = false>
+template <int D, int C, int TILE, int ROLE, int TMAX, bool FUSED = false>
 __device__ __forceinline__ void prep_role(const float* __restrict__ x, const float* __restrict__ coords,
                                           const float* __restrict__ sw_s, const float* __restrict__ alpha_s,
                                           const int64_t* __restrict__ codes, int N, int raw_size, int t0, int Tl,
@@ -130,9 +130,9 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
         wslot[j] = (c / D4) * ROW4 + (c % D4);
     }
 
-    float mn[HEPT_MAX_TABLES], mx[HEPT_MAX_TABLES], cm[HEPT_MAX_TABLES];
+    float mn[TMAX], mx[TMAX], cm[TMAX];
 #pragma unroll
-    for (int t = 0; t < HEPT_MAX_TABLES; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; cm[t] = 0.f; }
+    for (int t = 0; t < TMAX; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; cm[t] = 0.f; }
 
     const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
     for (int tile_i = blockIdx.x * WAVES + w; tile_i < ntiles; tile_i += gridDim.x * WAVES) {
@@ -201,7 +201,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
             if (ROLE == 0 && codes) {
                 // largest AND code of this (table, head): bounds the sort-key range for sort_tables
 #pragma unroll
-                for (int t = 0; t < HEPT_MAX_TABLES; ++t)
+                for (int t = 0; t < TMAX; ++t)
                     if (t < Tl && live) cm[t] = fmaxf(cm[t], __ll2float_ru(codes[((size_t)(t0 + t) * H + h) * N + n]));
             }
 #pragma unroll
@@ -231,19 +231,39 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
             }
         } else {
 
-        // E2LSH projections from the unrounded fp32 row; ascending-e fma chain
+        // E2LSH projections from the unrounded fp32 row: one ascending-e fma chain per table.  The slab is [e][TMAX]:
+        // one 16-B LDS read brings alpha[e] of four tables, and the TMAX chains advance side by side (slots t >= Tl
+        // hold zeros and are not stored)
+        float acc[TMAX];
 #pragma unroll
-        for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
-            if (t < Tl) {
-                float acc = 0.f;
+        for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
+        // (the slab does not change between tiles: hide that from the compiler, or it keeps all 4 E words of it in
+        //  registers across the tile loop)
+        int al_off = h * alpha_pitch(E, TMAX);
+        asm volatile("" : "+v"(al_off));
+        const float* al_row = alpha_s + al_off;
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc = fmaf(a[e], alpha_s[h * alpha_pitch(E) + e * HEPT_MAX_TABLES + t], acc);
-                if (live) {
-                    proj[((size_t)t * H + h) * N + n] = is_pad ? INFINITY : acc;
-                    mn[t] = fminf(mn[t], acc);
-                    mx[t] = fmaxf(mx[t], acc);
-                }
+        for (int e = 0; e < E; ++e) {
+#pragma unroll
+            for (int g = 0; g < TMAX / 4; ++g) {
+                const f32x4 al = *reinterpret_cast<const f32x4*>(al_row + e * TMAX + 4 * g);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[4 * g + u] = fmaf(a[e], al[u], acc[4 * g + u]);
             }
+            // a few reads in flight are enough: pin the chains here, or all E reads are issued first and their
+            // 4 E destination registers stay live until the fmas that were sunk below them
+            if (e % (TMAX == 4 ? 6 : 3) == (TMAX == 4 ? 5 : 2)) {
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t) asm volatile("" : "+v"(acc[t]));
+            }
+        }
+        // (the range update is unconditional in t -- slots t >= Tl are never read -- so that the chains above stay one
+        //  straight-line block instead of being sunk into TMAX branches with every alpha word live)
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            mn[t] = fminf(mn[t], live ? acc[t] : INFINITY);
+            mx[t] = fmaxf(mx[t], live ? acc[t] : -INFINITY);
+            if (t < Tl && live) proj[((size_t)t * H + h) * N + n] = is_pad ? INFINITY : acc[t];
         }
         float ss = 0.f;
         if (BF16) {
@@ -286,7 +306,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
 
     // per-workgroup partial hash range: lane keeps one head (h = lane & 7); fold the 8 point-lanes, then the waves
 #pragma unroll
-    for (int t = 0; t < HEPT_MAX_TABLES; ++t) {
+    for (int t = 0; t < TMAX; ++t) {
         if (t < Tl) {
             float lo = mn[t], hi = mx[t], c = cm[t];
 #pragma unroll
@@ -296,7 +316,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
                 c = fmaxf(c, __shfl_xor(c, off));
             }
             if (p == 0) {
-                float* r = red_s + ((w * HEPT_MAX_TABLES + t) * H + h) * 4;
+                float* r = red_s + ((w * TMAX + t) * H + h) * 4;
                 r[0] = lo; r[1] = hi; r[2] = c;
             }
         }
@@ -307,7 +327,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
         float lo = INFINITY, hi = -INFINITY, c = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) {
-            const float* r = red_s + ((ww * HEPT_MAX_TABLES + t) * H + hh) * 4;
+            const float* r = red_s + ((ww * TMAX + t) * H + hh) * 4;
             lo = fminf(lo, r[0]);
             hi = fmaxf(hi, r[1]);
             c = fmaxf(c, r[2]);
@@ -319,7 +339,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
 
 constexpr int PREP_WGS_PER_ROLE = HEPT_PREP_GRID / 2;  // q and k roles fill the HEPT_PREP_GRID partial slots
 
-template <int D, int C, int TILE>
+template <int D, int C, int TILE, int TMAX>
 __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
@@ -327,33 +347,33 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
     constexpr int H = 8, E = D + C;
     static_assert(D % 4 == 0 && E <= 30 && D <= 28, "row packing needs D%4==0, E<=30");
-    __shared__ float alpha_s[H * alpha_pitch(E)];
+    __shared__ __attribute__((aligned(16))) float alpha_s[H * alpha_pitch(E, TMAX)];
     __shared__ float sw_s[H * C];
-    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * HEPT_MAX_TABLES * H * 4];
+    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * TMAX * H * 4];
     __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * PREP_WAVE_SLOTS];
     static_assert(64 * ((D / 4) | 1) <= PREP_WAVE_SLOTS, "input tile does not fit the wave buffer");
     const int role = blockIdx.y;
     if (role != 2) {
-        for (int i = threadIdx.x; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
-            const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
-            alpha_s[(he / E) * alpha_pitch(E) + (he % E) * HEPT_MAX_TABLES + t] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
+        for (int i = threadIdx.x; i < H * E * TMAX; i += PREP_THREADS) {
+            const int t = i % TMAX, he = i / TMAX;
+            alpha_s[(he / E) * alpha_pitch(E, TMAX) + (he % E) * TMAX + t] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
         }
         for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
         __syncthreads();
     }
     if (role == 0)
-        prep_role<D, C, TILE, 0>(q, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(qhat_), qproj,
+        prep_role<D, C, TILE, 0, TMAX>(q, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(qhat_), qproj,
                                  red_s, tile_s, minmax, blockIdx.x);
     else if (role == 1)
-        prep_role<D, C, TILE, 1>(k, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
+        prep_role<D, C, TILE, 1, TMAX>(k, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
                                  red_s, tile_s, minmax, PREP_WGS_PER_ROLE + blockIdx.x);
     else
-        prep_role<D, C, TILE, 2>(v, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
+        prep_role<D, C, TILE, 2, TMAX>(v, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
                                  red_s, tile_s, minmax, 0);
 }
 
 // Attn-block front end: LayerNorm + the three projections fused into the row builder (D = 24 only)
-template <int C, int TILE>
+template <int C, int TILE, int TMAX>
 __global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
@@ -361,9 +381,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
     const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
     void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
     constexpr int D = 24, H = 8, E = D + C;
-    __shared__ float alpha_s[H * alpha_pitch(E)];
+    __shared__ __attribute__((aligned(16))) float alpha_s[H * alpha_pitch(E, TMAX)];
     __shared__ float sw_s[H * C];
-    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * HEPT_MAX_TABLES * H * 4];
+    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * TMAX * H * 4];
     __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * PREP_WAVE_SLOTS];
     __shared__ __attribute__((aligned(16))) float w_s[H * FUSED_WPITCH];
     const int role = blockIdx.y;
@@ -373,22 +393,22 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
         w_s[(hd / D) * FUSED_WPITCH + j * D + hd % D] = wsrc[i];
     }
     if (role != 2) {
-        for (int i = threadIdx.x; i < H * E * HEPT_MAX_TABLES; i += PREP_THREADS) {
-            const int t = i % HEPT_MAX_TABLES, he = i / HEPT_MAX_TABLES;
-            alpha_s[(he / E) * alpha_pitch(E) + (he % E) * HEPT_MAX_TABLES + t] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
+        for (int i = threadIdx.x; i < H * E * TMAX; i += PREP_THREADS) {
+            const int t = i % TMAX, he = i / TMAX;
+            alpha_s[(he / E) * alpha_pitch(E, TMAX) + (he % E) * TMAX + t] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
         }
         for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
     }
     __syncthreads();
     const FusedIn fin{ln_w, ln_b, w_s, eps};
     if (role == 0)
-        prep_role<D, C, TILE, 0, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(qhat_),
+        prep_role<D, C, TILE, 0, TMAX, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(qhat_),
                                        qproj, red_s, tile_s, minmax, blockIdx.x, fin);
     else if (role == 1)
-        prep_role<D, C, TILE, 1, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
+        prep_role<D, C, TILE, 1, TMAX, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
                                        kproj, red_s, tile_s, minmax, PREP_WGS_PER_ROLE + blockIdx.x, fin);
     else
-        prep_role<D, C, TILE, 2, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
+        prep_role<D, C, TILE, 2, TMAX, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
                                        nullptr, red_s, tile_s, minmax, 0, fin);
 }
 
@@ -398,12 +418,19 @@ int launch_prep_fused(const float* x, const float* ln_w, const float* ln_b, floa
                       const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision, void* qhat,
                       void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
     const dim3 grid(PREP_WGS_PER_ROLE, 3);
-#define HEPT_FUSED_LAUNCH(TILE)                                                                                       \
-    hipLaunchKernelGGL((prep_fused_kernel<C, TILE>), grid, dim3(PREP_THREADS), 0, st, x, ln_w, ln_b, eps, wq, wk, wv, \
-                       coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
-    if (precision == HEPT_PREC_BF16) HEPT_FUSED_LAUNCH(HEPT_PREC_BF16);
-    else if (precision == HEPT_PREC_MIXED16) HEPT_FUSED_LAUNCH(HEPT_PREC_MIXED16);
-    else HEPT_FUSED_LAUNCH(HEPT_PREC_F32);
+    // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
+#define HEPT_FUSED_LAUNCH(TILE, TMAX)                                                                                  \
+    hipLaunchKernelGGL((prep_fused_kernel<C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, x, ln_w, ln_b, eps, wq, wk, \
+                       wv, coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
+#define HEPT_FUSED_TILE(TILE)                                                                                          \
+    do {                                                                                                               \
+        if (Tl <= 4) HEPT_FUSED_LAUNCH(TILE, 4);                                                                       \
+        else HEPT_FUSED_LAUNCH(TILE, HEPT_MAX_TABLES);                                                                 \
+    } while (0)
+    if (precision == HEPT_PREC_BF16) HEPT_FUSED_TILE(HEPT_PREC_BF16);
+    else if (precision == HEPT_PREC_MIXED16) HEPT_FUSED_TILE(HEPT_PREC_MIXED16);
+    else HEPT_FUSED_TILE(HEPT_PREC_F32);
+#undef HEPT_FUSED_TILE
 #undef HEPT_FUSED_LAUNCH
     return hept_launch_status();
 }
@@ -414,15 +441,20 @@ int launch_prep(const float* q, const float* k, const float* v, const float* coo
                 void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
     // q- and k-role workgroups each write one of the HEPT_PREP_GRID partial slots the sort kernel reduces
     const dim3 grid(PREP_WGS_PER_ROLE, 3);
-    if (precision == HEPT_PREC_BF16)
-        hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_BF16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords,
-                           sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
-    else if (precision == HEPT_PREC_MIXED16)
-        hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_MIXED16>), grid, dim3(PREP_THREADS), 0, st, q, k, v,
-                           coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
-    else
-        hipLaunchKernelGGL((prep_hash_kernel<D, C, HEPT_PREC_F32>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords,
-                           sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+    // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
+#define HEPT_PREP_LAUNCH(TILE, TMAX)                                                                                 \
+    hipLaunchKernelGGL((prep_hash_kernel<D, C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w, \
+                       alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
+#define HEPT_PREP_TILE(TILE)                                                                                         \
+    do {                                                                                                             \
+        if (Tl <= 4) HEPT_PREP_LAUNCH(TILE, 4);                                                                      \
+        else HEPT_PREP_LAUNCH(TILE, HEPT_MAX_TABLES);                                                                \
+    } while (0)
+    if (precision == HEPT_PREC_BF16) HEPT_PREP_TILE(HEPT_PREC_BF16);
+    else if (precision == HEPT_PREC_MIXED16) HEPT_PREP_TILE(HEPT_PREC_MIXED16);
+    else HEPT_PREP_TILE(HEPT_PREC_F32);
+#undef HEPT_PREP_TILE
+#undef HEPT_PREP_LAUNCH
     return hept_launch_status();
 }
 
