@@ -32,6 +32,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP IPC between the ranks of a node (RCCL's and the one-sided exchange's) needs the dmabuf mode on this stack; set
+# before anything initialises the GPU, also when a launcher started this process as a rank
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WORKLOAD = "tracking-60k"
 TABLES_PER_GPU = 3
