@@ -36,10 +36,10 @@ namespace {
 
 // Register budget: a workgroup lives ~10 us, most of it waiting for its gathered rows, so throughput is set by how
 // many workgroups a CU holds.  16-bit tiles: 8 waves per SIMD (<= 64 VGPRs, no spills; 87 -> 80 us at tracking-60k);
-// f32 tiles carry twice the fragments: 6 waves per SIMD; the ragged-tile variants keep their masks in registers
-// and get a looser target (no spills anywhere).
+// f32 tiles carry twice the fragments: 6 waves per SIMD, 4 for their ragged-tile variants (masks in registers).  The
+// ragged 16-bit variants fit 64 VGPRs as well (B = 100, the reference's yaml: 97 -> see DESIGN.md section 6).
 template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL>
-__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(FULL ? (BF16 ? 8 : 6) : (BF16 ? 6 : 4), FULL ? (BF16 ? 8 : 6) : (BF16 ? 6 : 4))))
+__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(BF16 ? 8 : (FULL ? 6 : 4), BF16 ? 8 : (FULL ? 6 : 4))))
 void block_attn_kernel(const char* __restrict__ qhat,
                                                               const char* __restrict__ kvhat,
                                                               const int* __restrict__ qpos,
