@@ -122,7 +122,9 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
     constexpr int ROW4 = D4 | 1;                        // LDS pitch of an input row in 16-B slots (odd)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = lane & 7, p = lane >> 3;
-    f32x4* buf = tile_s + (size_t)w * PREP_WAVE_SLOTS;
+    // FUSED rows come from registers: only the output image (64 rows of CH chunks + one pad slot per head) is staged
+    constexpr int WSLOTS = FUSED ? 64 * CH + 8 : PREP_WAVE_SLOTS;
+    f32x4* buf = tile_s + (size_t)w * WSLOTS;
     int wslot[LOADS];  // chunk c of the tile belongs to row c / D4 (= the lane that reads it), slot c % D4
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
@@ -305,6 +307,9 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
     if (ROLE == 2) return;
 
     // per-workgroup partial hash range: lane keeps one head (h = lane & 7); fold the 8 point-lanes, then the waves
+    // (FUSED: red_s lives in the wave buffers -- LDS is what limits that kernel's occupancy -- so every wave has to be
+    //  done with its tiles first)
+    if constexpr (FUSED) __syncthreads();
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
         if (t < Tl) {
@@ -373,8 +378,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
 }
 
 // Attn-block front end: LayerNorm + the three projections fused into the row builder (D = 24 only)
+// 16-bit rows, 4 table slots: 39.9 KB of LDS = 4 workgroups per CU, and the registers are held to that occupancy too
 template <int C, int TILE, int TMAX>
-__global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
+__global__ __launch_bounds__(PREP_THREADS)
+__attribute__((amdgpu_waves_per_eu((TILE != HEPT_PREC_F32 && TMAX == 4) ? 4 : 2, (TILE != HEPT_PREC_F32 && TMAX == 4) ? 4 : 3)))
+void prep_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
@@ -383,8 +391,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_fused_kernel(
     constexpr int D = 24, H = 8, E = D + C;
     __shared__ __attribute__((aligned(16))) float alpha_s[H * alpha_pitch(E, TMAX)];
     __shared__ float sw_s[H * C];
-    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * TMAX * H * 4];
-    __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * PREP_WAVE_SLOTS];
+    // wave buffers: the output image only (264 slots for 16-bit rows, 520 for f32 rows); red_s reuses them after the loop
+    constexpr int WSLOTS = 64 * (TILE != HEPT_PREC_F32 ? 4 : 8) + 8;
+    __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * WSLOTS];
+    float* red_s = reinterpret_cast<float*>(tile_s);
+    static_assert((PREP_THREADS / HEPT_WAVE) * TMAX * H * 4 * 4 <= (PREP_THREADS / HEPT_WAVE) * WSLOTS * 16, "red_s fits the wave buffers");
     __shared__ __attribute__((aligned(16))) float w_s[H * FUSED_WPITCH];
     const int role = blockIdx.y;
     const float* wsrc = role == 0 ? wq : (role == 1 ? wk : wv);
