@@ -1,14 +1,13 @@
-"""A/B of the two forms of the Attn block's front end (prep_fused): outputs bit-identical?  python tools/micro/fused_ab.py
-(run twice: HEPT_FUSED_ROLE_SPLIT=1 selects the first form; this script writes / compares gpurun_out/fused_ab_*.pt)"""
-import os, sys
+"""Fingerprints of the Attn block front end's outputs (prep_hash_fused) on three workloads / precisions: run before and
+after a change of the kernel, the lines must not change (the rows, hashes and reduced ranges are defined bit for bit).
+python tools/micro/fused_ab.py"""
+import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from hept_amd import ops
 from hept_amd.synthetic import workload_inputs
 dev = torch.device("cuda:0")
-tag = "old" if os.environ.get("HEPT_FUSED_ROLE_SPLIT") else "new"
-out = {}
-for wl, prec in (("tracking-60k", "bf16"), ("tracking-6k", "fp32"), ("pileup-8clouds", "mixed16")):
+for wl, prec in (("tracking-60k", "bf16"), ("tracking-6k", "fp32"), ("pileup-8clouds", "mixed16"), ("tracking-60k-t8", "bf16")):
     inp = workload_inputs(wl, seed=0)
     g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
     torch.manual_seed(1)
@@ -19,14 +18,9 @@ for wl, prec in (("tracking-60k", "bf16"), ("tracking-6k", "fp32"), ("pileup-8cl
     sw = ops.rpe_scale(g["w_rpe_weight"], 8, 24, 10)
     r = ops.prep_hash_fused(x, lw, lb, 1e-5, wq, wk, wv, g["coords"], sw, g["alpha"], g["combined_shifts"], precision=prec)
     mm = r["minmax"]
-    red = torch.stack([mm[..., 0].amin(-1), mm[..., 1].amax(-1), mm[..., 2].amax(-1)])   # the sort only sees the reduction
-    for k in ("qhat", "kvhat", "qproj", "kproj"):
-        out[f"{wl}/{prec}/{k}"] = r[k].view(torch.uint8 if r[k].dtype != torch.float32 else torch.float32).cpu()
-    out[f"{wl}/{prec}/range"] = red.cpu()
-os.makedirs("gpurun_out", exist_ok=True)
-torch.save(out, f"gpurun_out/fused_ab_{tag}.pt")
-other = f"gpurun_out/fused_ab_{'new' if tag == 'old' else 'old'}.pt"
-if os.path.exists(other):
-    o = torch.load(other)
-    bad = [k for k in out if not torch.equal(out[k].view(torch.uint8), o[k].view(torch.uint8))]
-    print("bit-identical" if not bad else f"DIFFER: {bad}")
+    r["range"] = torch.stack([mm[..., 0].amin(-1), mm[..., 1].amax(-1), mm[..., 2].amax(-1)])   # what the sort sees
+    fp = []
+    for k in ("qhat", "kvhat", "qproj", "kproj", "range"):
+        b = r[k].contiguous().view(torch.uint8).cpu().numpy().tobytes()
+        fp.append(f"{k}={hashlib.sha256(b).hexdigest()[:12]}")
+    print(f"{wl:16s} {prec:8s} " + " ".join(fp))
