@@ -82,3 +82,22 @@ def test_bench_launcher_reports_a_failing_rank(gpu_device):
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
                           "--no-cpu-baseline"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert run.returncode != 0 and not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_as_a_rank_under_torch_distributed_run(gpu_device):
+    """The driver's own multi-GPU command: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- bench.py finds WORLD_SIZE set and is a rank
+    (here 2 ranks share the GPU through a gloo group); exactly one JSON line, from rank 0."""
+    env = dict(os.environ, HEPT_BENCH_BACKEND="gloo", HEPT_BENCH_EXCHANGE="all_to_all", HEPT_EXCHANGE="torch")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29643", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, run.stdout
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5
+    assert "(6 total)" in d["config"]["workload"] and d["c4"]["ms_per_step"] > 0
