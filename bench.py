@@ -297,7 +297,7 @@ def worker(args) -> int:
 
     def measure(step, steps, warmup, launches=1):
         """W untimed steps, then exactly K steps between fences; HIP events around block_attn on the launch stream for
-        a sample of the steps (an event pair costs stream time, so the stride keeps >= 90 % of the steps bare).
+        a sample of the steps (an event pair costs stream time, so the stride keeps >= 80 % of the steps bare).
         Returns (elapsed s, mean block_attn ms per step, event samples)."""
         # 4 ... 32 bracketed steps: an event pair is a barrier packet on either side of the kernel (~4 us of bubble
         # on this stack, tools/event_cost.py), so a 20-step region keeps 16 of its steps bare.  The event pool is the
