@@ -15,7 +15,7 @@ process starts N children (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in t
 non-zero if any child failed.  Under ``torch.distributed.run`` (WORLD_SIZE set) it is a rank.
 
 Beside the headline the line carries: ``fp32`` (N = 1: the reference-precision run of the same
-workload, measured in the same process after the bf16 region), ``c4`` (BASELINE config 4: one table
+workload, measured in the same process before the headline region), ``c4`` (BASELINE config 4: one table
 per GPU, n_hashes = N), ``roofline`` (HBM bound, dominant kernel, HIP events on the launch stream)
 and ``cpu_baseline`` (N = 1).  See DESIGN.md §6 for every field.
 """
