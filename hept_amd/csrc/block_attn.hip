@@ -353,27 +353,37 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
         stage();
         if (ch + 1 < NCH) fetch(ch + 1);
         __syncthreads();
+        // Q^.K^ of BOTH tiles of the chunk first: the second tile's MFMA chain has no dependence on the first tile's exp /
+        // split VALU work, so the two can share the SIMD (one wave's instruction stream is in order: a P tile computed
+        // right behind its own logits leaves the matrix pipe idle for the whole exp / split stretch)
+        f32x16 xs[CK / 32];
 #pragma unroll
         for (int kl = 0; kl < CK / 32; ++kl) {
             const int kt = ch * (CK / 32) + kl;
             if (kt >= NKT) break;
             if (!FULL && kt * 32 >= B) break;  // uniform
-            f32x16 x;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = 0.f;
+            for (int r = 0; r < 16; ++r) xs[kl][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int off = kl * 32 * PROW + krow[s];
                 const u32x4 kh = *reinterpret_cast<const u32x4*>(k_s + off);
                 const u32x4 km = *reinterpret_cast<const u32x4*>(k_s + CK * PROW + off);
                 const u32x4 kl3 = *reinterpret_cast<const u32x4*>(k_s + 2 * CK * PROW + off);
-                x = mfma_bf16(kl3, qh[s], x);
-                x = mfma_bf16(kh, ql[s], x);
-                x = mfma_bf16(km, qm[s], x);
-                x = mfma_bf16(km, qh[s], x);
-                x = mfma_bf16(kh, qm[s], x);
-                x = mfma_bf16(kh, qh[s], x);
+                xs[kl] = mfma_bf16(kl3, qh[s], xs[kl]);
+                xs[kl] = mfma_bf16(kh, ql[s], xs[kl]);
+                xs[kl] = mfma_bf16(km, qm[s], xs[kl]);
+                xs[kl] = mfma_bf16(km, qh[s], xs[kl]);
+                xs[kl] = mfma_bf16(kh, qm[s], xs[kl]);
+                xs[kl] = mfma_bf16(kh, qh[s], xs[kl]);
             }
+        }
+#pragma unroll
+        for (int kl = 0; kl < CK / 32; ++kl) {
+            const int kt = ch * (CK / 32) + kl;
+            if (kt >= NKT) break;
+            if (!FULL && kt * 32 >= B) break;  // uniform
+            const f32x16 x = xs[kl];
 
             float pr[16];
 #pragma unroll
