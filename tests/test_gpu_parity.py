@@ -383,3 +383,27 @@ def test_bench_workloads_all_rows_vs_oracle(workload, precision, gpu_device):
         assert _rows_ok(out, orc, 1e-5, 1e-4) >= 0.995
     else:
         assert _rows_ok(out, orc, atol=5e-3, rtol=8e-3) >= 0.995
+
+
+def test_full_size_with_the_references_own_block_size(gpu_device):
+    """block_size = 100, the value of the reference's yaml (src/configs/tracking/tracking_trans_hept.yaml:12), at the
+    benchmark's 60 000 points: three full 32-row tiles and one with four rows per block (the ragged kernel variants).
+    fp32 tiles: with the GPU's own permutations injected the oracle reproduces EVERY row; 16-bit tiles: the every-row
+    bound of the 16-bit modes."""
+    from hept_amd.synthetic import make_inputs
+
+    inp = make_inputs([60000], block_size=100, n_hashes=3, seed=0)
+    inp["block_size"], inp["w_per_dist"] = 100, 10
+    assert inp["q"].shape[0] == 60000
+    g = _gpu(inp, gpu_device)
+    st = _staged(g, inp, "fp32")
+    qp, kp = st["qpos"].long().cpu(), st["kpos"].long().cpu()
+    orc = _oracle(inp, q_positions=qp, k_positions=kp, keep=False)
+    out = st["out"].cpu()
+    assert _rows_ok(out, orc["out"], 1e-5, 1e-4) >= 0.999
+    torch.testing.assert_close(out, orc["out"], rtol=3e-2, atol=3e-5)
+    assert torch.equal(_forward(g, inp, "fp32").cpu(), out)          # the one-call operator = the staged kernels
+    for prec in ("bf16", "mixed16"):
+        s16 = _staged(g, inp, prec, qpos=st["qpos"], kpos=st["kpos"])["out"].cpu()
+        assert _rows_scaled_ok(s16, orc["out"], REL16[prec]) >= 0.96       # as test_tracking_60k_full_size
+        assert _rows_scaled_ok(s16, orc["out"], REL16_ALL_ROWS[prec]) == 1.0
