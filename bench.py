@@ -38,7 +38,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WORKLOAD = "tracking-60k"
 TABLES_PER_GPU = 3
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec ...
+HBM_COPY_GBS = 6290.0      # ... and the 6.29 TB/s the same guide measures for a device copy (roofline.frac_of_copy)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA (both the bf16 and the split-bf16 f32 kernel issue bf16 MFMAs)
 B, H, D = 128, 8, 24
 
@@ -195,15 +196,47 @@ def c_stdout_to_stderr():
         os.close(saved)
 
 
+def attn_source_sha256():
+    """Digest of the block-attention sources of THIS tree (tools/make_traffic.py stores the same digest with a PMC pass)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in ("hept_amd/csrc/block_attn.hip", "hept_amd/csrc/common.h", "hept_amd/csrc/p2p_dev.h", "hept_amd/csrc/Makefile"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
+
+
+def launched_kernel(precision, block_size=128, head_dim=24):
+    """The template instance hept_block_attn launches for this workload (csrc/block_attn.hip: block_attn_impl)"""
+    nkt, full = (block_size + 31) // 32, "true" if block_size % 32 == 0 else "false"
+    if precision == "fp32":
+        return f"block_attn_split_kernel<{nkt},{full},3>"
+    p16 = "true" if head_dim == 24 else "false"
+    return f"block_attn_kernel<{nkt},true,{p16},{'true' if precision == 'mixed16' else 'false'},{full}>"
+
+
 def pmc_record(precision):
-    """Per-launch PMC figures of the block-attention kernel from profiles/attn_traffic.json (tools/pmc.sh passes):
-    HBM traffic in bytes and the fraction of the kernel's cycles the matrix pipe was busy."""
+    """Per-launch PMC figures of the block-attention kernel from profiles/attn_traffic.json (tools/pmc.sh passes): HBM
+    traffic in bytes and the fraction of the kernel's cycles the matrix pipe was busy -- counters cannot be collected
+    inside an un-profiled run, so they are copied, but ONLY when the record belongs to this build: same digest of the
+    kernel sources and the same template instance as the one this run launches.  Returns (traffic, busy, source)."""
     tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
+    src = {"file": "profiles/attn_traffic.json", "kernel_launched": launched_kernel(precision)}
     try:
         rec = json.load(open(tpath))
-    except Exception:  # noqa: BLE001
-        return None, None
-    return rec.get(precision), rec.get(precision + "_mfma_busy_frac")
+    except Exception as exc:  # noqa: BLE001
+        src["refused"] = f"unreadable: {exc!r}"
+        return None, None, src
+    kernel = rec.get(precision + "_kernel")
+    src.update(kernel_measured=kernel, git_head=rec.get("git_head"), source_sha256=rec.get("source_sha256"),
+               command=rec.get("command"))
+    if rec.get("source_sha256") != attn_source_sha256():
+        src["refused"] = "the record's source digest is not this tree's (re-run tools/pmc.sh + tools/make_traffic.py)"
+        return None, None, src
+    if not isinstance(kernel, str) or src["kernel_launched"] not in kernel.replace(" ", ""):
+        src["refused"] = "the record was taken from another kernel template than the one this run launches"
+        return None, None, src
+    return rec.get(precision), rec.get(precision + "_mfma_busy_frac"), src
 
 
 def worker(args) -> int:
@@ -328,15 +361,16 @@ def worker(args) -> int:
         """HBM roofline of the block-attention kernel: algorithmic bytes per launch / mean launch duration.  The f32
         kernel issues bf16 MFMAs (split products) and is bound by its gathers and scatters as well, so both precisions
         are priced against HBM; ``mfma_busy_frac`` (PMC, profiles/) is the matrix pipe's share of the kernel's cycles."""
-        tile_bytes = 2 if precision == "bf16" else 4
+        tile_bytes = 4 if precision == "fp32" else 2
         nbytes = algorithmic_bytes(n, H, D, c, tables, tile_bytes)
         ach = nbytes / (attn_ms * 1e-3) / 1e9
-        traffic, busy = pmc_record(precision)
+        traffic, busy, source = pmc_record(precision)
         flops = algorithmic_flops(n, H, D, c, tables, B)
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "kernel": "block_attn_kernel" if precision == "bf16" else "block_attn_split_kernel",
+                "frac_of_copy": ach / HBM_COPY_GBS, "copy_peak": HBM_COPY_GBS,
+                "kernel": "block_attn_kernel" if precision != "fp32" else "block_attn_split_kernel",
                 "kernel_ms": attn_ms, "event_samples": n_rec, "algorithmic_bytes": nbytes, "traffic": traffic,
-                "mfma_busy_frac": busy,
+                "traffic_source": source, "mfma_busy_frac": busy,
                 "algorithmic_tflops": flops / (attn_ms * 1e-3) / 1e12, "mfma_bf16_peak_tflops": MFMA_BF16_PEAK_TF}
 
     tables_per_gpu = args.tables_per_gpu
@@ -388,6 +422,14 @@ def worker(args) -> int:
                 sub["fp32"] = {"ms_per_step": el / sub_steps * 1e3, "value": n_raw / (el / sub_steps), "unit": "points/s",
                                "steps": sub_steps, "dtype": "f32", "roofline": roofline(n, C, tables_per_gpu, "fp32", ams, nrec)}
                 del attn32, step32
+                # mixed16 (fp16 q^/k^ rows, bf16 weights and values): the 16-bit mode whose EVERY row stays within
+                # 2.5e-2 of the fp32 reference's row scale (bf16: 1e-1 on trained weights), at the same speed
+                _, attn16, step16 = build(tables_per_gpu, "mixed16")
+                el, ams, nrec = measure(step16, sub_steps, sub_warm)
+                sub["mixed16"] = {"ms_per_step": el / sub_steps * 1e3, "value": n_raw / (el / sub_steps), "unit": "points/s",
+                                  "steps": sub_steps, "dtype": "f16 q^,k^ rows / bf16 weights, values",
+                                  "block_attn_ms": ams}
+                del attn16, step16
             if tables_per_gpu != 1:
                 # BASELINE config 4: n_hashes = #GPUs, one table per GPU (at N = 1 a single table)
                 _, attn4, step4 = build(1, args.precision)

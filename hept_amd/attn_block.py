@@ -80,14 +80,15 @@ class Attn(nn.Module):
         params = {
             "norm1.weight": self.norm1.weight, "norm1.bias": self.norm1.bias, "w_q.weight": self.w_q.weight,
             "w_k.weight": self.w_k.weight, "w_v.weight": self.w_v.weight,
-            # sqrt_w (H, C) of the constant weight, computed once (w_per_dist = 0 below: hept_hip.h, K == 0)
-            "w_rpe.weight": a._rpe_scale_cached(self.w_rpe.weight),
+            # the weight itself: sqrt_w (H, C) is computed inside the row builder on every call (no cached copy that an
+            # in-place update of the parameter could leave stale)
+            "w_rpe.weight": self.w_rpe.weight,
             "attn.e2lsh.alpha": a.e2lsh.alpha, "attn.out_linear.weight": a.out_linear.weight,
             "attn.out_linear.bias": a.out_linear.bias, "norm2.weight": self.norm2.weight,
             "norm2.bias": self.norm2.bias, "ff.0.weight": self.ff[0].weight, "ff.0.bias": self.ff[0].bias,
             "ff.2.weight": self.ff[2].weight, "ff.2.bias": self.ff[2].bias,
         }
         y = ops.attn_block_forward(x.float(), kwargs["coords"].float(), kwargs["combined_shifts"], params,
-                                   num_heads=self.num_heads, block_size=a.block_size, w_per_dist=0,
+                                   num_heads=self.num_heads, block_size=a.block_size, w_per_dist=a.num_w_per_dist,
                                    eps1=self.norm1.eps, eps2=self.norm2.eps, precision=a.precision, workspace=ws)
         return y.to(x.dtype)

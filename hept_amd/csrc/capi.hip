@@ -9,7 +9,6 @@ namespace {
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
-    float* sqrt_w;
     void* qhat;
     void* kvhat;
     float* qproj;
@@ -37,7 +36,6 @@ Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
         return r;
     };
     Workspace w;
-    w.sqrt_w = reinterpret_cast<float*>(take((size_t)H * C * 4));
     w.qhat = take((size_t)H * N * 32 * esz);
     w.kvhat = take((size_t)H * N * 64 * esz);
     w.qproj = reinterpret_cast<float*>(take((size_t)Tc * H * N * 4));
@@ -87,17 +85,16 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
               int t0, int Tl, int precision, const Workspace& w, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     prof_mark(0, st);
-    // K == 0: `w_rpe` already holds sqrt_w (H, C) -- the caller computed it once for constant weights
-    // (hept_rpe_scale); the 400 exponentials are their own 5 us launch otherwise
-    const float* sqrt_w = K == 0 ? w_rpe : w.sqrt_w;
-    int rc = K == 0 ? HEPT_OK : hept_rpe_scale(w_rpe, H, D, C, K, w.sqrt_w, stream);
-    if (rc) return rc;
+    // K > 0: `w_rpe` is w_rpe.weight and the row builder computes sqrt_w (H, C) from it in its prologue, every call
+    // (reference example/hept.py:22-25; nothing is cached, so an in-place update of the parameter is always seen);
+    // K == 0: the caller passes sqrt_w itself (hept_rpe_scale)
+    int rc = HEPT_OK;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)Tl * H * N;
     for (int c0 = 0; c0 < Tl; c0 += HEPT_MAX_TABLES) {   // chunks of tables (the rows are rewritten identically)
         const int tc = Tl - c0 < HEPT_MAX_TABLES ? Tl - c0 : HEPT_MAX_TABLES;
-        rc = hept_prep_hash(q, k, v, coords, sqrt_w, alpha, codes, N, geo.eta ? geo.raw_size : N, H, D, C, T,
-                            t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream);
+        rc = hept_prep_hash_rpe(q, k, v, coords, w_rpe, K, alpha, codes, N, geo.eta ? geo.raw_size : N, H, D, C, T,
+                                t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream);
         if (rc) return rc;
         if (c0 == 0) prof_mark(1, st);
         // the sort writes one (2, tc, H, N) array: straight into w.pos when the call is a single chunk
@@ -501,12 +498,10 @@ extern "C" int hept_attn_block_forward(const float* x, const float* coords, cons
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     prof_mark(0, st);
-    const float* sqrt_w = K == 0 ? p->w_rpe : w.sqrt_w;   // K == 0: params->w_rpe is sqrt_w (H, C), see hept_forward
-    rc = K == 0 ? HEPT_OK : hept_rpe_scale(p->w_rpe, H, D, C, K, w.sqrt_w, stream);
-    if (rc) return rc;
-    rc = hept_prep_hash_fused(x, p->norm1_w, p->norm1_b, p->eps1, p->w_q, p->w_k, p->w_v, coords, sqrt_w, p->alpha,
-                              codes, N, N, H, D, C, T, 0, T, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax,
-                              stream);
+    // (K == 0: params->w_rpe is sqrt_w (H, C); K > 0: the weight itself, scale computed in the kernel -- see run_begin)
+    rc = hept_prep_hash_fused_rpe(x, p->norm1_w, p->norm1_b, p->eps1, p->w_q, p->w_k, p->w_v, coords, p->w_rpe, K,
+                                  p->alpha, codes, N, N, H, D, C, T, 0, T, precision, w.qhat, w.kvhat, w.qproj, w.kproj,
+                                  w.minmax, stream);
     if (rc) return rc;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)T * H * N;

@@ -112,3 +112,16 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                    0, 0);
 }
+
+// ---- entry points shared between translation units (not part of the C ABI) ---------------------------------------------
+// hept_prep_hash / hept_prep_hash_fused with the RPE weight math folded in (prep_hash.hip): K == 0: `sqrt_w` is
+// sqrt_w (H, C); K > 0: it is w_rpe.weight (H*D, (C-1)*K) and the kernels compute the scale in their prologue.
+int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
+                       const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
+                       int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
+                       void* stream);
+int hept_prep_hash_fused_rpe(const float* x, const float* norm_w, const float* norm_b, float eps, const float* w_q,
+                             const float* w_k, const float* w_v, const float* coords, const float* sqrt_w, int K,
+                             const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T,
+                             int t0, int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj,
+                             float* minmax, void* stream);

@@ -52,6 +52,34 @@ __global__ __launch_bounds__(1024) void rpe_scale_kernel(const float* __restrict
     }
 }
 
+// The same weight math inside another kernel's prologue (the row builders below): every workgroup computes sqrt_w (H, C)
+// of w_rpe.weight into its own LDS -- H*(C-1)*K <= 1024 terms of D L2-resident loads each, ~1 us beside the alpha
+// staging -- so the operator never depends on a cached copy of a parameter the caller may update in place
+// (reference example/hept.py:22-25 recomputes it every forward).  Same operations in the same order as
+// rpe_scale_kernel: the two are bit-identical.  Ends with the values visible to the whole workgroup.
+template <int NT>
+__device__ __forceinline__ void rpe_scale_lds(const float* __restrict__ w, int H, int D, int C, int K,
+                                              float* __restrict__ sw_s, float* __restrict__ term_s) {
+    const int R = C - 1, RK = R * K, total = H * RK;
+    for (int i = threadIdx.x; i < total; i += NT) {
+        const int h = i / RK, rk = i - h * RK;
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) s += w[(size_t)(h * D + d) * RK + rk];
+        term_s[i] = expf(fminf(s, 50.f));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H * R; i += NT) {
+        const int h = i / R, r = i - h * R;
+        float tot = 0.f;
+        for (int kk = 0; kk < K; ++kk) tot += term_s[h * RK + r * K + kk];
+        const float val = sqrtf(2.f * tot);
+        sw_s[h * C + r + 1] = val;
+        if (r == 0) sw_s[h * C] = val;
+    }
+    __syncthreads();
+}
+
 // backward of rpe_scale (training): d w[h*D+d][r*K+k] = [a <= 50] exp(a) * sum_{c -> r} d sqrt_w[h][c] / sqrt_w[h][c]
 // with a = sum_d w[h*D+d][r*K+k] (the same for every d of a head; torch's clamp passes the gradient at equality) and
 // columns c = 0 and c = 1 both fed by r = 0.  sqrt_w = 0 (all terms underflowed) gives inf/nan exactly as autograd does.
@@ -347,7 +375,7 @@ constexpr int PREP_WGS_PER_ROLE = HEPT_PREP_GRID / 2;  // q and k roles fill the
 template <int D, int C, int TILE, int TMAX>
 __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
+    const float* __restrict__ coords, const float* __restrict__ sqrt_w, int K, const float* __restrict__ alpha,
     const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
     void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
     constexpr int H = 8, E = D + C;
@@ -363,7 +391,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
             const int t = i % TMAX, he = i / TMAX;
             alpha_s[(he / E) * alpha_pitch(E, TMAX) + (he % E) * TMAX + t] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
         }
-        for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
+        // K > 0: `sqrt_w` is w_rpe.weight and the scale is computed here (the wave buffers are free until the tile loop)
+        if (K > 0) rpe_scale_lds<PREP_THREADS>(sqrt_w, H, D, C, K, sw_s, reinterpret_cast<float*>(tile_s));
+        else
+            for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
         __syncthreads();
     }
     if (role == 0)
@@ -385,7 +416,7 @@ __attribute__((amdgpu_waves_per_eu((TILE != HEPT_PREC_F32 && TMAX == 4) ? 4 : 2,
 void prep_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
-    const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
+    const float* __restrict__ coords, const float* __restrict__ sqrt_w, int K, const float* __restrict__ alpha,
     const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
     void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
     constexpr int D = 24, H = 8, E = D + C;
@@ -408,7 +439,9 @@ void prep_fused_kernel(
             const int t = i % TMAX, he = i / TMAX;
             alpha_s[(he / E) * alpha_pitch(E, TMAX) + (he % E) * TMAX + t] = (t < Tl) ? alpha[(size_t)he * T + t0 + t] : 0.f;
         }
-        for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
+        if (K > 0) rpe_scale_lds<PREP_THREADS>(sqrt_w, H, D, C, K, sw_s, reinterpret_cast<float*>(tile_s));   // see prep_hash_kernel
+        else
+            for (int i = threadIdx.x; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
     }
     __syncthreads();
     const FusedIn fin{ln_w, ln_b, w_s, eps};
@@ -425,14 +458,14 @@ void prep_fused_kernel(
 
 template <int C>
 int launch_prep_fused(const float* x, const float* ln_w, const float* ln_b, float eps, const float* wq, const float* wk,
-                      const float* wv, const float* coords, const float* sqrt_w, const float* alpha,
+                      const float* wv, const float* coords, const float* sqrt_w, int K, const float* alpha,
                       const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision, void* qhat,
                       void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
     const dim3 grid(PREP_WGS_PER_ROLE, 3);
     // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
 #define HEPT_FUSED_LAUNCH(TILE, TMAX)                                                                                  \
     hipLaunchKernelGGL((prep_fused_kernel<C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, x, ln_w, ln_b, eps, wq, wk, \
-                       wv, coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
+                       wv, coords, sqrt_w, K, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
 #define HEPT_FUSED_TILE(TILE)                                                                                          \
     do {                                                                                                               \
         if (Tl <= 4) HEPT_FUSED_LAUNCH(TILE, 4);                                                                       \
@@ -447,7 +480,7 @@ int launch_prep_fused(const float* x, const float* ln_w, const float* ln_b, floa
 }
 
 template <int D, int C>
-int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w,
+int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                 const float* alpha, const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision,
                 void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
     // q- and k-role workgroups each write one of the HEPT_PREP_GRID partial slots the sort kernel reduces
@@ -455,7 +488,7 @@ int launch_prep(const float* q, const float* k, const float* v, const float* coo
     // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
 #define HEPT_PREP_LAUNCH(TILE, TMAX)                                                                                 \
     hipLaunchKernelGGL((prep_hash_kernel<D, C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w, \
-                       alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
+                       K, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
 #define HEPT_PREP_TILE(TILE)                                                                                         \
     do {                                                                                                             \
         if (Tl <= 4) HEPT_PREP_LAUNCH(TILE, 4);                                                                      \
@@ -487,7 +520,7 @@ __device__ __forceinline__ float f32_from_ordered(unsigned int u) {
 template <int TILE>
 __global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const float* __restrict__ coords, const float* __restrict__ sqrt_w, const float* __restrict__ alpha,
+    const float* __restrict__ coords, const float* __restrict__ sqrt_w, int K, const float* __restrict__ alpha,
     const int64_t* __restrict__ codes, int N, int raw_size, int H, int D, int C, int T, int t0, int Tl,
     void* __restrict__ qhat_, void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj,
     float* __restrict__ minmax) {
@@ -496,6 +529,8 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
     constexpr int QROW = BF16 ? 64 : 128;
     __shared__ float alpha_s[16 * 30 * HEPT_MAX_TABLES];              // [h][e][t]
     __shared__ unsigned int red_s[HEPT_MAX_TABLES * 16 * 3];          // ordered-uint min / max / code max per (t, h)
+    __shared__ float sw_s[16 * 29];                                   // sqrt_w (H, C)
+    __shared__ float term_s[1024];                                    // scratch of rpe_scale_lds
     const int role = blockIdx.y, tid = threadIdx.x, E = D + C, HD = H * D;
     const int ppw = PREP_THREADS / H;             // points per workgroup step; thread = (point slot, head), head fixed
     const int h = tid % H, slot = tid / H;
@@ -507,6 +542,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
         }
         for (int i = tid; i < HEPT_MAX_TABLES * 16 * 3; i += PREP_THREADS)
             red_s[i] = (i % 3 == 0) ? f32_ordered(INFINITY) : (i % 3 == 1 ? f32_ordered(-INFINITY) : f32_ordered(0.f));
+        if (K > 0) rpe_scale_lds<PREP_THREADS>(sqrt_w, H, D, C, K, sw_s, term_s);   // `sqrt_w` is w_rpe.weight (see prep_hash_kernel)
+        else
+            for (int i = tid; i < H * C; i += PREP_THREADS) sw_s[i] = sqrt_w[i];
         __syncthreads();
     }
     const float* x = role == 0 ? q : (role == 1 ? k : v);
@@ -533,7 +571,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
 #pragma unroll
             for (int c = 0; c < 30; ++c)
                 if (c < C) {
-                    const float val = is_pad ? 0.f : sqrt_w[h * C + c] * coords[(size_t)n * C + c];
+                    const float val = is_pad ? 0.f : sw_s[h * C + c] * coords[(size_t)n * C + c];
 #pragma unroll
                     for (int e = 1; e < 30; ++e)
                         if (e == D + c) a[e] = val;
@@ -603,20 +641,20 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
     }
 }
 
-int launch_prep_generic(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w,
+int launch_prep_generic(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                         const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
                         int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
                         hipStream_t st) {
     const dim3 grid(HEPT_PREP_GRID / 2, 3);   // q- and k-role workgroups each own one partial slot
     if (precision == HEPT_PREC_BF16)
         hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_BF16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
-                           alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     else if (precision == HEPT_PREC_MIXED16)
         hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_MIXED16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
-                           alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     else
         hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_F32>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
-                           alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
     return hept_launch_status();
 }
 
@@ -638,11 +676,14 @@ extern "C" int hept_rpe_scale_bwd(const float* w_rpe, const float* d_sqrt_w, int
     return hept_launch_status();
 }
 
-extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
-                              const float* sqrt_w, const float* alpha, const int64_t* codes, int N, int raw_size,
-                              int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat, void* kvhat,
-                              float* qproj, float* kproj, float* minmax, void* stream) {
+// internal (common.h): K == 0: `sqrt_w` is sqrt_w (H, C); K > 0: it is w_rpe.weight (H*D, (C-1)*K) and every workgroup
+// of the launch computes the scale in its prologue (rpe_scale_lds)
+int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
+                       const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
+                       int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
+                       void* stream) {
     if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    if (K < 0 || (K > 0 && (C < 2 || H * (C - 1) * K > 1024))) return HEPT_ERR_SHAPE;
     if (!q || !k || !v || !coords || !sqrt_w || !alpha || !qhat || !kvhat || !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
     if (H < 1 || H > 16 || D < 1 || D > 28 || C < 1 || D + C > 30) return HEPT_ERR_SHAPE;
@@ -653,7 +694,7 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
     hipStream_t st = (hipStream_t)stream;
 #define HEPT_PREP_CASE(DD, CC)                                                                             \
     if (H == 8 && D == DD && C == CC)                                                                      \
-        return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, alpha, codes, N, raw_size, T, t0, Tl, precision, \
+        return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, K, alpha, codes, N, raw_size, T, t0, Tl, precision, \
                                    qhat, kvhat, qproj, kproj, minmax, st);
     HEPT_PREP_CASE(24, 6)
     HEPT_PREP_CASE(24, 4)
@@ -662,16 +703,26 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
     HEPT_PREP_CASE(16, 4)
     HEPT_PREP_CASE(8, 4)
 #undef HEPT_PREP_CASE
-    return launch_prep_generic(q, k, v, coords, sqrt_w, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, precision, qhat,
+    return launch_prep_generic(q, k, v, coords, sqrt_w, K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, precision, qhat,
                                kvhat, qproj, kproj, minmax, st);
 }
 
-extern "C" int hept_prep_hash_fused(const float* x, const float* norm_w, const float* norm_b, float eps,
-                                    const float* w_q, const float* w_k, const float* w_v, const float* coords,
-                                    const float* sqrt_w, const float* alpha, const int64_t* codes, int N, int raw_size,
-                                    int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat,
-                                    void* kvhat, float* qproj, float* kproj, float* minmax, void* stream) {
+extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
+                              const float* sqrt_w, const float* alpha, const int64_t* codes, int N, int raw_size,
+                              int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat, void* kvhat,
+                              float* qproj, float* kproj, float* minmax, void* stream) {
+    return hept_prep_hash_rpe(q, k, v, coords, sqrt_w, 0, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, precision, qhat,
+                              kvhat, qproj, kproj, minmax, stream);
+}
+
+// internal (common.h): K as in hept_prep_hash_rpe
+int hept_prep_hash_fused_rpe(const float* x, const float* norm_w, const float* norm_b, float eps, const float* w_q,
+                             const float* w_k, const float* w_v, const float* coords, const float* sqrt_w, int K,
+                             const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T,
+                             int t0, int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj,
+                             float* minmax, void* stream) {
     if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    if (K < 0 || (K > 0 && (C < 2 || H * (C - 1) * K > 1024))) return HEPT_ERR_SHAPE;
     if (!x || !norm_w || !norm_b || !w_q || !w_k || !w_v || !coords || !sqrt_w || !alpha || !qhat || !kvhat ||
         !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
@@ -682,11 +733,20 @@ extern "C" int hept_prep_hash_fused(const float* x, const float* norm_w, const f
     hipStream_t st = (hipStream_t)stream;
 #define HEPT_FUSED_CASE(CC)                                                                                         \
     if (C == CC)                                                                                                    \
-        return launch_prep_fused<CC>(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, N, raw_size, \
+        return launch_prep_fused<CC>(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, K, alpha, codes, N, raw_size, \
                                      T, t0, Tl, precision, qhat, kvhat, qproj, kproj, minmax, st);
     HEPT_FUSED_CASE(6)
     HEPT_FUSED_CASE(4)
     HEPT_FUSED_CASE(2)
 #undef HEPT_FUSED_CASE
     return HEPT_ERR_SHAPE;
+}
+
+extern "C" int hept_prep_hash_fused(const float* x, const float* norm_w, const float* norm_b, float eps,
+                                    const float* w_q, const float* w_k, const float* w_v, const float* coords,
+                                    const float* sqrt_w, const float* alpha, const int64_t* codes, int N, int raw_size,
+                                    int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat,
+                                    void* kvhat, float* qproj, float* kproj, float* minmax, void* stream) {
+    return hept_prep_hash_fused_rpe(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, 0, alpha, codes, N, raw_size, H,
+                                    D, C, T, t0, Tl, precision, qhat, kvhat, qproj, kproj, minmax, stream);
 }

@@ -105,9 +105,6 @@ def _rank_within_cloud(values: torch.Tensor, batch: torch.Tensor, raw_start: tor
     return rank - raw_start[batch]
 
 
-_REGION_BITS: Dict[str, object] = {}
-
-
 def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """``prepare_input`` on the GPU through the C ABI (``hept_prepare_input``, ``csrc/prepare.hip``).
 
@@ -130,20 +127,17 @@ def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Di
     n_clouds = int(batch[-1]) + 1
     edges = torch.searchsorted(batch.contiguous(), torch.arange(n_clouds + 1, device=dev, dtype=batch.dtype))
     cloud_start = edges.to(torch.int32)
-    sizes = edges.cpu().diff()
+    # packed codes must stay below 2^24 (they are sorted as exact fp32 keys): the largest region counts per axis are read
+    # from the tensor on EVERY call -- no cache keyed on a version counter that `.data` updates do not bump -- and ride
+    # in the boundaries' device-to-host copy, so the check costs no extra synchronisation
+    reg_hi = torch.ceil(regions.amax(dim=(0, 2))).to(edges.dtype)
+    host = torch.cat([edges, reg_hi]).cpu()
+    sizes = host[:n_clouds + 1].diff()
     if int(sizes.min()) < 1:
         raise ValueError("every cloud id in [0, batch.max()] must own at least one point")
     padded = ((sizes + block_size - 1) // block_size) * block_size
     max_cloud, n_pad = int(sizes.max()), int(padded.sum())
-    # packed codes must stay below 2^24 (they are sorted as exact fp32 keys); the region counts are constants of the
-    # model: their maxima are read back once per tensor version, not per call
-    src = helper_params["regions"]
-    key = (src.data_ptr(), src._version, tuple(src.shape), src.device)
-    if _REGION_BITS.get("key") != key:
-        reg_hi = src.float().amax(dim=(0, 2)).cpu()
-        _REGION_BITS["key"] = key
-        _REGION_BITS["bits"] = sum(int(torch.ceil(reg_hi[a]).item() + 1).bit_length() for a in (0, 1))
-    bits = _REGION_BITS["bits"]
+    bits = sum((int(host[n_clouds + 1 + a]) + 1).bit_length() for a in (0, 1))
     if (n_clouds << bits) >= (1 << 24):
         raise ValueError("AND codes would exceed 2^24: too many clouds x regions for the fp32-keyed pad sort")
     pad_start = torch.cat([torch.zeros(1, dtype=torch.int64), padded.cumsum(0)]).to(torch.int32).to(dev, non_blocking=True)

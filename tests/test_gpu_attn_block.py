@@ -162,3 +162,26 @@ def test_attn_block_full_size_vs_oracle(precision, gpu_device):
     else:
         assert float((err.amax(-1) <= 2.5e-2 * (want.abs().amax(-1) + 1)).float().mean()) >= 0.97
     assert float((err.amax(-1) <= 5e-2 * (want.abs().amax(-1) + 1)).float().mean()) >= 0.995
+
+
+def test_fused_block_sees_in_place_update_of_w_rpe(gpu_device):
+    """The fused block passes w_rpe.weight to the C call; an in-place ``.data`` update (no ``_version`` bump, same
+    pointer) between two forwards must change the second one exactly as it changes the composed block."""
+    inp, _ = cases.load_case_attn("a2_attn_rand")
+    dev = gpu_device
+    blk = Attn(inp["coords"].shape[1], precision="fp32", h_dim=24, num_heads=8, block_size=inp["block_size"],
+               n_hashes=3, num_w_per_dist=10, n_layers=4)
+    blk.load_state_dict(inp["params"], strict=True)
+    blk = blk.to(dev).eval()
+    kwargs = {"coords": inp["coords"].to(dev), "combined_shifts": inp["combined_shifts"].to(dev)}
+    x = inp["x"].to(dev)
+    with torch.no_grad():
+        y0 = blk(x, kwargs)
+        blk.w_rpe.weight.data.mul_(1.7)
+        y1 = blk(x, kwargs)
+    assert not torch.equal(y0, y1)
+    p2 = {k: v.clone() for k, v in inp["params"].items()}
+    p2["w_rpe.weight"] = blk.w_rpe.weight.detach().cpu().clone()
+    own = _oracle(dict(inp, params=p2))["y"]
+    ok = ((y1.cpu() - own).abs() <= ATOL["a2_attn_rand"] + 1e-4 * own.abs()).all(-1).float().mean()
+    assert float(ok) >= 0.97

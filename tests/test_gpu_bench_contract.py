@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
         "vs_baseline", "dtype", "data", "config", "roofline"}
-ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"}
+ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "frac_of_copy", "traffic_source"}
 
 
 def _run(*args, **env_extra):
@@ -35,6 +35,7 @@ def test_bench_line(precision, bound, dtype, gpu_device):
         assert f["dtype"] == "f32" and f["ms_per_step"] > d["ms_per_step"] and 0.0 < f["roofline"]["frac"] < 1.0
         assert f["roofline"]["bound"] == "hbm" and f["roofline"]["kernel"] == "block_attn_split_kernel"
         assert d["c4"]["ms_per_step"] < d["ms_per_step"] and "n_hashes=1" in d["c4"]["workload"]
+        assert 0.5 < d["mixed16"]["ms_per_step"] / d["ms_per_step"] < 1.5      # the every-row-tight 16-bit mode
     assert d["config"]["rccl_ranks"] == 0
     assert KEYS <= set(d) and ROOF <= set(d["roofline"])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 2 and d["higher_is_better"] is True
@@ -43,6 +44,15 @@ def test_bench_line(precision, bound, dtype, gpu_device):
     assert "tracking-60k" in d["config"]["workload"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == bound and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["frac_of_copy"] - r["achieved"] / 6290.0) < 1e-9
+    # PMC traffic is copied from profiles/ only when the record belongs to this build and this kernel template
+    src = r["traffic_source"]
+    assert src["kernel_launched"].startswith("block_attn_split_kernel<4" if precision == "fp32" else "block_attn_kernel<4")
+    if r["traffic"] is None:
+        assert "refused" in src
+    else:
+        assert "refused" not in src and src["kernel_launched"] in src["kernel_measured"].replace(" ", "")
+        assert r["traffic"] > 0.9 * r["algorithmic_bytes"] * 0.5
     assert 1e7 < d["value"] < 1e10 and abs(d["value"] - 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 

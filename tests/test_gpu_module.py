@@ -191,3 +191,43 @@ def test_reserve_sizes_the_workspace_before_the_first_call(gpu_device):
     assert (m._workspace.data_ptr(), m._workspace.numel()) == (ptr, size)
     assert plain._workspace.numel() < size
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_in_place_update_of_w_rpe_through_data_is_seen(precision, gpu_device):
+    """``w.weight.data.mul_()/copy_()`` (EMA swaps, hand-rolled optimisers) changes a parameter WITHOUT bumping its
+    ``_version`` and without moving it: the reference recomputes ``sqrt_w`` from the weight on every forward
+    (example/hept.py:21-28), and so does the row builder here -- both forwards must match the oracle."""
+    inp, _ = cases.load_case("g1_rand512")
+    m, w_rpe = _module(inp, gpu_device, precision=precision)
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+    model = dict(tile_dtype=torch.bfloat16) if precision == "bf16" else {}
+
+    def oracle(weight):
+        return ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], weight, inp["alpha"],
+                          inp["out_weight"], inp["out_bias"], block_size=inp["block_size"], w_per_dist=10, keep=False,
+                          **model)["out"]
+
+    def rows_ok(out, ref):
+        atol, rtol = (1e-5, 1e-4) if precision == "fp32" else (5e-3, 8e-3)
+        return ((out.cpu() - ref).abs() <= atol + rtol * ref.abs()).all(-1).float().mean().item()
+
+    with torch.no_grad():
+        first = m(g["q"], g["k"], g["v"], **kw)
+    assert rows_ok(first, oracle(inp["w_rpe_weight"])) >= 0.99
+    version, ptr = w_rpe.weight._version, w_rpe.weight.data_ptr()
+    w_rpe.weight.data.mul_(1.5)                       # in place, through .data
+    w_rpe.weight.data[:, :10].add_(0.01)
+    assert w_rpe.weight._version == version and w_rpe.weight.data_ptr() == ptr   # nothing a cache key could see
+    new_w = w_rpe.weight.detach().cpu().clone()
+    with torch.no_grad():
+        second = m(g["q"], g["k"], g["v"], **kw)
+    ref2 = oracle(new_w)
+    assert rows_ok(second, ref2) >= 0.99
+    assert rows_ok(first, ref2) < 0.5                 # the update does change the answer: a stale scale would fail
+    # the stage entry point with an explicit sqrt_w agrees bit for bit with the in-kernel weight math
+    sw = ops.rpe_scale(w_rpe.weight.detach(), m.num_heads, m.dim_per_head, 10)
+    staged = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], sw, g["alpha"], g["out_weight"],
+                         g["out_bias"], block_size=inp["block_size"], w_per_dist=0, precision=precision)
+    assert torch.equal(staged, second)

@@ -72,9 +72,24 @@ def _rows_scaled_ok(out, ref, rel):
 # stated tolerances of the 16-bit modes against the fp32 REFERENCE (measured 99th percentiles: bf16 <= 1.9e-2,
 # mixed16 <= 0.85e-2 of the row scale on every golden case, tests/diag_tol_probe.py)
 REL16 = {"bf16": 2.5e-2, "mixed16": 1.0e-2}
-# ... and the bound EVERY row of every golden case meets (bf16 rounds q^/k^ to 8 bits, so the worst rows are those of
-# the trained-checkpoint case G3, |q^|^2 ~ 1e3: measured worst row 7.2e-2 there, <= 5.1e-2 elsewhere)
-REL16_ALL_ROWS = {"bf16": 1.0e-1, "mixed16": 2.5e-2}
+# ... and the bound EVERY row meets, per golden case, set from measurement (tests/diag_bounds.py, round 3; the kernels
+# are deterministic, so the measured worst row is reproduced on every box) at <= 2x the measured worst row.  bf16
+# rounds q^/k^ to 8 bits, so its worst rows are those of the trained-checkpoint case G3 (|q^|^2 ~ 1e3); fp16 q^/k^
+# rows (mixed16) remove that term.          measured worst row:   bf16      mixed16
+REL16_ALL_ROWS = {
+    "g1_rand512":   {"bf16": 4.0e-2, "mixed16": 1.2e-2},     # 2.30e-2   6.2e-3
+    "g2_example4k": {"bf16": 8.0e-2, "mixed16": 1.5e-2},     # 5.04e-2   7.7e-3
+    "g3_ckpt6k":    {"bf16": 1.0e-1, "mixed16": 2.5e-2},     # 7.23e-2   1.68e-2
+    "g4_pileup":    {"bf16": 1.0e-2, "mixed16": 1.0e-2},     # 5.7e-3    5.2e-3
+    "g6_block100":  {"bf16": 1.0e-2, "mixed16": 1.0e-2},     # 5.4e-3    5.4e-3
+}
+# synthetic full-size clouds (default-initialised weights, |q^| ~ 5): every row within this
+REL16_ALL_ROWS_FULL = {"bf16": 1.0e-1, "mixed16": 2.5e-2}
+# fp32 tiles, identical permutations: the stated tolerance (atol 1e-5 / rtol 1e-4) holds for EVERY element of every
+# golden case (measured worst element: 0.44x of it); at full size (60k points, ~1.4 M elements, a few rows whose total
+# weight sits near the 1e-20 denominator floor) >= 99.9 % of rows meet it and EVERY element is within HARD_X times it
+# (measured worst: 1.27x, tests/diag_bounds.py)
+HARD_X = 2.0
 
 
 def _rows_ok(out, ref, atol, rtol=1e-4):
@@ -133,18 +148,16 @@ def test_block_attention_with_reference_permutations(name, precision, gpu_device
     ref = torch.from_numpy(fx["out"])
     out = st["out"].cpu()
     if precision == "fp32":
-        # stated tolerance atol 1e-5 / rtol 1e-4 on >= 99.9 % of rows; rows whose total weight sits at the
-        # 1e-20 denominator floor amplify fp32 round-off, so the hard bound on every element is 3x looser
+        # stated tolerance atol 1e-5 / rtol 1e-4 (G3: atol 1e-3) on EVERY element (measured worst: 0.44x of it)
         atol = ATOL.get(name, 1e-5)
-        assert _rows_ok(out, ref, atol, 1e-4) >= 0.999
-        torch.testing.assert_close(out, ref, rtol=3e-2, atol=3 * atol)
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=atol)
     else:
         # bf16 rounds q^/k^ to 8 bits (logit error grows with |q^|); mixed16 keeps 11 bits there, what is left
         # is the bf16 rounding of the weights, v and the stored numerators (2^-9 relative each, unbiased)
         assert _rows_scaled_ok(out, ref, REL16[precision]) >= 0.99
         worst = ((out - ref).abs().amax(-1) / (ref.abs().amax(-1) + 1e-3)).max().item()
         print(f"worst row-scaled error {name} {precision}: {worst:.3e}")
-        assert _rows_scaled_ok(out, ref, REL16_ALL_ROWS[precision]) == 1.0
+        assert _rows_scaled_ok(out, ref, REL16_ALL_ROWS[name][precision]) == 1.0
         # tight against the oracle's model of the 16-bit path (rounded tiles and weights, fp32 accumulate)
         orc = _oracle(inp, q_positions=qp.long().cpu(), k_positions=kp.long().cpu(), keep=False, **_model_kw(precision))
         # (rtol = 2 bf16 ulps: a last-bit fp32 difference can flip the rounding of a stored bf16 numerator)
@@ -349,17 +362,34 @@ def test_full_size_every_row_with_the_gpu_permutations_injected(workload, gpu_de
     orc = _oracle(inp, q_positions=qp, k_positions=kp, keep=False)
     out = st["out"].cpu()
     assert _rows_ok(out, orc["out"], 1e-5, 1e-4) >= 0.999
-    torch.testing.assert_close(out, orc["out"], rtol=3e-2, atol=3e-5)      # every element, 3x looser (as on the goldens)
+    torch.testing.assert_close(out, orc["out"], rtol=HARD_X * 1e-4, atol=HARD_X * 1e-5)      # every element
     own = _oracle(inp, keep=True)
     hash_scale = float(own["q_hashed"].abs().max())
+    b, n = inp["block_size"], out.shape[0]
+    touched = torch.zeros(n, dtype=torch.bool)   # queries whose block (in any table / head) gained or lost a point
+    q_block = None
     for pos, keys, theirs in ((qp, own["q_keys"], own["q_positions"]), (kp, own["k_keys"], own["k_positions"])):
         tol = 8e-6 * hash_scale + 4 * 2.0 ** -23 * float(keys.abs().max())
         assert _almost_sorted(keys, pos, tol) <= tol
-        moved = (pos != theirs)
-        frac = moved.float().mean().item()
+        frac = (pos != theirs).float().mean().item()
         print(f"{workload}: {frac:.2e} of the sorted positions differ from the oracle's stable sort")
-        assert frac < 2e-2
-    # the end-to-end rows that differ are exactly rows whose block membership changed: none if nothing moved
+        assert frac <= 1e-3                      # measured: 1.5e-5 (tracking-60k), 1.4e-6 (pileup)
+        rank_gpu = torch.empty_like(pos).scatter_(-1, pos, torch.arange(n).expand_as(pos))
+        rank_orc = torch.empty_like(theirs).scatter_(-1, theirs, torch.arange(n).expand_as(theirs))
+        changed = (rank_gpu // b) != (rank_orc // b)            # (T, H, N): the point sits in another block
+        if q_block is None:
+            q_block = rank_gpu // b
+            touched |= changed.any(0).any(0)                    # a query that moved to another block itself
+        else:                                                   # a key moved: every query of both blocks is affected
+            cnt = torch.zeros(pos.shape[0], pos.shape[1], n // b, dtype=torch.int32)
+            cnt.scatter_add_(-1, rank_gpu // b, changed.int())
+            cnt.scatter_add_(-1, rank_orc // b, changed.int())
+            touched |= (cnt > 0).gather(-1, q_block).any(0).any(0)
+    # attribution: end to end (the GPU's own sort against the oracle's stable sort) every row that is off by more than
+    # the every-element bound is a row whose block membership differs between the two permutations
+    off = ~(((out - own["out"]).abs() <= HARD_X * (1e-5 + 1e-4 * own["out"].abs())).all(-1))
+    print(f"{workload}: {int(off.sum())} rows off end to end, {int(touched.sum())} rows touched by a moved point")
+    assert not bool((off & ~touched).any())
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -401,9 +431,9 @@ def test_full_size_with_the_references_own_block_size(gpu_device):
     orc = _oracle(inp, q_positions=qp, k_positions=kp, keep=False)
     out = st["out"].cpu()
     assert _rows_ok(out, orc["out"], 1e-5, 1e-4) >= 0.999
-    torch.testing.assert_close(out, orc["out"], rtol=3e-2, atol=3e-5)
+    torch.testing.assert_close(out, orc["out"], rtol=HARD_X * 1e-4, atol=HARD_X * 1e-5)    # every element (measured 1.22x)
     assert torch.equal(_forward(g, inp, "fp32").cpu(), out)          # the one-call operator = the staged kernels
     for prec in ("bf16", "mixed16"):
         s16 = _staged(g, inp, prec, qpos=st["qpos"], kpos=st["kpos"])["out"].cpu()
         assert _rows_scaled_ok(s16, orc["out"], REL16[prec]) >= 0.96       # as test_tracking_60k_full_size
-        assert _rows_scaled_ok(s16, orc["out"], REL16_ALL_ROWS[prec]) == 1.0
+        assert _rows_scaled_ok(s16, orc["out"], REL16_ALL_ROWS_FULL[prec]) == 1.0

@@ -166,3 +166,20 @@ def test_segmented_argsort_oversize_bucket_paths(gpu_device, spread):
     keys = keys[:, torch.randperm(n + 1500, generator=g)]
     pos = ops.segmented_argsort(keys.to(gpu_device)).long().cpu()
     assert torch.equal(pos, torch.sort(keys, dim=-1, stable=True).indices)
+
+
+def test_region_table_updated_in_place_is_re_read(gpu_device):
+    """The 2^24 guard of the pad sort reads the region counts from the tensor on every call: growing them in place
+    through ``.data`` (no ``_version`` bump) must trip it on the next call instead of reusing a remembered width."""
+    inp, _ = cases.load_case("g2_example4k")
+    b = cases.CASES["g2_example4k"]["block_size"]
+    regions = inp["regions"].to(gpu_device).clone()
+    helper = {"block_size": b, "num_heads": cases.NUM_HEADS, "regions": regions}
+    x = torch.arange(inp["n_raw"], device=gpu_device)
+    args = (x, inp["coords_raw"].to(gpu_device), inp["batch"].to(gpu_device), helper)
+    prepare_input_hip(*args)
+    v = regions._version
+    regions.data.mul_(4096.0)            # 12 more bits per axis: codes no longer fit an exact fp32 key
+    assert regions._version == v
+    with pytest.raises(ValueError, match="2\\^24"):
+        prepare_input_hip(*args)

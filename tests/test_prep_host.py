@@ -21,6 +21,36 @@ def test_codes_match_reference_checksum(name):
     assert len(fx["code_patch_idx"]) <= 8  # tie-induced only
 
 
+def _row_digests(codes):
+    """(T, H, N) int64 -> (T, H) uint64, as tests/golden/make_golden_codes.py computed them on the reference's codes."""
+    import hashlib
+
+    arr = np.ascontiguousarray(codes.numpy().astype("<i8"))
+    return np.array([[int.from_bytes(hashlib.sha256(arr[i, j].tobytes()).digest()[:8], "little")
+                      for j in range(arr.shape[1])] for i in range(arr.shape[0])], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("name", PREP_CASES)
+def test_codes_equal_the_references_element_for_element(name):
+    """Every (table, head) row of the AND codes the tests feed to the operator has the SHA-256 digest of the REFERENCE's
+    own ``combined_shifts`` row (stored by make_golden_codes.py from a run of example/transformer.py:35-63): the rows
+    are equal element for element, not just in their sum.  The host mirror alone differs only at the stored patches."""
+    inp, _ = cases.load_case(name)
+    with np.load(cases.os.path.join(cases.GOLDEN_DIR, "ref_codes_digest.npz")) as z:
+        want, row_sum, row_max = z[name + "/digest"], z[name + "/row_sum"], z[name + "/row_max"]
+    codes = inp["combined_shifts"]
+    assert np.array_equal(_row_digests(codes), want)
+    assert np.array_equal(codes.sum(-1).numpy(), row_sum) and np.array_equal(codes.amax(-1).numpy(), row_max)
+    # the un-patched mirror: rebuilt from the raw inputs, it differs from the reference in <= 8 tie-induced elements
+    cfg = cases.CASES[name]
+    helper = {"block_size": cfg["block_size"], "num_heads": cases.NUM_HEADS, "regions": inp["regions"]}
+    _, kw, _ = prepare_input(torch.arange(inp["n_raw"]), inp["coords_raw"], inp["batch"], helper)
+    # (compared on the real points: the mirror draws its own padding duplicates from the same window)
+    mine = kw["combined_shifts"][..., inp["unpad_seq"]]
+    ref = codes[..., inp["unpad_seq"]]
+    assert int((mine != ref).sum()) <= 8
+
+
 @pytest.mark.parametrize("name", PREP_CASES)
 def test_own_padding_follows_reference_rule(name):
     """Pads of cloud i are drawn from the last block_size positions of that cloud in table-0/head-0
