@@ -94,13 +94,24 @@ class HeptPartialSums(torch.autograd.Function):
         n, hd = q.shape
         h = alpha.shape[0]
         d = hd // h
-        if geo is None:
-            ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, "fp32")
-            qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"])
-        else:
-            eta, phi, cfac, raw_size = geo
-            ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, None, "fp32", raw_size=raw_size)
-            qpos, kpos = ops.sort_tables_src(ph["qproj"], ph["kproj"], eta, phi, cfac, ph["minmax"])
+        # hashes and the sort walk the tables in chunks of HEPT_MAX_TABLES, as the inference entry points do (the
+        # reference takes any n_hashes, example/hept.py:37-41); the rows are rewritten identically by every chunk
+        from ._lib import MAX_TABLES
+
+        n_tables = alpha.shape[2]
+        qs, ks = [], []
+        for c0 in range(0, n_tables, MAX_TABLES):
+            tc = min(MAX_TABLES, n_tables - c0)
+            if geo is None:
+                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, "fp32", t0=c0, tl=tc)
+                qp, kp = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"], t0=c0)
+            else:
+                eta, phi, cfac, raw_size = geo
+                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, None, "fp32", t0=c0, tl=tc, raw_size=raw_size)
+                qp, kp = ops.sort_tables_src(ph["qproj"], ph["kproj"], eta, phi, cfac, ph["minmax"], t0=c0)
+            qs.append(qp)
+            ks.append(kp)
+        qpos, kpos = (qs[0], ks[0]) if len(qs) == 1 else (torch.cat(qs), torch.cat(ks))
         part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, block_size, f32_mfma=f32_mfma)
         acc = ops.reduce_tables(part, d)
         ctx.f32_mfma = f32_mfma

@@ -193,8 +193,49 @@ void block_attn_kernel(const char* __restrict__ qhat,
     }
 
     if constexpr (P16) {
-        // ---- scatter, 64-B rows: even lane 2i packs columns (2i, 2i+1) as bf16 -> dword i (i < 12);
-        //      lane 24 holds the denominator (f32, dword 12); lanes 26..30 write the zero padding
+        // ---- scatter, 64-B rows [24 bf16 numer | f32 denom | 0]: even lane 2i packs columns (2i, 2i+1) -> dword i
+        //      (i < 12), lane 24 holds the denominator (dword 12), lanes 26..30 the zero padding.  The wave's 32 x 16
+        //      dword tile passes through LDS (the K^ / V tiles are dead after the loop; 16-B pieces XOR-swizzled by the
+        //      row so that the two lane halves -- rows r and r + 4, 64 dwords apart -- land on different banks), so that
+        //      a lane stores a 16-B piece and four lanes a whole 64-B row: two store instructions per wave instead of
+        //      sixteen 4-byte ones, and the form the xGMI links want when the row belongs to another rank (direct mode).
+#ifndef HEPT_ATTN_DWORD_SCATTER
+        __syncthreads();   // every wave is done reading k_s / v_s
+        unsigned int* tile = reinterpret_cast<unsigned int*>(smem) + w * 32 * 16;   // this wave's 2 KiB of the K^ tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float mine = z[r];
+            const float nbr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mine), 0xB1,
+                                                                                 0xF, 0xF, true));  // lane ^ 1
+            if ((li & 1) == 0) {
+                const int row = hept_acc_row(r, hh), dw = li >> 1;
+                unsigned int word = hept_pack_bf16(mine, nbr);
+                if (li == D) word = __float_as_uint(mine + 1e-20f);  // example/hept.py:14 (D is even)
+                if (li > D) word = 0u;
+                tile[row * 16 + (((dw >> 2) ^ ((row >> 2) & 3)) << 2) + (dw & 3)] = word;
+            }
+        }
+        // (one wave's LDS accesses execute in order: the tile is complete when the reads below are issued)
+        unsigned int* __restrict__ pt =
+            reinterpret_cast<unsigned int*>(part) + (size_t)t * hr.tstride_rows * 16 + (size_t)(h - hr.hsub) * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (lane >> 2) + 16 * j, pc = lane & 3;
+            const int q2 = w * 32 + row;
+            if (FULL || q2 < B) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * 16 + ((pc ^ ((row >> 2) & 3)) << 2));
+                const int dst = qidx_s[q2];
+                if (pa.direct) {
+                    bool remote;
+                    char* rowp = direct_row(pa, dst, h - hr.h0, 64, remote) + pc * 16;
+                    if (remote) store16_system(rowp, v);
+                    else *reinterpret_cast<u32x4*>(rowp) = v;
+                } else {
+                    *reinterpret_cast<u32x4*>(pt + (size_t)dst * hr.hout * 16 + pc * 4) = v;
+                }
+            }
+        }
+#else
         unsigned int* __restrict__ pt =
             reinterpret_cast<unsigned int*>(part) + (size_t)t * hr.tstride_rows * 16 + (size_t)(h - hr.hsub) * 16 + (li >> 1);
 #pragma unroll
@@ -211,6 +252,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
                 pt[(size_t)dst * hr.hout * 16] = word;
             }
         }
+#endif
     } else {
         // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
         float* __restrict__ pt = part + (size_t)t * hr.tstride_rows * 32 + (size_t)(h - hr.hsub) * 32 + li;
@@ -221,10 +263,19 @@ void block_attn_kernel(const char* __restrict__ qhat,
                 const int dst = qidx_s[q2];
                 float val = z[r];
                 if (li == D) val += 1e-20f;  // example/hept.py:14
-                pt[(size_t)dst * hr.hout * 32] = val;
+                if (pa.direct) {   // (f32 rows to another rank: 4-byte system-scope stores -- correct, not tuned)
+                    bool remote;
+                    char* rowp = direct_row(pa, dst, h - hr.h0, 128, remote) + li * 4;
+                    if (remote) store4_system(rowp, __float_as_uint(val));
+                    else *reinterpret_cast<float*>(rowp) = val;
+                } else {
+                    pt[(size_t)dst * hr.hout * 32] = val;
+                }
             }
         }
     }
+    // direct mode: the last workgroup of the launch raises this rank's row flag in every rank's buffer
+    if (pa.direct) signal_when_all_done(pa.counter, pa.peers, pa.world, pa.flag_idx, pa.epoch);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -433,9 +484,17 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
         if (FULL || q2 < B) {
             float val = z[r];
             if (li == D) val += 1e-20f;  // example/hept.py:14
-            pt[(size_t)dst * hr.hout * 32] = val;
+            if (pa.direct) {   // see block_attn_kernel
+                bool remote;
+                char* rowp = direct_row(pa, dst, h - hr.h0, 128, remote) + li * 4;
+                if (remote) store4_system(rowp, __float_as_uint(val));
+                else *reinterpret_cast<float*>(rowp) = val;
+            } else {
+                pt[(size_t)dst * hr.hout * 32] = val;
+            }
         }
     }
+    if (pa.direct) signal_when_all_done(pa.counter, pa.peers, pa.world, pa.flag_idx, pa.epoch);
 }
 
 template <bool FULL, int VP>
@@ -514,7 +573,7 @@ namespace {
 int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N, int H, int D,
                     int Tl, int B, int precision, const HeadRange& hr, float* part, void* stream,
                     const PushArgs* push = nullptr) {
-    if (!qhat || !kvhat || !qpos || !kpos || !part) return HEPT_ERR_ARG;
+    if (!qhat || !kvhat || !qpos || !kpos || (!part && !(push && push->direct))) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
         return HEPT_ERR_SHAPE;
     if (hr.h0 < 0 || hr.hg < 1 || hr.h0 + hr.hg > H || hr.hout < 1 || hr.hsub < 0 || hr.hsub > hr.h0 ||
@@ -525,8 +584,10 @@ int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, co
     PushArgs pa{};
     if (push) {
         pa = *push;
-        // the rows being sent must be in the format this launch's kernels write (the previous group's launch wrote them)
-        if (pa.push_wgs < 1) return HEPT_ERR_ARG;
+        // carried push: the rows being sent must be in the format this launch's kernels write (the previous group's
+        // launch wrote them); direct scatter: no pushing workgroups, one local table, the launch's heads = the group
+        if (pa.direct ? (pa.push_wgs != 0 || Tl != 1 || pa.h0 != hr.h0 || pa.hg != hr.hg) : pa.push_wgs < 1)
+            return HEPT_ERR_ARG;
     }
     const dim3 grid((unsigned)((size_t)Tl * nb * hr.hg + pa.push_wgs));
     hipStream_t st = (hipStream_t)stream;

@@ -328,24 +328,12 @@ extern "C" size_t hept_exchange_bytes(int N, int H, int D, int world, int precis
 }
 
 namespace {
-int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
-                         const int64_t* codes, const GeoShift& geo, const float* w_rpe, const float* alpha,
-                         const float* out_weight, const float* out_bias, int N, int H, int D, int C, int K, int T,
-                         int t0, int Tl, int B, int precision, int head_groups, int transport, void* workspace,
-                         size_t workspace_bytes, void* xbuf, size_t xbuf_bytes, float* out_full, void* stream) {
-    if (!comm || !q || !k || !v || !coords || !w_rpe || !alpha || !out_weight || !workspace || !out_full)
-        return HEPT_ERR_ARG;
-    const bool one_sided = transport == HEPT_TRANSPORT_ONE_SIDED;
-    if (!one_sided && (transport != HEPT_TRANSPORT_RCCL || !xbuf)) return HEPT_ERR_ARG;
-    int rc = hept_check_shape(N, H, D, C, Tl, B);
-    if (rc) return rc;
-    if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
-    if (head_groups < 1 || head_groups > HEPT_MAX_HEAD_GROUPS || H % head_groups != 0) return HEPT_ERR_SHAPE;
-    const Workspace w = carve(workspace, N, H, C, Tl, precision);
-    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
-    if (!one_sided && xbuf_bytes < hept_exchange_bytes(N, H, D, comm->world, precision)) return HEPT_ERR_ARG;
+int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
+                  const int64_t* codes, const GeoShift& geo, const float* w_rpe, const float* alpha,
+                  const float* out_weight, const float* out_bias, int N, int H, int D, int C, int K, int T, int t0,
+                  int Tl, int B, int precision, int head_groups, bool one_sided, const Workspace& w, void* xbuf,
+                  float* out_full, void* stream) {
     const P2pLayout lay = hept_p2p_layout(N, H, D, comm->world, precision);
-    if (one_sided && (!comm->p2p_open || comm->p2p_bytes < lay.bytes)) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int world = comm->world, hg = H / head_groups;
     const int per = (N + world - 1) / world, n_pad = per * world;
@@ -354,15 +342,32 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
     const size_t group_bytes = (size_t)n_pad * hg * row;       // one head group, all ranks' slices
     char* send = reinterpret_cast<char*>(xbuf);
     char* recv = one_sided ? comm->p2p_local + lay.recv_off : send + up256((size_t)n_pad * H * row);
-    if (one_sided) ++comm->epoch;
-    rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
+    int rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
     if (rc) return rc;
     const int pprec = hept_part_precision(precision, D);
     const bool direct = Tl == 1 && !one_sided;   // one local table: block_attn scatters straight into the send buffer
     const int32_t* qpos = w.pos;
     const int32_t* kpos = w.pos + (size_t)Tl * H * N;
     const bool rec = g_prof.mode == 1;
-    if (one_sided) {
+    if (one_sided && Tl == 1) {
+        // ONE local table (BASELINE config 4): nothing to sum, so nothing to carry -- the block attention of a head
+        // group stores every finished row straight into the receive buffer of the rank that owns the point (16-B
+        // pieces of 64-B rows, system-scope stores) and its last workgroup raises the flags.  The rows cross the
+        // links while the kernel runs; only the drain of the last stores is exposed.
+        for (int g = 0; g < head_groups; ++g) {
+            PushArgs pa;
+            rc = hept_p2p_direct_args(comm, N, H, D, g * hg, hg, g, aprec, lay, &pa);
+            if (rc) return rc;
+            if (rec) prof_mark(2, st);
+            rc = hept_block_attn_heads_push(w.qhat, w.kvhat, qpos, kpos, N, H, D, 1, B, precision, g * hg, hg, hg, g * hg,
+                                            n_pad, nullptr, &pa, stream);
+            if (rec) {
+                prof_mark(3, st);
+                prof_call_done();
+            }
+            if (rc) return rc;
+        }
+    } else if (one_sided) {
         // ONE stream, no events: the launch that computes head group g also carries, as its first workgroups, the
         // table sum + one-sided push of group g - 1 (link-bound work beside gather-bound work); the last group's
         // push has nothing left to ride on and runs alone.
@@ -433,7 +438,7 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
         // wait for the rows + combine + push of the output slice + output flag in one kernel, then gather
         rc = hept_p2p_combine_push(comm, head_groups, per, cnt, H, hg, aprec, out_weight, out_bias, lay, st);
         if (rc) return rc;
-        return hept_p2p_wait_copy_out(comm, n_pad, D, lay, out_full, st);
+        return hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, st);
     }
     if (one_sided) {
         rc = hept_p2p_wait_rows(comm, head_groups, st);
@@ -451,9 +456,51 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
     if (one_sided) {
         rc = hept_p2p_push_out(comm, per, D, lay, st);
         if (rc) return rc;
-        return hept_p2p_wait_copy_out(comm, n_pad, D, lay, out_full, st);
+        return hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, st);
     }
     return hept_comm_all_gather_f32(comm, out_full, (size_t)per * D, st);
+}
+
+int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
+                         const int64_t* codes, const GeoShift& geo, const float* w_rpe, const float* alpha,
+                         const float* out_weight, const float* out_bias, int N, int H, int D, int C, int K, int T,
+                         int t0, int Tl, int B, int precision, int head_groups, int transport, void* workspace,
+                         size_t workspace_bytes, void* xbuf, size_t xbuf_bytes, float* out_full, void* stream) {
+    // Everything that can be refused is refused BEFORE the step takes its epoch: a rank that bails out here has not
+    // moved, and the others time out against it once (and say so) instead of running one epoch apart for good.
+    if (!comm || !q || !k || !v || !coords || !w_rpe || !alpha || !out_weight || !workspace || !out_full)
+        return HEPT_ERR_ARG;
+    const bool one_sided = transport == HEPT_TRANSPORT_ONE_SIDED;
+    if (!one_sided && (transport != HEPT_TRANSPORT_RCCL || !xbuf)) return HEPT_ERR_ARG;
+    int rc = hept_check_shape(N, H, D, C, Tl, B);
+    if (rc) return rc;
+    if (t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
+    if (head_groups < 1 || head_groups > HEPT_MAX_HEAD_GROUPS || H % head_groups != 0) return HEPT_ERR_SHAPE;
+    if (K < 0 || (K > 0 && H * (C - 1) * K > 1024)) return HEPT_ERR_SHAPE;
+    const Workspace w = carve(workspace, N, H, C, Tl, precision);
+    if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
+    if (!one_sided && xbuf_bytes < hept_exchange_bytes(N, H, D, comm->world, precision)) return HEPT_ERR_ARG;
+    if (one_sided) {
+        const P2pLayout lay = hept_p2p_layout(N, H, D, comm->world, precision);
+        if (!comm->p2p_open || comm->p2p_bytes < lay.bytes) return HEPT_ERR_ARG;
+        if (head_groups * comm->world > 256) return HEPT_ERR_SHAPE;
+        // a wait of an EARLIER step timed out on this GPU (the kernel wrote the host-mapped status word; that step's
+        // output was NaN), or an earlier step failed after taking its epoch: the transport is out of step with its
+        // peers and refuses to run until every rank has called hept_comm_reset_status (TableSharding.check does)
+        if (const int bad = hept_p2p_failed(comm)) {
+            hept_comm_set_error("one-sided exchange",
+                                bad & 4 ? "an earlier step failed after taking its epoch; the transport needs hept_comm_reset_status on every rank"
+                                        : "a wait for a peer timed out in an earlier step (its output was NaN); the transport needs hept_comm_reset_status on every rank");
+            return HEPT_ERR_COMM;
+        }
+        ++comm->epoch;
+    }
+    rc = sharded_steps(comm, q, k, v, coords, codes, geo, w_rpe, alpha, out_weight, out_bias, N, H, D, C, K, T, t0, Tl, B,
+                       precision, head_groups, one_sided, w, xbuf, out_full, stream);
+    // a failure after the epoch was taken (a launch error half-way through the step): the peers will time out on this
+    // step, and this rank may have raised only some of its flags -- fatal for the transport until it is reset
+    if (rc && one_sided) comm->broken = true;
+    return rc;
 }
 }  // namespace
 

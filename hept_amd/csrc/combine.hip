@@ -126,6 +126,10 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         }
         __syncthreads();   // nobody reads a received row before every flag has been seen
     }
+    // a wait that timed out (now or in an earlier step: the status word is sticky) means some received rows may be
+    // unfinished: this rank's slice then goes out as NaN, so that no rank can take it for a result
+    bool poisoned = false;
+    if constexpr (PUSH) poisoned = status_bad(px.status);
     // The first tile's rows are requested BEFORE the weights are staged: every wave of the launch is resident at once
     // (one tile per wave at tracking-60k), so without this the whole chip spends the staging prologue (~3 us) with
     // no row in flight.
@@ -317,7 +321,8 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             for (int kk = 0; kk < 3; ++kk) {
                 const int c = lane + 64 * kk;            // 16-B piece c of the tile's 192: floats [4c, 4c + 4), row c / 6
                 if (c < rows * 6) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(push_s + 4 * c);
+                    u32x4 v = *reinterpret_cast<const u32x4*>(push_s + 4 * c);
+                    if (poisoned) v = u32x4{0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u};
                     for (int s = 0; s < px.world; ++s) store16_system(px.peers[s] + tile_off + (size_t)c * 16, v);
                 }
             }

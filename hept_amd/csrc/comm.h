@@ -24,7 +24,11 @@ struct hept_comm {
     char* p2p_peer[HEPT_MAX_RANKS] = {};  // every rank's buffer as mapped here (own rank: p2p_local)
     bool p2p_open = false;
     char** d_peer = nullptr;     // device copy of p2p_peer
-    unsigned int* d_state = nullptr;  // device words: [0..7] per-group completion counters, [8] output counter, [16] status
+    unsigned int* d_state = nullptr;  // device words: [0..7] per-group completion counters, [8] output counter, [16] status,
+                                      // [18, 19] device address of h_status (p2p_dev.h: HEPT_STATE_*)
+    unsigned int* h_status = nullptr; // host-mapped copy of the status word: a kernel whose wait timed out writes it
+    bool broken = false;              // a step failed on the host after it had taken its epoch: the ranks' epochs may
+                                      // differ, the transport refuses further steps until hept_comm_reset_status
     unsigned int epoch = 0;      // one per forward call, the same on every rank
     unsigned long long timeout_ticks = 0;  // bound of a device-side wait in wall_clock64 ticks (HEPT_P2P_TIMEOUT_S, 20 s)
 };
@@ -49,6 +53,10 @@ int hept_p2p_reduce_push(hept_comm* c, const float* part, int part_precision, in
 struct PushArgs;
 int hept_p2p_push_args(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0, int hg,
                        int g, int acc_precision, const P2pLayout& lay, int push_wgs, PushArgs* out);
+// one local table per rank: arguments of a block-attention launch that scatters its rows straight into the owners'
+// receive buffers and raises the flags itself (PushArgs::direct)
+int hept_p2p_direct_args(hept_comm* c, int N, int H, int D, int h0, int hg, int g, int acc_precision,
+                         const P2pLayout& lay, PushArgs* out);
 int hept_block_attn_heads_push(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
                                int H, int D, int Tl, int B, int precision, int h0, int hg, int hout, int hsub,
                                int n_rows_out, float* part, const PushArgs* push, void* stream);   // block_attn.hip
@@ -60,4 +68,6 @@ int hept_p2p_push_out(hept_comm* c, int per, int D, const P2pLayout& lay, hipStr
 int hept_p2p_combine_push(hept_comm* c, int head_groups, int per, int cnt, int H, int hg, int acc_precision,
                           const float* out_weight, const float* out_bias, const P2pLayout& lay, hipStream_t st);
 // wait for every rank's slice, then copy the gathered (n_pad, D) output to `dst`
-int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int D, const P2pLayout& lay, float* dst, hipStream_t st);
+// (rows [N, n_pad) are written as zeros; the whole output as NaN when a wait of the step timed out)
+int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int N, int D, const P2pLayout& lay, float* dst, hipStream_t st);
+int hept_p2p_failed(const hept_comm* c);   // non-zero: a wait timed out or a step failed mid-way (no device sync)

@@ -131,7 +131,13 @@ extern "C" int hept_comm_create_local(int rank, int world, hept_comm** out) {
 
 extern "C" int hept_comm_destroy(hept_comm* c) {
     if (!c) return HEPT_OK;
-    if (c->side) (void)hipStreamSynchronize(c->side);
+    // Everything this object owns belongs to c->device, and kernels of the caller's stream may still be storing into
+    // the peers' mappings or using d_state (the Python owner can be collected right after an asynchronous forward):
+    // make that device current and drain it before anything is unmapped or freed.
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
     hept_p2p_release(c);
     for (int i = 0; i < HEPT_MAX_HEAD_GROUPS; ++i)
         if (c->fork[i]) (void)hipEventDestroy(c->fork[i]);
@@ -140,6 +146,7 @@ extern "C" int hept_comm_destroy(hept_comm* c) {
     Rccl* r = rccl();
     if (r && c->nccl) (void)r->CommDestroy(static_cast<ncclComm_t>(c->nccl));
     delete c;
+    if (prev >= 0) (void)hipSetDevice(prev);
     return HEPT_OK;
 }
 

@@ -35,35 +35,46 @@ __global__ __launch_bounds__(256) void wait_rows_kernel(char* local, int head_gr
 }
 
 // this rank's slice of the output (already in its own `out` region) -> the same place in every other rank's buffer
+// (a slice computed after a timed-out wait goes out as NaN, see combine_out_kernel<PUSH>)
 __global__ __launch_bounds__(256) void push_out_kernel(char* const* peers, int world, int me, size_t slice_off,
-                                                       size_t slice_bytes, unsigned int epoch, unsigned int* counter) {
+                                                       size_t slice_bytes, unsigned int epoch, unsigned int* counter,
+                                                       const unsigned int* status) {
     const u32x4* src = reinterpret_cast<const u32x4*>(peers[me] + slice_off);
     const size_t n16 = slice_bytes / 16;
+    const bool poisoned = status_bad(status);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
-        const u32x4 v = src[i];
+        u32x4 v = src[i];
+        if (poisoned) v = u32x4{0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u};
         for (int s = 0; s < world; ++s)
             if (s != me) store16_system(peers[s] + slice_off + i * 16, v);
     }
     signal_when_all_done(counter, peers, world, OUT_FLAG_WORD + me, epoch);
 }
 
+// `bytes` = the whole (n_pad, D) output, `valid_bytes` = its first N rows: the padding rows are written as zeros (the
+// RCCL and torch transports zero them too; nobody stores them in the fused combine).  If any wait of this step -- here
+// or in an earlier kernel -- has timed out, the rows it announces may be unfinished: the WHOLE output is then written
+// as NaN, so that a lost or slow peer can never turn into plausible numbers (the host also finds the status word at
+// its next call, hept_forward_sharded returns HEPT_ERR_COMM from then on).
 __global__ __launch_bounds__(256) void wait_copy_out_kernel(char* local, int world, unsigned int epoch, size_t out_off,
-                                                            size_t bytes, float* __restrict__ dst,
+                                                            size_t bytes, size_t valid_bytes, float* __restrict__ dst,
                                                             unsigned int* status, unsigned long long timeout) {
     if (threadIdx.x < world) wait_flag(flag_word(local, OUT_FLAG_WORD + threadIdx.x), epoch, status, 2u, timeout);
     __syncthreads();
+    const bool bad = status_bad(status);
     const u32x4* src = reinterpret_cast<const u32x4*>(local + out_off);
     u32x4* out = reinterpret_cast<u32x4*>(dst);
-    const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n16 = bytes / 16, v16 = valid_bytes / 16, stride = (size_t)gridDim.x * blockDim.x;
+    const u32x4 nan4 = {0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u}, zero4 = {0u, 0u, 0u, 0u};
     // uncached reads have a long latency: four pieces in flight per thread
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += 4 * stride) {
         u32x4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i + u * stride < n16) v[u] = src[i + u * stride];
+            if (i + u * stride < v16 && !bad) v[u] = src[i + u * stride];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i + u * stride < n16) out[i + u * stride] = v[u];
+            if (i + u * stride < n16) out[i + u * stride] = bad ? nan4 : (i + u * stride < v16 ? v[u] : zero4);
     }
 }
 
@@ -96,9 +107,11 @@ void hept_p2p_release(hept_comm* c) {
     if (c->p2p_local) (void)hipFree(c->p2p_local);
     if (c->d_peer) (void)hipFree(c->d_peer);
     if (c->d_state) (void)hipFree(c->d_state);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     c->p2p_local = nullptr;
     c->d_peer = nullptr;
     c->d_state = nullptr;
+    c->h_status = nullptr;
     c->p2p_bytes = 0;
     c->p2p_open = false;
 }
@@ -126,6 +139,18 @@ extern "C" int hept_comm_p2p_alloc(hept_comm* c, size_t bytes, void* handle_out)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->d_peer), sizeof(char*) * HEPT_MAX_RANKS) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&c->d_state), sizeof(unsigned int) * 32) == hipSuccess;
     ok = ok && hipMemset(c->d_state, 0, sizeof(unsigned int) * 32) == hipSuccess;
+    // host-mapped copy of the status word (written by the device on a timeout only; read by the host before every step)
+    void* hs = nullptr;
+    ok = ok && hipHostMalloc(&hs, 64, hipHostMallocMapped) == hipSuccess;
+    if (ok) {
+        c->h_status = static_cast<unsigned int*>(hs);
+        *c->h_status = 0u;
+        void* dptr = nullptr;
+        ok = hipHostGetDevicePointer(&dptr, hs, 0) == hipSuccess;
+        const unsigned long long addr = reinterpret_cast<unsigned long long>(dptr);
+        ok = ok && hipMemcpy(c->d_state + HEPT_STATE_HOSTPTR, &addr, sizeof(addr), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    c->broken = false;
     hipIpcMemHandle_t h;
     __builtin_memset(&h, 0, sizeof(h));
     if (ok && c->world > 1 && hipIpcGetMemHandle(&h, p) != hipSuccess) {
@@ -170,7 +195,7 @@ extern "C" int hept_comm_p2p_open(hept_comm* c, const void* handles) {
         return HEPT_ERR_LAUNCH;
     // first launch out of this library in a fresh process loads its code object (seconds on a cold box): do it now,
     // not inside the first exchange, where the other ranks would be polling for this one
-    hipLaunchKernelGGL(wait_rows_kernel, dim3(1), dim3(64), 0, nullptr, c->p2p_local, 0, c->world, 0u, c->d_state + 16, 0ull);
+    hipLaunchKernelGGL(wait_rows_kernel, dim3(1), dim3(64), 0, nullptr, c->p2p_local, 0, c->world, 0u, c->d_state + HEPT_STATE_STATUS, 0ull);
     if (hipDeviceSynchronize() != hipSuccess) return HEPT_ERR_LAUNCH;
     c->p2p_open = true;
     return HEPT_OK;
@@ -192,17 +217,34 @@ extern "C" int hept_comm_status(hept_comm* c, int* status) {
     *status = 0;
     if (!c->d_state) return HEPT_OK;
     unsigned int v = 0;
-    if (hipMemcpy(&v, c->d_state + 16, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return HEPT_ERR_LAUNCH;
-    *status = (int)v;
+    if (hipMemcpy(&v, c->d_state + HEPT_STATE_STATUS, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return HEPT_ERR_LAUNCH;
+    *status = (int)v | (c->broken ? 4 : 0);   // bit 2: a step failed on the host after its epoch was taken
     return HEPT_OK;
 }
 
-// forget a recorded timeout (the caller has stopped using the one-sided transport, or wants to try again)
+// What the host can see without touching the device: non-zero once a device-side wait has timed out (the kernel that
+// timed out wrote the host-mapped word) or a step failed after taking its epoch.  hept_forward_sharded checks it first.
+int hept_p2p_failed(const hept_comm* c) {
+    if (!c) return 0;
+    unsigned int v = c->h_status ? __atomic_load_n(c->h_status, __ATOMIC_RELAXED) : 0u;
+    return (int)v | (c->broken ? 4 : 0);
+}
+
+// Forget a recorded failure and restart the protocol: status words cleared, epoch and every arrival flag and completion
+// counter back to zero.  COLLECTIVE by convention: after a failure the ranks' epochs may differ (a rank that failed
+// before taking its epoch is one behind for good), so every rank calls this, and the ranks meet at a host barrier
+// before the next exchange (TableSharding.check / tune do).  Synchronises the device.
 extern "C" int hept_comm_reset_status(hept_comm* c) {
     if (!c) return HEPT_ERR_ARG;
     if (!c->d_state) return HEPT_OK;
     if (hipDeviceSynchronize() != hipSuccess) return HEPT_ERR_LAUNCH;
-    return hipMemset(c->d_state + 16, 0, sizeof(unsigned int)) == hipSuccess ? HEPT_OK : HEPT_ERR_LAUNCH;
+    bool ok = hipMemset(c->d_state, 0, sizeof(unsigned int) * HEPT_STATE_HOSTPTR) == hipSuccess;
+    if (c->p2p_local) ok = ok && hipMemset(c->p2p_local, 0, HEPT_P2P_FLAG_BYTES) == hipSuccess;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
+    if (c->h_status) __atomic_store_n(c->h_status, 0u, __ATOMIC_RELAXED);
+    c->broken = false;
+    c->epoch = 0;
+    return ok ? HEPT_OK : HEPT_ERR_LAUNCH;
 }
 
 int hept_p2p_push_args(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0, int hg,
@@ -223,7 +265,19 @@ int hept_p2p_push_args(hept_comm* c, const float* part, int part_precision, int 
     a.counter = c->d_state + g;
     a.flag_idx = g * HEPT_MAX_RANKS + c->rank;
     a.push_wgs = push_wgs;
+    a.direct = 0;
     *out = a;
+    return HEPT_OK;
+}
+
+// one local table: the block-attention launch of head group g scatters its rows into the owners' buffers itself
+int hept_p2p_direct_args(hept_comm* c, int N, int H, int D, int h0, int hg, int g, int acc_precision,
+                         const P2pLayout& lay, PushArgs* out) {
+    static const float dummy = 0.f;   // (hept_p2p_push_args wants a row pointer; direct launches never read it)
+    int rc = hept_p2p_push_args(c, &dummy, acc_precision, 1, N, H, D, h0, hg, g, acc_precision, lay, 0, out);
+    if (rc) return rc;
+    out->part = nullptr;
+    out->direct = 1;
     return HEPT_OK;
 }
 
@@ -245,7 +299,7 @@ int hept_p2p_reduce_push(hept_comm* c, const float* part, int part_precision, in
 int hept_p2p_wait_rows(hept_comm* c, int head_groups, hipStream_t st) {
     if (!c || !c->p2p_open || head_groups * c->world > 256) return HEPT_ERR_ARG;
     hipLaunchKernelGGL(wait_rows_kernel, dim3(1), dim3(256), 0, st, c->p2p_local, head_groups, c->world, c->epoch,
-                       c->d_state + 16, c->timeout_ticks);
+                       c->d_state + HEPT_STATE_STATUS, c->timeout_ticks);
     return hept_launch_status();
 }
 
@@ -256,7 +310,7 @@ int hept_p2p_push_out(hept_comm* c, int per, int D, const P2pLayout& lay, hipStr
     const size_t blocks = (slice_bytes / 16 + 255) / 256;
     hipLaunchKernelGGL(push_out_kernel, dim3((unsigned)(blocks < 512 ? (blocks ? blocks : 1) : 512)), dim3(256), 0, st,
                        c->d_peer, c->world, c->rank, lay.out_off + (size_t)c->rank * slice_bytes, slice_bytes, c->epoch,
-                       c->d_state + 8);
+                       c->d_state + 8, c->d_state + HEPT_STATE_STATUS);
     return hept_launch_status();
 }
 
@@ -276,7 +330,7 @@ int hept_p2p_combine_push(hept_comm* c, int head_groups, int per, int cnt, int H
     px.me = c->rank;
     px.epoch = c->epoch;
     px.counter = c->d_state + 8;
-    px.status = c->d_state + 16;
+    px.status = c->d_state + HEPT_STATE_STATUS;
     px.timeout = c->timeout_ticks;
     px.wait_groups = head_groups;
     px.slice_off = lay.out_off + (size_t)c->rank * per * 24 * 4;
@@ -284,12 +338,13 @@ int hept_p2p_combine_push(hept_comm* c, int head_groups, int per, int cnt, int H
                              cnt, hg, (size_t)per * c->world * hg * row / 4, out_weight, out_bias, px, st);
 }
 
-int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int D, const P2pLayout& lay, float* dst, hipStream_t st) {
-    if (!c || !c->p2p_open || !dst) return HEPT_ERR_ARG;
-    const size_t bytes = (size_t)n_pad * D * 4;
-    if (bytes % 16 != 0) return HEPT_ERR_SHAPE;
+int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int N, int D, const P2pLayout& lay, float* dst, hipStream_t st) {
+    if (!c || !c->p2p_open || !dst || N > n_pad) return HEPT_ERR_ARG;
+    const size_t bytes = (size_t)n_pad * D * 4, valid = (size_t)N * D * 4;
+    if (bytes % 16 != 0 || valid % 16 != 0) return HEPT_ERR_SHAPE;
     const size_t blocks = (bytes / 16 + 255) / 256;
     hipLaunchKernelGGL(wait_copy_out_kernel, dim3((unsigned)(blocks < 1024 ? (blocks ? blocks : 1) : 1024)), dim3(256), 0,
-                       st, c->p2p_local, c->world, c->epoch, lay.out_off, bytes, dst, c->d_state + 16, c->timeout_ticks);
+                       st, c->p2p_local, c->world, c->epoch, lay.out_off, bytes, valid, dst, c->d_state + HEPT_STATE_STATUS,
+                       c->timeout_ticks);
     return hept_launch_status();
 }

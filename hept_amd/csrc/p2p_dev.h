@@ -32,6 +32,11 @@ struct PushArgs {
     unsigned int* counter;
     int flag_idx;
     int push_wgs;             // workgroups of the launch that push (the first ones of the grid); 0: none
+    // direct != 0 (one local table per rank, BASELINE config 4): nothing is summed and nothing is carried -- the block
+    // attention of heads [h0, h0 + hg) stores every finished row straight into the receive buffer of the rank that
+    // owns the point (direct_row below; `part`, `Tl`, `push_wgs` are unused), and the launch's last workgroup raises
+    // the flags.  No extra pass over the rows, no separate push: only the drain of the last stores is exposed.
+    int direct;
 };
 
 namespace {
@@ -53,15 +58,32 @@ __device__ __forceinline__ void store16_system(void* dst, const u32x4& v) {
     __hip_atomic_store(p + 1, ((unsigned long long)v[3] << 32) | v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// true when the flag has reached `epoch` (wrap-safe); false on timeout (status bit set)
+// The communicator's device words (hept_comm::d_state): `status` points at word HEPT_STATE_STATUS; the two words at
+// status + 2 hold the device address of a host-mapped copy of the status (hept_comm::h_status), written on the failure
+// path only, so that the host sees a timeout at its next call without synchronising the device.
+#define HEPT_STATE_STATUS 16
+#define HEPT_STATE_HOSTPTR 18
+__device__ __forceinline__ void record_timeout(unsigned int* status, unsigned int bit) {
+    atomicOr(status, bit);
+    unsigned int* host = reinterpret_cast<unsigned int*>(
+        (unsigned long long)status[HEPT_STATE_HOSTPTR - HEPT_STATE_STATUS] |
+        ((unsigned long long)status[HEPT_STATE_HOSTPTR - HEPT_STATE_STATUS + 1] << 32));
+    if (host) __hip_atomic_fetch_or(host, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool status_bad(const unsigned int* status) {
+    return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// true when the flag has reached `epoch` (wrap-safe); false on timeout (status bit set, sticky: every later wait
+// returns false at once, and every consumer of a wait's result poisons what it produces -- see wait_copy_out_kernel)
 __device__ __forceinline__ bool wait_flag(const unsigned int* flag, unsigned int epoch, unsigned int* status, unsigned int bit,
                                           unsigned long long timeout) {
-    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;  // sticky
+    if (status_bad(status)) return false;  // sticky
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > timeout) {
-            atomicOr(status, bit);
+            record_timeout(status, bit);
             return false;
         }
     }
@@ -95,6 +117,18 @@ __device__ __forceinline__ void signal_when_all_done(unsigned int* counter, char
     }
 }
 
+
+// direct mode: address of the partial row of point n, head h0 + hl, in the owner's receive buffer (same slot as
+// reduce_push_body's: recv[g][me][n - dest * per][hl]); `remote` = the owner is another rank (system-scope stores)
+__device__ __forceinline__ char* direct_row(const PushArgs& a, int n, int hl, int rowb, bool& remote) {
+    const int dest = n / a.per;
+    remote = dest != a.me;
+    return a.peers[dest] + a.recv_off + a.group_off + (((size_t)a.me * a.per + (n - dest * a.per)) * a.hg + hl) * rowb;
+}
+__device__ __forceinline__ void store4_system(void* dst, unsigned int v) {
+    typedef unsigned int __attribute__((address_space(1))) * gptr_t;
+    __hip_atomic_store((gptr_t)(reinterpret_cast<unsigned int*>(dst)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Rows of heads [h0, h0 + hg) summed over the local tables; the row of point n goes to rank s = n / per, slot
 // recv[g][me][n - s * per][h - h0].  One lane per 16-B piece of an output row (4 pieces per packed 64-B row, 8 per

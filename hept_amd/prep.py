@@ -243,7 +243,10 @@ def prepare_input_src_hip(x, coords, block_size: int, regions) -> Tuple[torch.Te
     regions_f = regions.to(device=dev, dtype=torch.float32).contiguous()
     coords_f = coords.float().contiguous()
     feat = int(x[0].numel()) if raw_size else 0
-    x_is_f32 = x.is_cuda and x.dtype == torch.float32 and feat > 0
+    # the HIP padding kernel is outside autograd: features that carry a gradient are padded by torch.cat, as in the
+    # reference (src/models/baselines/transformer.py:43-57), so that the gradient reaches the caller's tensor
+    x_is_f32 = (x.is_cuda and x.dtype == torch.float32 and feat > 0
+                and not (x.requires_grad and torch.is_grad_enabled()))
     x_f = x.reshape(raw_size, feat).contiguous() if x_is_f32 else None
     x_pad = torch.empty((n, feat), device=dev, dtype=torch.float32) if x_is_f32 else None
     coords_pad = torch.empty((n, coords.shape[1]), device=dev, dtype=torch.float32)

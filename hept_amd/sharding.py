@@ -216,27 +216,39 @@ class TableSharding:
         for tr in transports:
             for g in head_groups:
                 self.exchange, self.head_groups = tr, g
-                bad = 0
+                bad, dt = 0, 0.0
+
+                def run(count):
+                    """`count` steps; a failure on this rank is remembered, never raised past here: the sequence of
+                    collectives below (barrier, all_reduce) must be the same on every rank whatever happened"""
+                    nonlocal bad
+                    try:
+                        for _ in range(count):
+                            if not bad:
+                                step()
+                        torch.cuda.synchronize(device)
+                    except Exception:  # noqa: BLE001
+                        bad = 1
+
+                run(3)
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                run(steps)
+                dt = (time.perf_counter() - t0) / steps
                 try:
-                    for _ in range(3):
-                        step()
-                    torch.cuda.synchronize(device)
-                    dist.barrier(group=self.group)
-                    t0 = time.perf_counter()
-                    for _ in range(steps):
-                        step()
-                    torch.cuda.synchronize(device)
-                    dt = (time.perf_counter() - t0) / steps
                     self.check()
                 except Exception:  # noqa: BLE001
-                    bad, dt = 1, 0.0
+                    bad = 1
                 t = torch.tensor([dt, float(bad)], device=on, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 if t[1].item() == 0:
                     table[(tr, g)] = t[0].item()
                 elif tr == "p2p":
-                    self._p2p_failed = True   # on every rank (the flag was reduced): no further one-sided candidates
+                    # on every rank (the flag was reduced): no further one-sided candidates; the reset is collective
+                    # (epochs and flags restart together), and nobody stores into a buffer that is being cleared
+                    self._p2p_failed = True
                     lib.hept_comm_reset_status(self._native)
+                    dist.barrier(group=self.group)
                     break
         if table:
             self.exchange, self.head_groups = min(table, key=table.get)
@@ -282,11 +294,16 @@ class TableSharding:
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
-    def groups_for(self, n_heads: int) -> int:
-        """Head groups actually used for ``n_heads`` heads (equal groups only)."""
+    def groups_for(self, n_heads: int, local_tables: Optional[int] = None) -> int:
+        """Head groups actually used for ``n_heads`` heads (equal groups only).  One-sided transport with ONE local
+        table: the block attention stores its rows straight into the owners' buffers while it runs, so one launch
+        (one group) already overlaps the transfer with the computation."""
         want = self.head_groups
         if want is None:
-            want = 4 if (self._native and self.exchange == "p2p" and not self._p2p_failed) else 2
+            p2p = bool(self._native and self.exchange == "p2p" and not self._p2p_failed)
+            if local_tables is None:
+                local_tables = self.local_tables()[1]
+            want = (1 if local_tables == 1 else 4) if p2p else 2
         g = max(1, min(want, n_heads))
         while n_heads % g != 0:
             g -= 1

@@ -100,6 +100,23 @@ def test_more_tables_than_one_chunk(gpu_device):
             b = ops.forward_partial(*args, block_size=128, w_per_dist=10, t0=8, tl=2)
             whole = ops.forward_partial(*args, block_size=128, w_per_dist=10, t0=0, tl=10)
             torch.testing.assert_close(whole, a + b, rtol=2e-5, atol=1e-30)  # ((t0..t7) + t8) + t9 vs (t0..t7) + (t8 + t9)
+            # ... and the TRAINING path takes more than one chunk of tables too (same values, gradients against the
+            # oracle's autograd)
+            m.train()
+            qg = g["q"].clone().requires_grad_(True)
+            out_t = m(qg, g["k"], g["v"], w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+            ok = ((out_t.detach().cpu() - ref).abs() <= atol + rtol * ref.abs()).all(-1).float().mean().item()
+            assert ok >= 0.99, ok
+            gup = torch.randn(out_t.shape, generator=torch.Generator().manual_seed(5))
+            (out_t * gup.to(gpu_device)).sum().backward()
+            qc = inp["q"].clone().requires_grad_(True)
+            o = ho.forward(qc, inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
+                           inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=128, w_per_dist=10, keep=False,
+                           grad=True)["out"]
+            (o * gup).sum().backward()
+            scale = float(qc.grad.abs().max())
+            assert float(((qg.grad.cpu() - qc.grad).abs() <= 2e-4 * scale).float().mean()) >= 0.99
+            m.eval()
 
 
 @pytest.mark.parametrize("variant", ["example", "src"])

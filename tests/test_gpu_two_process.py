@@ -115,7 +115,7 @@ def test_sharded_training_matches_single_process(gpu_device):
 _SIZES = [int(os.environ["HEPT_TEST_BIG"])] if os.environ.get("HEPT_TEST_BIG") else [1500, 700]
 
 
-def _synthetic_worker(rank, world, port, precision, exchange, ret):
+def _synthetic_worker(rank, world, port, precision, exchange, ret, groups=2):
     """BASELINE config 4 in miniature: n_hashes = world, one table per rank, the production exchange."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -131,7 +131,7 @@ def _synthetic_worker(rank, world, port, precision, exchange, ret):
         g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
         m = HEPTAttention(30, h_dim=24, num_heads=8, block_size=128, n_hashes=world, num_w_per_dist=10,
                           precision=precision, process_group=dist.group.WORLD)
-        m.sharding = TableSharding(world, dist.group.WORLD, mode="all_to_all", head_groups=2)
+        m.sharding = TableSharding(world, dist.group.WORLD, mode="all_to_all", head_groups=groups)
         m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
                            "e2lsh.alpha": inp["alpha"]})
         m = m.to(dev).eval()
@@ -147,19 +147,21 @@ def _synthetic_worker(rank, world, port, precision, exchange, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_eight_ranks_one_table_each_match_the_unsharded_operator(precision, gpu_device):
+@pytest.mark.parametrize("precision,groups", [("fp32", 2), ("bf16", 2), ("bf16", None), ("mixed16", 1)])
+def test_eight_ranks_one_table_each_match_the_unsharded_operator(precision, groups, gpu_device):
     """8 processes (sharing this GPU), n_hashes = 8, one table per rank, rows exchanged with the one-sided transport
-    (buffers mapped across processes through HIP IPC) -- against the plain operator on all 8 tables."""
+    (buffers mapped across processes through HIP IPC) -- against the plain operator on all 8 tables.  One table per
+    rank takes the DIRECT path: the block attention stores its rows straight into the owners' receive buffers and
+    raises the flags itself (no table sum, no separate push); groups = None is the transport's own choice (1 launch)."""
     world = 8
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_synthetic_worker, args=(world, port, precision, "p2p", ret), nprocs=world, join=True)
+    mp.spawn(_synthetic_worker, args=(world, port, precision, "p2p", ret, groups), nprocs=world, join=True)
     assert all(torch.equal(ret[0][0], ret[r][0]) for r in range(1, world))
-    assert "one-sided" in ret[0][1]
+    assert "one-sided" in ret[0][1] and (groups is not None or "in auto head" in ret[0][1])
     from hept_amd import ops
     from hept_amd.synthetic import make_inputs
 
@@ -198,3 +200,70 @@ def test_processes_sharing_one_gpu(world, mode, precision, gpu_device):
         assert bool((err <= 4e-3 * (plain.abs().amax(-1) + 1e-2)).all())
     else:
         torch.testing.assert_close(ret[0], plain, rtol=1e-5, atol=1e-6)
+
+
+def _lost_peer_worker(rank, world, port, ret):
+    """Two ranks, one table each; after two good steps rank 1 stops taking part.  Rank 0's next step must not return
+    plausible numbers: its waits time out (HEPT_P2P_TIMEOUT_S), the output is NaN, check() raises, and the step after
+    that is refused by the C call without touching the GPU."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HEPT_EXCHANGE"] = "p2p"
+    os.environ["HEPT_P2P_TIMEOUT_S"] = "1.0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hept_amd import HEPTAttention
+        from hept_amd.sharding import TableSharding
+        from hept_amd.synthetic import make_inputs
+
+        dev = torch.device("cuda", 0)
+        inp = make_inputs([700, 300], block_size=128, n_hashes=world, seed=5, cluster_size=8)
+        g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+        m = HEPTAttention(30, h_dim=24, num_heads=8, block_size=128, n_hashes=world, num_w_per_dist=10,
+                          precision="bf16", process_group=dist.group.WORLD)
+        m.sharding = TableSharding(world, dist.group.WORLD, mode="all_to_all")
+        m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
+                           "e2lsh.alpha": inp["alpha"]})
+        m = m.to(dev).eval()
+        w_rpe = torch.nn.Linear(50, 192).to(dev)
+        kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+        with torch.no_grad():
+            w_rpe.weight.copy_(g["w_rpe_weight"])
+            for _ in range(2):
+                good = m(g["q"], g["k"], g["v"], **kw)
+            torch.cuda.synchronize()
+            m.sharding.check()
+            dist.barrier()
+            res = {"good_finite": bool(torch.isfinite(good).all())}
+            if rank == 0:
+                lost = m(g["q"], g["k"], g["v"], **kw)     # rank 1 never comes
+                torch.cuda.synchronize()
+                res["lost_all_nan"] = bool(torch.isnan(lost).all())
+                try:
+                    m(g["q"], g["k"], g["v"], **kw)
+                    res["refused"] = "no"
+                except RuntimeError as exc:
+                    res["refused"] = str(exc)
+                try:
+                    m.sharding.check()
+                    res["check"] = "no"
+                except RuntimeError as exc:
+                    res["check"] = str(exc)
+            dist.barrier()
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_lost_peer_poisons_the_output_and_is_reported(gpu_device):
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_lost_peer_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0]["good_finite"] and ret[1]["good_finite"]
+    assert ret[0]["lost_all_nan"] is True
+    assert "HEPT_ERR_COMM" in ret[0]["refused"] and "timed out" in ret[0]["refused"]
+    assert "timed out" in ret[0]["check"]
