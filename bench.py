@@ -373,6 +373,31 @@ def worker(args) -> int:
                 "traffic_source": source, "mfma_busy_frac": busy,
                 "algorithmic_tflops": flops / (attn_ms * 1e-3) / 1e12, "mfma_bf16_peak_tflops": MFMA_BF16_PEAK_TF}
 
+    def exchange_record(attn, step, steps=30):
+        """What ran between the GPUs, said by the objects that ran it: the transport and head groups after the ladder
+        and tuning, the world size of the communicator that moved the rows (hept_comm_world -- not torch's process
+        group), and per-term HIP-event times of the sharded step (one extra, untimed pass with every stage bracketed:
+        exposed push / transfer of the last head group, combine, output gather)."""
+        sh = attn.sharding
+        rec = {"describe": sh.describe(), "head_groups": launches_per_step(attn), "comm_world": 0, "transport": "torch.distributed"}
+        if sh._native:
+            from hept_amd import _lib
+
+            rec["comm_world"] = int(_lib.load().hept_comm_world(sh._native))
+            rec["transport"] = "rccl" if (sh._p2p_failed or sh.exchange == "rccl") else "one-sided"
+            ops.profile_enable(2, steps + 2)
+            fence()
+            for _ in range(steps):
+                step()
+            fence()
+            ms, cnt = ops.profile_read()
+            ops.profile_enable(1, (max(args.steps, sub_cap) + 2) * (8 if multi else 1), stride=NO_SAMPLES)
+            if cnt:
+                us = {k: v / cnt * 1e3 for k, v in ms.items()}
+                rec.update(samples=cnt, prep_us=us["prep_hash"], sort_us=us["sort_tables"], block_attn_us=us["block_attn"],
+                           exposed_push_us=us["combine"], combine_us=us["sharded_combine"], gather_us=us["sharded_gather"])
+        return rec
+
     tables_per_gpu = args.tables_per_gpu
     inp, attn, step = build(tables_per_gpu, args.precision)
     n, n_raw, C = inp["q"].shape[0], inp["n_raw"], inp["coords"].shape[1]
@@ -442,6 +467,9 @@ def worker(args) -> int:
                              "ms_per_step": el / sub_steps * 1e3, "value": world * n_raw / (el / sub_steps),
                              "unit": "points/s (N_gpus * N_raw / step time, one table pass per point and GPU)",
                              "steps": sub_steps, "block_attn_ms": ams}
+                if multi:
+                    sub["c4"]["exchange"] = exchange_record(attn4, step4)
+                    attn4.sharding.check()
                 del attn4, step4
         return sub
 
@@ -455,8 +483,11 @@ def worker(args) -> int:
     # ---------------------------------------------------------------------------------------------- headline region
     elapsed, attn_ms, n_rec = measure(step, args.steps, args.warmup, launches_per_step(attn))
     ms_per_step = elapsed / args.steps * 1e3
+    exch = None
     if multi:
         attn.sharding.check()   # a one-sided wait that timed out inside the region voids the measurement
+        exch = exchange_record(attn, step)
+        attn.sharding.check()
 
     if args.stages and rank == 0:
         ops.profile_enable(2, args.steps)
@@ -490,10 +521,16 @@ def worker(args) -> int:
                                    f"({n_tables} total), H={H}, D={D}, C={C}, tiles {args.precision}",
                        "parallelism": f"tables sharded {tables_per_gpu}/GPU over {world} GPU(s)" +
                                       (f", exchange {attn.sharding.describe()}" if multi else ""),
+                       # ranks of torch's RCCL process group (rendezvous, barriers) ...
                        "rccl_ranks": (dist.get_world_size() if multi and backend == "nccl" else 0),
+                       # ... and of the communicator that actually moved the rows (0: torch.distributed collectives)
+                       "comm_world": exch["comm_world"] if exch else 0,
+                       "transport": exch["transport"] if exch else None,
                        "hbm_algorithmic_GBps_block_attn": roof["achieved"]},
             "roofline": roof,
         }
+        if exch:
+            line["exchange"] = exch
     del attn, step
     if multi:
         sub = sub_records()

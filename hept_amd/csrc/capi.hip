@@ -50,10 +50,12 @@ Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
 }
 
 // ---- optional stage timing (hept_profile_*): a pool of HIP events recorded on the caller's stream
+constexpr int PROF_SLOTS = 7;   // events per call: 6 stages (the table-sharded call has two more than hept_forward)
 struct Profiler {
     int mode = 0, max_calls = 0, n_calls = 0;
     int stride = 1, seen = 0;  // only every `stride`-th forward call is bracketed
-    hipEvent_t* ev = nullptr;  // [max_calls][5]
+    hipEvent_t* ev = nullptr;  // [max_calls][PROF_SLOTS]
+    int* last = nullptr;       // [max_calls] highest slot recorded in the call
 } g_prof;
 
 inline bool prof_active() {
@@ -62,7 +64,10 @@ inline bool prof_active() {
 inline void prof_mark(int slot, hipStream_t st) {
     if (!prof_active()) return;
     if (g_prof.mode == 1 && slot != 2 && slot != 3) return;
-    (void)hipEventRecord(g_prof.ev[(size_t)g_prof.n_calls * 5 + slot], st);
+    (void)hipEventRecord(g_prof.ev[(size_t)g_prof.n_calls * PROF_SLOTS + slot], st);
+    int& last = g_prof.last[g_prof.n_calls];
+    const bool opens = slot == (g_prof.mode == 1 ? 2 : 0);   // first event of a call: the pool entry is reused
+    if (opens || slot > last) last = slot;
 }
 inline void prof_call_done() {
     if (prof_active()) ++g_prof.n_calls;
@@ -349,6 +354,7 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
     const int32_t* qpos = w.pos;
     const int32_t* kpos = w.pos + (size_t)Tl * H * N;
     const bool rec = g_prof.mode == 1;
+    const bool rec_all = g_prof.mode == 2;   // stage times of the whole sharded step (bench.py: exchange terms)
     if (one_sided && Tl == 1) {
         // ONE local table (BASELINE config 4): nothing to sum, so nothing to carry -- the block attention of a head
         // group stores every finished row straight into the receive buffer of the rank that owns the point (16-B
@@ -366,6 +372,10 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
                 prof_call_done();
             }
             if (rc) return rc;
+        }
+        if (rec_all) {
+            prof_mark(3, st);   // end of the (last) attention launch = the rows have been stored and flagged
+            prof_mark(4, st);   // no separate push
         }
     } else if (one_sided) {
         // ONE stream, no events: the launch that computes head group g also carries, as its first workgroups, the
@@ -389,9 +399,11 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
             }
             if (rc) return rc;
         }
+        if (rec_all) prof_mark(3, st);
         rc = hept_p2p_reduce_push(comm, w.part, pprec, Tl, N, H, D, (head_groups - 1) * hg, hg, head_groups - 1, aprec,
                                   lay, st);
         if (rc) return rc;
+        if (rec_all) prof_mark(4, st);   // the exposed push: table sum + rows of the last head group
     }
     // RCCL transport.  Caller's stream: the block attention of the head groups back to back.  Side stream: for every
     // group but the last, wait for its attention, sum the local tables into the send buffer and put it on the links.
@@ -417,6 +429,7 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
             prof_call_done();
         }
         if (rc) return rc;
+        if (rec_all && last) prof_mark(3, st);
         hipStream_t xs = last ? st : comm->side;
         if (!last && (hipEventRecord(comm->fork[g], st) != hipSuccess ||
                       hipStreamWaitEvent(comm->side, comm->fork[g], 0) != hipSuccess))
@@ -431,6 +444,7 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
     if (!one_sided && head_groups > 1 &&
         (hipEventRecord(comm->join, comm->side) != hipSuccess || hipStreamWaitEvent(st, comm->join, 0) != hipSuccess))
         return HEPT_ERR_LAUNCH;
+    if (rec_all && !one_sided) prof_mark(4, st);   // the exposed transfer: last group's table sum + all-to-all (+ join)
     // this rank's points [rank * per, ...): the `world` received slices are the "tables" of the combine
     const int first = comm->rank * per;
     const int cnt = first >= N ? 0 : (N - first < per ? N - first : per);
@@ -438,7 +452,13 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
         // wait for the rows + combine + push of the output slice + output flag in one kernel, then gather
         rc = hept_p2p_combine_push(comm, head_groups, per, cnt, H, hg, aprec, out_weight, out_bias, lay, st);
         if (rc) return rc;
-        return hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, st);
+        if (rec_all) prof_mark(5, st);   // wait for the rows + combine + output slice to every rank
+        rc = hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, st);
+        if (rec_all) {
+            prof_mark(6, st);            // wait for every rank's slice + copy out
+            prof_call_done();
+        }
+        return rc;
     }
     if (one_sided) {
         rc = hept_p2p_wait_rows(comm, head_groups, st);
@@ -456,9 +476,17 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
     if (one_sided) {
         rc = hept_p2p_push_out(comm, per, D, lay, st);
         if (rc) return rc;
-        return hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, st);
+        if (rec_all) prof_mark(5, st);
+        rc = hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, st);
+    } else {
+        if (rec_all) prof_mark(5, st);
+        rc = hept_comm_all_gather_f32(comm, out_full, (size_t)per * D, st);
     }
-    return hept_comm_all_gather_f32(comm, out_full, (size_t)per * D, st);
+    if (rec_all) {
+        prof_mark(6, st);
+        prof_call_done();
+    }
+    return rc;
 }
 
 int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
@@ -569,17 +597,20 @@ extern "C" int hept_attn_block_forward(const float* x, const float* coords, cons
 extern "C" int hept_profile_enable(int mode, int max_calls) {
     if (mode < 0 || mode > 2 || max_calls < 0) return HEPT_ERR_ARG;
     if (g_prof.ev) {
-        for (size_t i = 0; i < (size_t)g_prof.max_calls * 5; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+        for (size_t i = 0; i < (size_t)g_prof.max_calls * PROF_SLOTS; ++i) (void)hipEventDestroy(g_prof.ev[i]);
         delete[] g_prof.ev;
+        delete[] g_prof.last;
         g_prof.ev = nullptr;
+        g_prof.last = nullptr;
     }
     g_prof.mode = mode;
     g_prof.n_calls = 0;
     g_prof.seen = 0;
     g_prof.max_calls = mode ? max_calls : 0;
     if (g_prof.max_calls) {
-        g_prof.ev = new hipEvent_t[(size_t)g_prof.max_calls * 5];
-        for (size_t i = 0; i < (size_t)g_prof.max_calls * 5; ++i)
+        g_prof.ev = new hipEvent_t[(size_t)g_prof.max_calls * PROF_SLOTS];
+        g_prof.last = new int[g_prof.max_calls]();
+        for (size_t i = 0; i < (size_t)g_prof.max_calls * PROF_SLOTS; ++i)
             if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return HEPT_ERR_LAUNCH;
     }
     return HEPT_OK;
@@ -594,11 +625,12 @@ extern "C" int hept_profile_stride(int stride) {
 
 extern "C" int hept_profile_read(float* ms, int* n_calls) {
     if (!ms || !n_calls) return HEPT_ERR_ARG;
-    for (int i = 0; i < 4; ++i) ms[i] = 0.f;
+    for (int i = 0; i < PROF_SLOTS - 1; ++i) ms[i] = 0.f;
     *n_calls = g_prof.n_calls;
     for (int c = 0; c < g_prof.n_calls; ++c) {
-        hipEvent_t* e = g_prof.ev + (size_t)c * 5;
-        const int first = g_prof.mode == 1 ? 2 : 0, last = g_prof.mode == 1 ? 3 : 4;
+        hipEvent_t* e = g_prof.ev + (size_t)c * PROF_SLOTS;
+        const int first = g_prof.mode == 1 ? 2 : 0, last = g_prof.mode == 1 ? 3 : g_prof.last[c];
+        if (last <= first) continue;
         if (hipEventSynchronize(e[last]) != hipSuccess) return HEPT_ERR_LAUNCH;
         for (int sidx = first; sidx < last; ++sidx) {
             float dt = 0.f;

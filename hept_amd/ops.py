@@ -685,7 +685,9 @@ def profile_read() -> Tuple[Dict[str, float], int]:
     """Summed milliseconds per stage over the recorded calls, and the number of calls; resets the pool."""
     import ctypes
 
-    ms = (ctypes.c_float * 4)()
+    ms = (ctypes.c_float * 6)()
     n = ctypes.c_int(0)
     _lib.check(_lib.load().hept_profile_read(ms, ctypes.byref(n)), "hept_profile_read")
-    return dict(zip(("prep_hash", "sort_tables", "block_attn", "combine"), [float(x) for x in ms])), int(n.value)
+    # (the sharded call: "combine" = the exposed push / transfer of the last head group, then its own two stages)
+    return dict(zip(("prep_hash", "sort_tables", "block_attn", "combine", "sharded_combine", "sharded_gather"),
+                    [float(x) for x in ms])), int(n.value)

@@ -294,16 +294,17 @@ class TableSharding:
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
-    def groups_for(self, n_heads: int, local_tables: Optional[int] = None) -> int:
+    def groups_for(self, n_heads: int) -> int:
         """Head groups actually used for ``n_heads`` heads (equal groups only).  One-sided transport with ONE local
         table: the block attention stores its rows straight into the owners' buffers while it runs, so one launch
         (one group) already overlaps the transfer with the computation."""
         want = self.head_groups
         if want is None:
             p2p = bool(self._native and self.exchange == "p2p" and not self._p2p_failed)
-            if local_tables is None:
-                local_tables = self.local_tables()[1]
-            want = (1 if local_tables == 1 else 4) if p2p else 2
+            # (every rank must arrive at the same count: the receive buffers are laid out by head group -- so the
+            #  choice rests on the table count of the whole group, not on this rank's share)
+            one_each = self.n_tables == self.world
+            want = (1 if one_each else 4) if p2p else 2
         g = max(1, min(want, n_heads))
         while n_heads % g != 0:
             g -= 1

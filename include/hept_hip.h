@@ -378,10 +378,12 @@ int hept_prepare_input_src(const float* x, int F, const float* coords, int C, in
 /* Optional stage timing with HIP events recorded on the caller's stream inside hept_forward /
  * hept_forward_partial (nothing like it exists in the reference; used by bench.py for the roofline).
  * mode 0: off (default).  mode 1: bracket the block_attn kernel only (2 events per call).
- * mode 2: bracket all four stages (5 events per call).  `max_calls` sizes the event pool; calls
- * beyond it are not recorded.  hept_profile_read waits for the recorded events, adds up the
- * elapsed milliseconds per stage [prep(+rpe), sort, block_attn, combine/reduce] over the recorded
- * calls into ms[4], stores the number of calls in *n_calls and resets the pool. */
+ * mode 2: bracket every stage (5 events per hept_forward call, 7 per hept_forward_sharded call).  `max_calls`
+ * sizes the event pool; calls beyond it are not recorded.  hept_profile_read waits for the recorded events, adds
+ * up the elapsed milliseconds per stage over the recorded calls into ms[6] -- [prep (with the RPE weight math),
+ * sort, block_attn, combine/reduce, 0, 0] for hept_forward, [prep, sort, block_attn (all head groups, with the pushes
+ * they carry), exposed push or transfer of the last head group, combine (+ output slice to the ranks), output
+ * gather] for hept_forward_sharded -- stores the number of calls in *n_calls and resets the pool. */
 int hept_profile_enable(int mode, int max_calls);
 int hept_profile_read(float* ms, int* n_calls);
 /* Bracket only every `stride`-th forward call (default 1): an event pair costs a few microseconds of

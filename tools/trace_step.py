@@ -23,7 +23,7 @@ if how != "plain":
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     group = dist.group.WORLD
 wl = os.environ.get("HEPT_TRACE_WORKLOAD", "tracking-60k")
-inp = workload_inputs(wl, seed=0)
+inp = workload_inputs(wl, seed=0, **({"n_hashes": int(os.environ["HEPT_TRACE_TABLES"])} if os.environ.get("HEPT_TRACE_TABLES") else {}))
 from hept_amd.synthetic import WORKLOADS  # noqa: E402
 g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
 w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], 192).to(dev)
