@@ -15,17 +15,20 @@
 // where [kmin,kmax] = [hash min, hash max + largest code * span] is known before any key exists (from the
 // prep kernel's partials).  id() is a monotone non-decreasing function of the key itself (fp32 subtract,
 // multiply and truncate are monotone), so id order never contradicts key order and equal keys share an id.
-//   K1 keygen       key -> order-preserving u32, per-chunk histogram of the top HEPT_TOP_BITS id bits
-//   K3 scatter      counting pass on the top bits: every workgroup reduces its segment's chunk histograms to its own
-//                   global offsets (no separate scan kernel), bucket-sorts its 4096-key chunk inside LDS (slot = LDS
-//                   atomic on the digit counter) and writes runs of consecutive (key,index) pairs
-//   K4 bucket sort  one workgroup per (segment, bucket): histogram / prefix / scatter on the LOW id bits inside LDS
-//                   groups the pairs by their full id, then every pair counts the members of its id group that are
-//                   smaller as u64 (key << 32 | index) -> final position.  Groups are 1-3 pairs.
+//   KA chunk sort   one workgroup per 4096-key chunk of a segment: keys (two rounded ops) -> (key, low id, index) pairs,
+//                   digit-sorted by the top HEPT_TOP_BITS id bits inside LDS (slot = LDS atomic on the digit counter)
+//                   and written back IN PLACE as one linear run, next to the chunk's 257-entry digit offset table.
+//                   No key array, no global histogram, no cross-workgroup prefix.
+//   KB bucket sort  one workgroup per (segment, bucket): collects the bucket's pairs from the n_chunks runs (its final
+//                   position range starts at the sum of the chunks' offsets of its digit), then histogram / prefix /
+//                   scatter on the LOW id bits inside LDS groups the pairs by their full id, and every pair counts the
+//                   members of its id group that are smaller as u64 (key << 32 | index) -> final position.  Groups are
+//                   1-3 pairs.
 // The result is the exact stable sort for ANY input; cost O(N + sum group^2).  Adversarial inputs (all keys
 // inside 2^-bits of the range) degrade to O(N^2) compares per segment -- slow, never wrong.
 // History (tracking-60k, 48 segments x 60 032 keys): 4-pass LSD radix 144 us -> two 8-bit LSD passes + windowed
-// neighbour rank 89 us -> this design 44 us.
+// neighbour rank 89 us -> keygen / scatter / bucket sort 40 us (three launches, 11.5 MB of keys and 23 MB of pairs
+// written and read back) -> this design (two launches, keys never leave the chip).
 #include "common.h"
 
 namespace {
@@ -69,219 +72,179 @@ __device__ __forceinline__ unsigned int bucket_id(unsigned int u, float kmin, fl
     return (unsigned int)(b < 0 ? 0 : b);
 }
 
-// per-segment id map parameters, written once by K1 (chunk 0) and read by the later kernels
+// per-segment id map parameters, written once by KA (chunk 0) and read by KB
 struct SegParams {
     float kmin, scale;
 };
 
-// K1: keys0[seg][n] = ordered bits of (proj + float(code) * span); hist[seg][chunk][256] of the low id byte.
-// SRC = true: the src variant's float shift (get_geo_shift, src/models/attention/hept.py:46-56) replaces
-// float(code) * span:  shift = (phi * span) * cfac + eta * span, every operation rounded on its own; the
-// key bound uses the third partial column as max(phi * cfac + eta).
-template <bool SRC>
-__global__ __launch_bounds__(SORT_THREADS) void keygen_hist_kernel(
-    const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
-    const float* __restrict__ eta_idx, const float* __restrict__ phi_idx, const float* __restrict__ cfac,
-    const float* __restrict__ minmax, int N, int H, int t0, int Tl, unsigned int* __restrict__ keys0,
-    unsigned int* __restrict__ hist, SegParams* __restrict__ seg_params, int n_chunks) {
-    __shared__ unsigned int h_s[RADIX];
-    __shared__ float red_s[3][SORT_WAVES];
-    const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
-    const int th = seg % (Tl * H);  // local (table, head)
-    const bool is_k = seg >= Tl * H;
-    const int t = th / H, h = th % H;
-    h_s[tid] = 0;
-
-    // hash range + largest code of this (table, head): reduce the prep kernel's per-workgroup partials
-    float lo = INFINITY, hi = -INFINITY, cmax = 0.f;
-    {
-        f32x4 m[HEPT_PREP_GRID / SORT_THREADS];
-#pragma unroll
-        for (int i = 0; i < HEPT_PREP_GRID / SORT_THREADS; ++i)
-            m[i] = *reinterpret_cast<const f32x4*>(minmax + (((size_t)t * H + h) * HEPT_PREP_GRID + i * SORT_THREADS + tid) * 4);
-#pragma unroll
-        for (int i = 0; i < HEPT_PREP_GRID / SORT_THREADS; ++i) {
-            lo = fminf(lo, m[i][0]);
-            hi = fmaxf(hi, m[i][1]);
-            cmax = fmaxf(cmax, m[i][2]);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, off));
-        hi = fmaxf(hi, __shfl_xor(hi, off));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, off));
-    }
-    if ((tid & 63) == 0) { red_s[0][tid >> 6] = lo; red_s[1][tid >> 6] = hi; red_s[2][tid >> 6] = cmax; }
-    __syncthreads();
-    lo = fminf(fminf(red_s[0][0], red_s[0][1]), fminf(red_s[0][2], red_s[0][3]));
-    hi = fmaxf(fmaxf(red_s[1][0], red_s[1][1]), fmaxf(red_s[1][2], red_s[1][3]));
-    cmax = fmaxf(fmaxf(red_s[2][0], red_s[2][1]), fmaxf(red_s[2][2], red_s[2][3]));
-    const float span = hi - lo;
-    // keys lie in [lo, hi + cmax*span] (codes >= 0); any key outside is clamped by bucket_id (still monotone)
-    const float width = (hi + cmax * span) - lo;
-    float scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
-    if (!(scale < 3.0e38f)) scale = 0.f;  // inf/nan guard for denormal widths: one bucket, still exact
-    if (chunk == 0 && tid == 0) seg_params[seg] = SegParams{lo, scale};
-
-    const float* proj = (is_k ? kproj : qproj) + (size_t)th * N;
-    const size_t row_off = ((size_t)(t0 + t) * H + h) * N;
-    unsigned int* kout = keys0 + (size_t)seg * N;
-    const int base = chunk * SORT_CHUNK;
-    if constexpr (SRC) {
-        const float cf = cfac[(size_t)(t0 + t) * H + h];
-        const float* eta = eta_idx + row_off;
-        const float* phi = phi_idx + row_off;
-#pragma unroll 4
-        for (int i = 0; i < SORT_ITEMS; ++i) {
-            const int n = base + i * SORT_THREADS + tid;
-            if (n < N) {
-                float t1 = eta[n] * span;
-                asm volatile("" : "+v"(t1));
-                float t2 = phi[n] * span;
-                asm volatile("" : "+v"(t2));
-                t2 = t2 * cf;
-                asm volatile("" : "+v"(t2));
-                float t3 = t2 + t1;
-                asm volatile("" : "+v"(t3));
-                const unsigned int u = ordered_bits(proj[n] + t3);
-                kout[n] = u;
-                atomicAdd(&h_s[bucket_id(u, lo, scale) >> TOP_SHIFT], 1u);
-            }
-        }
-        __syncthreads();
-        hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
-        return;
-    }
-    const int64_t* code = codes + row_off;
-    // two separately rounded ops per key, as the two eager ops of the reference; HIP's __fmul_rn /
-    // __fadd_rn are plain * and + and would be contracted to one fma without -ffp-contract=off
-    // (Makefile) -- the asm barrier makes it explicit here as well
-    auto make_key = [&](float pj, long long cd) {
-        float off = (float)cd * span;
-        asm volatile("" : "+v"(off));
-        return ordered_bits(pj + off);
-    };
-    const bool vec_ok = (N % 4) == 0;  // segment bases stay 16-B aligned
-#pragma unroll
-    for (int i = 0; i < SORT_ITEMS / 4; ++i) {
-        const int n = base + (i * SORT_THREADS + tid) * 4;
-        if (vec_ok && n + 3 < N) {
-            typedef __attribute__((ext_vector_type(2))) long long i64x2;
-            const f32x4 pj = *reinterpret_cast<const f32x4*>(proj + n);
-            const i64x2 c01 = *reinterpret_cast<const i64x2*>(code + n);
-            const i64x2 c23 = *reinterpret_cast<const i64x2*>(code + n + 2);
-            u32x4 u;
-            u[0] = make_key(pj[0], c01[0]);
-            u[1] = make_key(pj[1], c01[1]);
-            u[2] = make_key(pj[2], c23[0]);
-            u[3] = make_key(pj[3], c23[1]);
-            *reinterpret_cast<u32x4*>(kout + n) = u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&h_s[bucket_id(u[e], lo, scale) >> TOP_SHIFT], 1u);
-        } else {
-            for (int e = 0; e < 4; ++e)
-                if (n + e < N) {
-                    const unsigned int u = make_key(proj[n + e], code[n + e]);
-                    kout[n + e] = u;
-                    atomicAdd(&h_s[bucket_id(u, lo, scale) >> TOP_SHIFT], 1u);
-                }
-        }
-    }
-    __syncthreads();
-    hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
-}
-
-// K3: counting-sort pass on the top id bits: keys0 (index implicit) -> (key, index) pairs grouped into the NTOP
-// buckets of their segment (any order inside a bucket: K4 ranks full pairs).  A chunk of 4096 keys is bucket-sorted
-// inside LDS first (local slot = LDS atomic on the digit counter), so that the global writes are runs of
-// consecutive pairs instead of single 8-byte scatters.
 // EMBED (segments of at most 2^20 keys): the pair carries the low id bits next to the point index,
 //     pair = key << 32 | low id << 20 | index,
-// so that K4 reads a pair's group with a shift instead of recomputing the float id map (K4 is bound by VALU issue:
+// so that KB reads a pair's group with a shift instead of recomputing the float id map (KB is bound by VALU issue:
 // three id evaluations per pair were 40 % of its instructions).  The order of the pairs as u64 is unchanged: the id is
 // a monotone function of the key, equal keys carry equal ids.
 constexpr int EMBED_SHIFT = 20;
 constexpr unsigned int EMBED_INDEX_MASK = (1u << EMBED_SHIFT) - 1u;
 static_assert(TOP_SHIFT + EMBED_SHIFT <= 32, "low id bits + index fit the low word of a pair");
-// SCT threads per workgroup (the chunk stays 4096 keys): the launch is a single round of workgroups (720 at
-// tracking-60k on 1024 resident slots), so its length is one workgroup's dependent chain; 512 threads halve the
-// per-thread item loops of that chain and double the waves that hide its latencies.  The RADIX digit counters are
-// owned by the first RADIX threads.
+
+// KA: one workgroup = one 4096-key chunk of one segment.  The launch is a single round of workgroups (720 at
+// tracking-60k on 1024 resident slots), so its length is one workgroup's dependent chain: 512 threads halve the
+// per-thread item loops of that chain and double the waves that hide its latencies.
+//   loads of the chunk's hashes and codes (issued first: they do not depend on the key range)
+//   -> key range of the segment (the prep kernel's per-workgroup partials, 16 KiB from L2)
+//   -> keys: key = proj + float(code) * span as TWO rounded ops (the two eager ops of the reference,
+//      example/hept.py:63-65; HIP's __fmul_rn / __fadd_rn are plain * and + and would be contracted to one fma
+//      without -ffp-contract=off (Makefile) -- the asm barrier makes it explicit here as well)
+//   -> digit = top id bits; local slot = LDS atomic on the digit counter; exclusive prefix over the digits
+//   -> pairs into the LDS stage in digit order -> one linear, fully coalesced run of pairs[seg][chunk * 4096 ...]
+//      + tab[seg][chunk][0..256] = first position of every digit inside the run (tab[..][256] = pairs of the chunk)
+// MODE 0: example keys;  MODE 1: the src variant's float shift (get_geo_shift, src/models/attention/hept.py:46-56):
+// shift = (phi * span) * cfac + eta * span, every operation rounded on its own, key bound from the third partial column
+// (src_bound_kernel);  MODE 2: raw keys (hept_segmented_argsort), range from raw_range_kernel.
 #ifndef HEPT_SCATTER_THREADS
 #define HEPT_SCATTER_THREADS 512
 #endif
 constexpr int SCT = HEPT_SCATTER_THREADS;
 constexpr int SCT_ITEMS = SORT_CHUNK / SCT;
-static_assert(SCT >= RADIX && SCT % RADIX == 0 && SORT_CHUNK % SCT == 0, "digit ownership / items per thread");
-template <bool EMBED>
-__global__ __launch_bounds__(SCT) void scatter_kernel(const unsigned int* __restrict__ keys0,
-                                                      const SegParams* __restrict__ seg_params,
-                                                      const unsigned int* __restrict__ hist, int N, int n_chunks,
-                                                      unsigned int* __restrict__ bstart,
-                                                      unsigned long long* __restrict__ dst_pairs,
-                                                      const int* __restrict__ seg_len) {
+constexpr int SCT_WAVES = SCT / HEPT_WAVE;
+constexpr int TAB = RADIX + 1;   // digit offset table of a chunk
+static_assert(SCT >= RADIX && SCT % RADIX == 0 && SORT_CHUNK % SCT == 0 && SCT_ITEMS % 4 == 0, "digit ownership / items per thread");
+static_assert(HEPT_PREP_GRID % SCT == 0, "range partials per thread");
+template <int MODE, bool EMBED>
+__global__ __launch_bounds__(SCT) void chunk_sort_kernel(
+    const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
+    const float* __restrict__ eta_idx, const float* __restrict__ phi_idx, const float* __restrict__ cfac,
+    const float* __restrict__ minmax, const unsigned int* __restrict__ range_bits, int N, int H, int t0, int Tl,
+    int n_chunks, const int* __restrict__ seg_len, SegParams* __restrict__ seg_params,
+    unsigned long long* __restrict__ pairs, unsigned int* __restrict__ tab) {
     __shared__ unsigned long long stage_s[SORT_CHUNK];   // the chunk, digit-sorted (32 KiB)
     __shared__ unsigned int cnt_s[RADIX];                // keys of the chunk per digit
-    __shared__ unsigned int start_s[RADIX];              // first local position of a digit
-    __shared__ unsigned int goff_s[RADIX];               // global offset of the digit's first key of this chunk
+    __shared__ unsigned int start_s[TAB];                // first local position of a digit
     __shared__ unsigned int wsum_s[RADIX / HEPT_WAVE];
+    __shared__ float red_s[3][SCT_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool digit = tid < RADIX;                      // this thread owns digit `tid`
     const int seg = blockIdx.y, chunk = blockIdx.x;
-    const SegParams rg = seg_params[seg];
     const size_t seg_off = (size_t)seg * N;        // N = segment stride; len = keys that take part (ragged argsort)
     const int len = seg_len ? seg_len[seg] : N;
-    if (digit) cnt_s[tid] = 0;
-    unsigned int key[SCT_ITEMS];
     const int base = chunk * SORT_CHUNK;
+    if (digit) cnt_s[tid] = 0;
+
+    // ---- the chunk's inputs: item (i, e) of this thread is key n = base + (i * SCT + tid) * 4 + e
+    const int th = MODE == 2 ? 0 : seg % (Tl * H);   // local (table, head)
+    const int t = th / H, h = th % H;
+    const float* proj = MODE == 2 ? qproj + seg_off : ((seg >= Tl * H ? kproj : qproj) + (size_t)th * N);
+    const size_t row_off = ((size_t)(t0 + t) * H + h) * N;
+    float pj[SCT_ITEMS];
+    long long cd[MODE == 0 ? SCT_ITEMS : 1];
+    float ev[MODE == 1 ? SCT_ITEMS : 1], pv[MODE == 1 ? SCT_ITEMS : 1];
+    const bool vec_ok = (N % 4) == 0;  // segment bases stay 16-B aligned
 #pragma unroll
-    for (int r = 0; r < SCT_ITEMS; ++r) {
-        const int n = base + r * SCT + tid;
-        key[r] = n < len ? keys0[seg_off + n] : 0u;
-    }
-    // global offset of digit `tid` for this chunk = (keys of the segment with a smaller digit) + (same digit in
-    // earlier chunks): every workgroup reduces the segment's chunk histograms itself (a few KiB from L2) instead
-    // of waiting for a separate scan kernel
-    unsigned int own = 0, tot = 0;
-    if (digit) {
-        const unsigned int* hseg = hist + (size_t)seg * n_chunks * RADIX + tid;
-        for (int c0 = 0; c0 < n_chunks; c0 += 8) {
-            unsigned int x[8];
+    for (int i = 0; i < SCT_ITEMS / 4; ++i) {
+        const int n = base + (i * SCT + tid) * 4;
+        if (vec_ok && n + 3 < len) {
+            const f32x4 p4 = *reinterpret_cast<const f32x4*>(proj + n);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = (c0 + i < n_chunks) ? hseg[(size_t)(c0 + i) * RADIX] : 0u;
+            for (int e = 0; e < 4; ++e) pj[4 * i + e] = p4[e];
+            if constexpr (MODE == 0) {
+                typedef __attribute__((ext_vector_type(2))) long long i64x2;
+                const i64x2 c01 = *reinterpret_cast<const i64x2*>(codes + row_off + n);
+                const i64x2 c23 = *reinterpret_cast<const i64x2*>(codes + row_off + n + 2);
+                cd[4 * i] = c01[0]; cd[4 * i + 1] = c01[1]; cd[4 * i + 2] = c23[0]; cd[4 * i + 3] = c23[1];
+            }
+            if constexpr (MODE == 1) {
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(eta_idx + row_off + n);
+                const f32x4 f4 = *reinterpret_cast<const f32x4*>(phi_idx + row_off + n);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                tot += x[i];
-                own += (c0 + i < chunk) ? x[i] : 0u;
+                for (int e = 0; e < 4; ++e) { ev[4 * i + e] = e4[e]; pv[4 * i + e] = f4[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = n + e < len;
+                pj[4 * i + e] = ok ? proj[n + e] : 0.f;
+                if constexpr (MODE == 0) cd[4 * i + e] = ok ? codes[row_off + n + e] : 0;
+                if constexpr (MODE == 1) {
+                    ev[4 * i + e] = ok ? eta_idx[row_off + n + e] : 0.f;
+                    pv[4 * i + e] = ok ? phi_idx[row_off + n + e] : 0.f;
+                }
             }
         }
     }
-    {
-        unsigned int incl = tot;
+
+    // ---- key range of the segment -> id map (every workgroup of a segment computes the same two numbers)
+    float lo, span = 0.f, scale;
+    if constexpr (MODE == 2) {
+        const unsigned int lo_b = range_bits[2 * seg], nhi_b = range_bits[2 * seg + 1];
+        const bool none = lo_b == 0xFFFFFFFFu && nhi_b == 0xFFFFFFFFu;  // no finite key in the segment
+        lo = none ? 0.f : from_ordered(lo_b);
+        const float hi = none ? 0.f : from_ordered(~nhi_b);
+        const float width = hi - lo;
+        scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
+    } else {
+        // hash range + largest code of this (table, head): reduce the prep kernel's per-workgroup partials
+        float hi = -INFINITY, cmax = 0.f;
+        lo = INFINITY;
+        f32x4 m[HEPT_PREP_GRID / SCT];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int y = __shfl_up(incl, off);
-            if (lane >= off) incl += y;
+        for (int i = 0; i < HEPT_PREP_GRID / SCT; ++i)
+            m[i] = *reinterpret_cast<const f32x4*>(minmax + (((size_t)t * H + h) * HEPT_PREP_GRID + i * SCT + tid) * 4);
+#pragma unroll
+        for (int i = 0; i < HEPT_PREP_GRID / SCT; ++i) {
+            lo = fminf(lo, m[i][0]);
+            hi = fmaxf(hi, m[i][1]);
+            cmax = fmaxf(cmax, m[i][2]);
         }
-        if (digit && lane == 63) wsum_s[w] = incl;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off));
+            hi = fmaxf(hi, __shfl_xor(hi, off));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, off));
+        }
+        if (lane == 0) { red_s[0][w] = lo; red_s[1][w] = hi; red_s[2][w] = cmax; }
         __syncthreads();
-        if (digit) {
-            unsigned int excl = incl - tot;
+        lo = red_s[0][0]; hi = red_s[1][0]; cmax = red_s[2][0];
 #pragma unroll
-            for (int ww = 0; ww < RADIX / HEPT_WAVE; ++ww)
-                if (ww < w) excl += wsum_s[ww];
-            goff_s[tid] = excl + own;
-            if (chunk == 0) bstart[(size_t)seg * RADIX + tid] = excl;
+        for (int ww = 1; ww < SCT_WAVES; ++ww) {
+            lo = fminf(lo, red_s[0][ww]); hi = fmaxf(hi, red_s[1][ww]); cmax = fmaxf(cmax, red_s[2][ww]);
         }
+        span = hi - lo;
+        // keys lie in [lo, hi + cmax*span] (codes >= 0); any key outside is clamped by bucket_id (still monotone)
+        const float width = (hi + cmax * span) - lo;
+        scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
     }
-    __syncthreads();
+    if (!(scale < 3.0e38f)) scale = 0.f;  // inf/nan guard for denormal widths: one bucket, still exact
+    if (chunk == 0 && tid == 0) seg_params[seg] = SegParams{lo, scale};
+    if (MODE == 2) __syncthreads();   // (the other modes passed a barrier in the range reduction: cnt_s is zero)
+
+    // ---- keys, digits, local slots
+    float cf = 0.f;
+    if constexpr (MODE == 1) cf = cfac[(size_t)(t0 + t) * H + h];
+    unsigned int key[SCT_ITEMS];
     unsigned short rank[SCT_ITEMS], lowid[SCT_ITEMS];
     unsigned char dig[SCT_ITEMS];
 #pragma unroll
     for (int r = 0; r < SCT_ITEMS; ++r) {
-        const int n = base + r * SCT + tid;
-        const unsigned int id = bucket_id(key[r], rg.kmin, rg.scale);
+        const int n = base + ((r >> 2) * SCT + tid) * 4 + (r & 3);
+        float kf;
+        if constexpr (MODE == 0) {
+            float off = (float)cd[r] * span;
+            asm volatile("" : "+v"(off));
+            kf = pj[r] + off;
+        } else if constexpr (MODE == 1) {
+            float t1 = ev[r] * span;
+            asm volatile("" : "+v"(t1));
+            float t2 = pv[r] * span;
+            asm volatile("" : "+v"(t2));
+            t2 = t2 * cf;
+            asm volatile("" : "+v"(t2));
+            float t3 = t2 + t1;
+            asm volatile("" : "+v"(t3));
+            kf = pj[r] + t3;
+        } else {
+            kf = pj[r];
+        }
+        key[r] = ordered_bits(kf);
+        const unsigned int id = bucket_id(key[r], lo, scale);
         const unsigned int dg = id >> TOP_SHIFT;
         lowid[r] = (unsigned short)(id & (unsigned int)(LOBINS - 1));
         dig[r] = (unsigned char)dg;
@@ -298,78 +261,234 @@ __global__ __launch_bounds__(SCT) void scatter_kernel(const unsigned int* __rest
     }
     if (digit && lane == 63) wsum_s[w] = incl;
     __syncthreads();
+    const int n_valid = max(0, min(SORT_CHUNK, len - base));
+    unsigned int* my_tab = tab + ((size_t)seg * n_chunks + chunk) * TAB;
     if (digit) {
         unsigned int first = incl - total;
 #pragma unroll
         for (int ww = 0; ww < RADIX / HEPT_WAVE; ++ww)
             if (ww < w) first += wsum_s[ww];
         start_s[tid] = first;
+        my_tab[tid] = first;
+        if (tid == RADIX - 1) my_tab[RADIX] = (unsigned int)n_valid;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SCT_ITEMS; ++r) {
-        const int n = base + r * SCT + tid;
+        const int n = base + ((r >> 2) * SCT + tid) * 4 + (r & 3);
         if (n < len)
             stage_s[start_s[dig[r]] + rank[r]] = ((unsigned long long)key[r] << 32) |
                                                  (EMBED ? ((unsigned int)lowid[r] << EMBED_SHIFT) | (unsigned int)n : (unsigned int)n);
     }
     __syncthreads();
-    // write out: consecutive local positions of one digit are consecutive global positions
-    const int n_valid = min(SORT_CHUNK, len - base);
+    // write out: the chunk's run, linear
+    unsigned long long* out = pairs + seg_off + base;
 #pragma unroll
     for (int r = 0; r < SCT_ITEMS; ++r) {
         const int lp = r * SCT + tid;
-        if (lp < n_valid) {
-            const unsigned long long p = stage_s[lp];
-            const unsigned int dg = bucket_id((unsigned int)(p >> 32), rg.kmin, rg.scale) >> TOP_SHIFT;
-            dst_pairs[seg_off + goff_s[dg] + (lp - start_s[dg])] = p;
-        }
+        if (lp < n_valid) out[lp] = stage_s[lp];
     }
 }
 
-// K4: every (segment, top-bits bucket) is finished by one workgroup.  A bucket holds the pairs whose id shares the
-// top bits, contiguous after K3; id is monotone in the key, so the bucket's final positions are exactly its own
-// range [start, end) and only the order inside it is left.  Histogram of the LOW id bits -> exclusive prefix
-// -> scatter (any order): the pairs are now grouped by their full id, group g = [first[g], first[g+1]), and
+// KB: every (segment, top-bits bucket) is finished by one workgroup.  A bucket holds the pairs whose id shares the
+// top bits; id is monotone in the key, so the bucket's final positions are exactly its own range [start, start + nb)
+// and only the order inside it is left.  Its pairs lie in n_chunks runs (one per chunk KA sorted):
+//        run c = pairs[seg][c * 4096 + tab[c][bucket] .. c * 4096 + tab[c][bucket + 1]),     start = sum_c tab[c][bucket]
+// -- no cross-workgroup prefix anywhere.  The runs are ~16 pairs each when a chunk's keys are spread over the whole key
+// range (one cloud), but a batch of clouds puts a chunk's keys into ITS cloud's part of the range: a bucket then draws
+// hundreds of pairs from two or three chunks.  So the pairs are dealt to the threads by their position in run order
+// (position i -> thread i % threads: one binary search over the run offsets, kept in LDS, per position), whatever the
+// run lengths are.  The bucket (up to CAP pairs) is loaded into registers with every load in flight at once; positions
+// beyond CAP are re-read from L2 by the later passes.
+// Then: histogram of the LOW id bits -> exclusive prefix -> scatter (any order): the pairs are grouped by their full
+// id, group g = [first[g], first[g+1]), and
 //        final position(i) = start + first[g] + #{ j in group g : pair_j < pair_i }        (pairs are unique u64)
-// Groups are 1-3 pairs at tracking-60k.  A bucket larger than the LDS tile takes the same three steps through a
-// global scratch copy, grouped by sampled splitters instead of id bits (streaming; slower, never wrong); a
-// tile-sized bucket of equal keys costs at most CAP^2 compares.
-// The whole bucket is loaded into registers with every load in flight at once; only the grouped copy lives in LDS.
-// One bins array serves as histogram, exclusive prefix and scatter cursor: after the scatter cur[d] is one past the
-// last slot of group d, i.e. group d = [cur[d-1], cur[d]).
+// Groups are 1-3 pairs at tracking-60k.  Only the grouped copy lives in LDS; one bins array serves as histogram,
+// exclusive prefix and scatter cursor: after the scatter cur[d] is one past the last slot of group d, i.e. group
+// d = [cur[d-1], cur[d]).  A bucket of up to 2 CAP pairs (skewed key distributions -- pileup clouds of unequal size --
+// put 1.5x to 2x the expected pairs into a few buckets) goes through the tile in two passes, lower half of the id bins
+// first, if each half fits.  Anything else (a pile of equal or nearly equal keys, possibly next to a few spread ones,
+// which neither those bits nor any linear map of the key range can separate) takes the same three steps through a
+// global scratch copy, grouped by SPLITTERS -- LOBINS pairs sampled at regular positions of the bucket and sorted in
+// LDS; a pair's bin is the number of splitters <= it (binary search).  Pairs are unique u64, so even 60 000 equal keys
+// spread over the bins by their index (streaming; slower, never wrong); a tile-sized bucket of equal keys costs at most
+// CAP^2 compares.
 constexpr int BKT_THREADS = HEPT_BKT_THREADS;
 constexpr int BKT_WAVES = BKT_THREADS / HEPT_WAVE;
 constexpr int BKT_BINS_PER_THREAD = LOBINS / BKT_THREADS;
 static_assert(LOBINS % BKT_THREADS == 0, "every thread owns the same number of bins");
-template <int CAP, bool EMBED>
+// MAXR = chunks whose run offsets fit the kernel's LDS table (64: every wave builds the table by itself with one
+// shuffle scan, no barrier; the large-tile kernel takes up to 1024 chunks = 4 M keys per segment through a serial
+// scan); longer segments walk the global table for every lookup -- slow, never wrong
+template <int CAP, bool EMBED, int MAXR>
 __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned long long* __restrict__ pairs,
                                                                   unsigned long long* __restrict__ scratch,
                                                                   const SegParams* __restrict__ seg_params,
-                                                                  const unsigned int* __restrict__ bstart, int N,
-                                                                  int* __restrict__ pos_out,
-                                                                  const int* __restrict__ seg_len) {
+                                                                  const unsigned int* __restrict__ tab, int N,
+                                                                  int n_chunks, int* __restrict__ pos_out) {
     static_assert(CAP >= LOBINS, "the tile also holds the splitters of the streaming path");
     __shared__ unsigned long long tile_s[CAP];
     __shared__ unsigned int cur_s[LOBINS + 1];  // [0] stays 0; bin d lives at [d + 1]
     __shared__ unsigned int wsum_s[BKT_WAVES];
+    __shared__ unsigned int roff_s[MAXR + 1];   // pairs of the bucket in runs 0 .. c-1
+    __shared__ unsigned int rbase_s[MAXR + 1];  // first pair of run c, as an index into the segment's pairs; [MAXR]: start
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int seg = blockIdx.y, bucket = blockIdx.x;
-    const unsigned int* o = bstart + (size_t)seg * RADIX;  // keys of the segment with a smaller digit (written by K3)
-    const int start = (int)o[bucket];
-    const int end = bucket == NTOP - 1 ? (seg_len ? seg_len[seg] : N) : (int)o[bucket + 1];
-    const int nb = end - start;
-    if (nb <= 0) return;
-    const unsigned long long* src = pairs + (size_t)seg * N + start;
+    const unsigned long long* seg_pairs = pairs + (size_t)seg * N;
+    const unsigned int* btab = tab + (size_t)seg * n_chunks * TAB + bucket;   // + c * TAB: [first, end) of run c
+    unsigned int* bin_s = cur_s + 1;
+    auto zero_bins = [&]() {
+#pragma unroll
+        for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) bin_s[u * BKT_THREADS + tid] = 0;
+        if (tid == 0) cur_s[0] = 0;
+    };
+    zero_bins();
+    // ---- the bucket's runs: offsets, first final position, size
+    const bool table_in_lds = n_chunks <= MAXR;
+    int start = 0, nb = 0, longest = 1 << 30;
+    if (n_chunks <= HEPT_WAVE) {
+        // every wave builds the table by itself (same values, written twice): no barrier before the lookups
+        unsigned int a0 = 0, a1 = 0;
+        if (lane < n_chunks) { a0 = btab[(size_t)lane * TAB]; a1 = btab[(size_t)lane * TAB + 1]; }
+        unsigned int incl = a1 - a0, ssum = a0, lmax = a1 - a0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            ssum += __shfl_xor(ssum, off);
+            lmax = max(lmax, (unsigned int)__shfl_xor((int)lmax, off));
+        }
+        longest = (int)lmax;
+        if (lane < n_chunks) {
+            roff_s[lane] = incl - (a1 - a0);
+            rbase_s[lane] = (unsigned int)lane * SORT_CHUNK + a0;
+        }
+        nb = (int)__shfl(incl, 63);
+        start = (int)ssum;
+        if (lane == 0) roff_s[n_chunks] = (unsigned int)nb;
+    } else {
+        if (table_in_lds) {
+            for (int c = tid; c < n_chunks; c += BKT_THREADS) {
+                const unsigned int a0 = btab[(size_t)c * TAB], a1 = btab[(size_t)c * TAB + 1];
+                roff_s[c + 1] = a1 - a0;
+                rbase_s[c] = (unsigned int)c * SORT_CHUNK + a0;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned int run = 0, ssum = 0;
+                for (int c = 0; c < n_chunks; ++c) {
+                    const unsigned int l = roff_s[c + 1];
+                    ssum += rbase_s[c] - (unsigned int)c * SORT_CHUNK;
+                    roff_s[c] = run;
+                    run += l;
+                }
+                roff_s[n_chunks] = run;
+                rbase_s[MAXR] = ssum;
+            }
+        } else if (tid == 0) {
+            unsigned int run = 0, ssum = 0;
+            for (int c = 0; c < n_chunks; ++c) {
+                const unsigned int a0 = btab[(size_t)c * TAB], a1 = btab[(size_t)c * TAB + 1];
+                ssum += a0;
+                run += a1 - a0;
+            }
+            roff_s[0] = run;
+            rbase_s[MAXR] = ssum;
+        }
+        __syncthreads();
+        nb = (int)roff_s[table_in_lds ? n_chunks : 0];
+        start = (int)rbase_s[MAXR];
+    }
+    // (the two sums come out of shuffles / LDS: tell the compiler that they are wave-uniform, or every quantity derived
+    //  from them -- loop bounds, the path taken, the output base -- lives in vector registers and every branch on them
+    //  becomes predicated code: 122 VGPRs instead of ~60)
+    nb = __builtin_amdgcn_readfirstlane(nb);
+    start = __builtin_amdgcn_readfirstlane(start);
+    longest = __builtin_amdgcn_readfirstlane(longest);
+    if (nb <= 0) return;   // uniform
+    // position in run order -> (run, first pair of the run, pairs in front of the run)
+    struct Where { int c; unsigned int before, base, len; };
+    auto locate = [&](unsigned int idx) -> Where {
+        Where wv;
+        if (table_in_lds) {
+            int lo = 0, hi = n_chunks;   // the last c with roff[c] <= idx (runs of length 0 are passed over)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (roff_s[mid] <= idx) lo = mid; else hi = mid;
+            }
+            wv.c = lo;
+            wv.before = roff_s[lo];
+            wv.base = rbase_s[lo];
+            wv.len = roff_s[lo + 1] - wv.before;
+        } else {
+            unsigned int before = 0;
+            int c = 0;
+            unsigned int a0 = 0, l = 0;
+            for (; c < n_chunks; ++c) {
+                a0 = btab[(size_t)c * TAB];
+                l = btab[(size_t)c * TAB + 1] - a0;
+                if (idx < before + l) break;
+                before += l;
+            }
+            wv.c = c; wv.before = before; wv.base = (unsigned int)c * SORT_CHUNK + a0; wv.len = l;
+        }
+        return wv;
+    };
+    auto pair_at = [&](unsigned int idx) -> unsigned long long {
+        const Where wv = locate(idx);
+        return seg_pairs[(size_t)wv.base + (idx - wv.before)];
+    };
+    // ---- the first CAP pairs of the bucket: registers, every load in flight at once.  Two ways of dealing them out:
+    //  * by run (one cloud: every chunk contributes a short run): LPR = threads / n_chunks lanes (a power of two) share
+    //    run c = tid / LPR and take its pairs rl, rl + LPR, ...; no lookup at all.  Taken when every run fits its lanes'
+    //    ITEMS register slots.
+    //  * by position (a batch of clouds: a bucket draws hundreds of pairs from two or three chunks): position
+    //    i = u * threads + tid in run order, one binary search over the run offsets per position; only
+    //    ceil(nb / threads) of the ITEMS slots have an active lane, the others are skipped as a whole.
+    constexpr int ITEMS = CAP / BKT_THREADS;
+    const int n_reg = nb < CAP ? nb : CAP;
+    int lpr_log = 0;
+    while ((2 << lpr_log) * n_chunks <= BKT_THREADS) ++lpr_log;
+#ifdef HEPT_BKT_NO_BY_RUN
+    const bool by_run = false;
+#else
+    const bool by_run = n_chunks <= HEPT_WAVE && n_chunks <= BKT_THREADS && longest <= (ITEMS << lpr_log);   // uniform
+#endif
+    unsigned long long mine[ITEMS];
+    unsigned long long vmask = 0;   // bit u: slot u holds a pair (ITEMS <= 64)
+    if (by_run) {
+        const int rc = tid >> lpr_log, rl = tid & ((1 << lpr_log) - 1);
+        int rlen = 0;
+        const unsigned long long* rsrc = seg_pairs;
+        if (rc < n_chunks) {
+            rlen = (int)(roff_s[rc + 1] - roff_s[rc]);
+            rsrc = seg_pairs + rbase_s[rc];
+        }
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int j = rl + (u << lpr_log);
+            mine[u] = j < rlen ? rsrc[j] : 0ull;
+            vmask |= j < rlen ? 1ull << u : 0ull;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int i = u * BKT_THREADS + tid;
+            mine[u] = i < n_reg ? pair_at((unsigned int)i) : 0ull;
+            vmask |= i < n_reg ? 1ull << u : 0ull;
+        }
+    }
+    static_assert(ITEMS <= 64, "one validity bit per register slot");
+    auto valid = [&](int u) { return (vmask >> u) & 1ull; };
+    // every pair of the bucket that is NOT in a register (positions >= CAP: oversize buckets only)
+    auto for_rest = [&](auto&& f) {
+        for (int i = CAP + tid; i < nb; i += BKT_THREADS) f(pair_at((unsigned int)i));
+    };
     int* out = pos_out + (size_t)seg * N + start;
     const SegParams rg = seg_params[seg];
-    // Grouping key inside the bucket.  LDS path: the low bits of the global id; a bucket of up to 2 CAP pairs (skewed
-    // key distributions -- pileup clouds of unequal size -- put 1.5x to 2x the expected pairs into a few buckets) goes
-    // through the tile in two passes, lower half of the id bins first, if each half fits.  Streaming path (anything
-    // else: a pile of equal or nearly equal keys, possibly next to a few spread ones, which neither those bits nor
-    // any linear map of the key range can separate): SPLITTERS -- LOBINS pairs sampled at regular positions of the
-    // bucket and sorted in LDS; a pair's bin is the number of splitters <= it (binary search).  Pairs are unique
-    // u64, so even 60 000 equal keys spread over the bins by their index.
     bool in_lds = nb <= 2 * CAP;                 // workgroup-uniform
     unsigned long long* spl_s = tile_s;          // the streaming path groups in global scratch, its tile is free
     auto lo_of = [&](unsigned long long p) -> unsigned int {
@@ -383,13 +502,8 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         }
         return (unsigned int)(lo > 0 ? lo - 1 : 0);
     };
-    unsigned int* bin_s = cur_s + 1;
-    auto zero_bins = [&]() {
-#pragma unroll
-        for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) bin_s[u * BKT_THREADS + tid] = 0;
-        if (tid == 0) cur_s[0] = 0;
-    };
     auto prefix_bins = [&]() {  // exclusive prefix over the bins: thread owns bins BPT*tid .. BPT*tid + BPT - 1
+        __syncthreads();   // the histogram is complete
         unsigned int c[BKT_BINS_PER_THREAD], tot = 0;
 #pragma unroll
         for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) { c[u] = bin_s[BKT_BINS_PER_THREAD * tid + u]; tot += c[u]; }
@@ -412,27 +526,13 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         }
         __syncthreads();
     };
-    zero_bins();
-    // The first CAP pairs of the bucket are loaded into registers with every load in flight at once; only the
-    // grouped copy lives in LDS.  One bins array serves as histogram, exclusive prefix and scatter cursor: after
-    // the scatter cur[d] is one past the last slot of group d, i.e. group d = [cur[d-1], cur[d]).
-    constexpr int ITEMS = CAP / BKT_THREADS;
-    unsigned long long mine[ITEMS];
-    if (in_lds) {
-#pragma unroll
-        for (int u = 0; u < ITEMS; ++u) {
-            const int i = u * BKT_THREADS + tid;
-            mine[u] = i < nb ? src[i] : 0ull;
-        }
-    }
-    __syncthreads();
+    __syncthreads();   // the bins are zero in every wave's view
     int n_low = nb;  // pairs in the lower half of the id bins (two-pass buckets)
     if (in_lds) {
 #pragma unroll
         for (int u = 0; u < ITEMS; ++u)
-            if (u * BKT_THREADS + tid < nb) atomicAdd(&bin_s[lo_of(mine[u])], 1u);
-        for (int i = CAP + tid; i < nb; i += BKT_THREADS) atomicAdd(&bin_s[lo_of(src[i])], 1u);
-        __syncthreads();
+            if (valid(u)) atomicAdd(&bin_s[lo_of(mine[u])], 1u);
+        for_rest([&](unsigned long long p) { atomicAdd(&bin_s[lo_of(p)], 1u); });
         prefix_bins();
         if (nb > CAP) {
             n_low = (int)bin_s[LOBINS / 2];
@@ -440,8 +540,14 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         }
     }
     if (!in_lds) {
+        // splitters: pairs at regular positions of the bucket in run order
+        unsigned long long sample[LOBINS / BKT_THREADS];
+#pragma unroll
+        for (int u = 0; u < LOBINS / BKT_THREADS; ++u)
+            sample[u] = pair_at((unsigned int)((size_t)(u * BKT_THREADS + tid) * nb / LOBINS));
         __syncthreads();
-        for (int i = tid; i < LOBINS; i += BKT_THREADS) spl_s[i] = src[(size_t)i * nb / LOBINS];
+#pragma unroll
+        for (int u = 0; u < LOBINS / BKT_THREADS; ++u) spl_s[u * BKT_THREADS + tid] = sample[u];
         zero_bins();
         __syncthreads();
         for (int k = 2; k <= LOBINS; k <<= 1)          // bitonic sort, ascending
@@ -456,8 +562,10 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
                 }
                 __syncthreads();
             }
-        for (int i = tid; i < nb; i += BKT_THREADS) atomicAdd(&bin_s[lo_of(src[i])], 1u);
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u)
+            if (valid(u)) atomicAdd(&bin_s[lo_of(mine[u])], 1u);
+        for_rest([&](unsigned long long p) { atomicAdd(&bin_s[lo_of(p)], 1u); });
         prefix_bins();
     }
     // rank the pairs grouped[0 .. cnt) = bucket positions [off, off + cnt) inside their groups
@@ -487,25 +595,24 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
             const int off = ps ? n_low : 0, cnt = n_pass == 2 ? (ps ? nb - n_low : n_low) : nb;
 #pragma unroll
             for (int u = 0; u < ITEMS; ++u)
-                if (u * BKT_THREADS + tid < nb) {
+                if (valid(u)) {
                     const unsigned int d = lo_of(mine[u]);
                     if (n_pass == 1 || (d >> (TOP_SHIFT - 1)) == half) tile_s[atomicAdd(&bin_s[d], 1u) - off] = mine[u];
                 }
-            for (int i = CAP + tid; i < nb; i += BKT_THREADS) {
-                const unsigned long long p = src[i];
+            for_rest([&](unsigned long long p) {
                 const unsigned int d = lo_of(p);
-                if ((d >> (TOP_SHIFT - 1)) == half) tile_s[atomicAdd(&bin_s[d], 1u) - off] = p;
-            }
+                if (n_pass == 1 || (d >> (TOP_SHIFT - 1)) == half) tile_s[atomicAdd(&bin_s[d], 1u) - off] = p;
+            });
             __syncthreads();
             rank_all(tile_s, off, cnt);
             __syncthreads();
         }
     } else {
         unsigned long long* g = scratch + (size_t)seg * N + start;
-        for (int i = tid; i < nb; i += BKT_THREADS) {
-            const unsigned long long p = src[i];
-            g[atomicAdd(&bin_s[lo_of(p)], 1u)] = p;
-        }
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u)
+            if (valid(u)) g[atomicAdd(&bin_s[lo_of(mine[u])], 1u)] = mine[u];
+        for_rest([&](unsigned long long p) { g[atomicAdd(&bin_s[lo_of(p)], 1u)] = p; });
         __threadfence_block();
         __syncthreads();
         rank_all(g, 0, nb);
@@ -574,43 +681,6 @@ __global__ __launch_bounds__(SORT_THREADS) void raw_range_kernel(const float* __
         if (lo != 0xFFFFFFFFu) atomicMin(range_bits + 2 * seg, lo);
         if (nhi != 0xFFFFFFFFu) atomicMin(range_bits + 2 * seg + 1, nhi);
     }
-}
-
-// keys0 = ordered bits of the raw keys + per-chunk histogram of the low id byte
-__global__ __launch_bounds__(SORT_THREADS) void raw_keygen_hist_kernel(const float* __restrict__ keys, int L,
-                                                                       const int* __restrict__ seg_len,
-                                                                       const unsigned int* __restrict__ range_bits,
-                                                                       SegParams* __restrict__ seg_params,
-                                                                       unsigned int* __restrict__ keys0,
-                                                                       unsigned int* __restrict__ hist, int n_chunks) {
-    __shared__ unsigned int h_s[RADIX];
-    const int tid = threadIdx.x, seg = blockIdx.y, chunk = blockIdx.x;
-    SegParams rg;
-    {
-        const unsigned int lo_b = range_bits[2 * seg], nhi_b = range_bits[2 * seg + 1];
-        const bool none = lo_b == 0xFFFFFFFFu && nhi_b == 0xFFFFFFFFu;  // no finite key in the segment
-        const float lo = none ? 0.f : from_ordered(lo_b), hi = none ? 0.f : from_ordered(~nhi_b);
-        const float width = hi - lo;
-        float scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
-        if (!(scale < 3.0e38f)) scale = 0.f;
-        rg = SegParams{lo, scale};
-        if (chunk == 0 && tid == 0) seg_params[seg] = rg;
-    }
-    h_s[tid] = 0;
-    __syncthreads();
-    const int base = chunk * SORT_CHUNK;
-    const int len = seg_len ? seg_len[seg] : L;
-#pragma unroll 4
-    for (int i = 0; i < SORT_ITEMS; ++i) {
-        const int n = base + i * SORT_THREADS + tid;
-        if (n < len) {
-            const unsigned int u = ordered_bits(keys[(size_t)seg * L + n]);
-            keys0[(size_t)seg * L + n] = u;
-            atomicAdd(&h_s[bucket_id(u, rg.kmin, rg.scale) >> TOP_SHIFT], 1u);
-        }
-    }
-    __syncthreads();
-    hist[((size_t)seg * n_chunks + chunk) * RADIX + tid] = h_s[tid];
 }
 
 // ---- short segments (N <= SMALL_CAP: the 4k / 6k clouds): the whole sort of a segment in ONE workgroup ----------------
@@ -796,13 +866,11 @@ int launch_small_sort(int segs, hipStream_t st, const float* qproj, const float*
     return hept_launch_status();
 }
 
-// the passes shared by hept_sort_tables and hept_segmented_argsort: keys0 + hist(top bits) + params -> pos
+// the two passes shared by hept_sort_tables and hept_segmented_argsort
 struct SortBuffers {
-    unsigned int* keys0;
-    unsigned long long *pa, *pb;
-    unsigned int* hist;
-    unsigned int* bstart;  // [segs][RADIX] first position of every top-level bucket
-    unsigned int* range;   // [segs][2] ordered-uint finite min / ~max of raw keys (hept_segmented_argsort)
+    unsigned long long *pa, *pb;   // pairs (chunk runs), scratch of the streaming path
+    unsigned int* tab;             // [segs][n_chunks][257] digit offsets of every chunk's run
+    unsigned int* range;           // [segs][2] ordered-uint finite min / ~max of raw keys (hept_segmented_argsort)
     SegParams* params;
 };
 SortBuffers carve_sort(void* sort_ws, int segs, int N) {
@@ -810,16 +878,12 @@ SortBuffers carve_sort(void* sort_ws, int segs, int N) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     char* ws = reinterpret_cast<char*>(sort_ws);
     SortBuffers b;
-    b.keys0 = reinterpret_cast<unsigned int*>(ws);
-    ws += al((size_t)segs * N * 4);
     b.pa = reinterpret_cast<unsigned long long*>(ws);
     ws += al((size_t)segs * N * 8);
     b.pb = reinterpret_cast<unsigned long long*>(ws);
     ws += al((size_t)segs * N * 8);
-    b.hist = reinterpret_cast<unsigned int*>(ws);
-    ws += al((size_t)segs * n_chunks * RADIX * 4);
-    b.bstart = reinterpret_cast<unsigned int*>(ws);
-    ws += al((size_t)segs * RADIX * 4);
+    b.tab = reinterpret_cast<unsigned int*>(ws);
+    ws += al((size_t)segs * n_chunks * TAB * 4);
     b.range = reinterpret_cast<unsigned int*>(ws);
     ws += al((size_t)segs * 8);
     b.params = reinterpret_cast<SegParams*>(ws);
@@ -827,23 +891,29 @@ SortBuffers carve_sort(void* sort_ws, int segs, int N) {
 }
 constexpr int BKT_CAP_SMALL = HEPT_BKT_CAP;  // LDS tile: the average bucket is N/NTOP
 constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segments (average bucket up to ~3000 pairs)
-template <bool EMBED>
-void run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const int* seg_len) {
+template <int MODE, bool EMBED>
+void run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj,
+                     const float* kproj, const int64_t* codes, const float* eta, const float* phi, const float* cfac,
+                     const float* minmax, int H, int t0, int Tl, const int* seg_len) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
-    const dim3 grid(n_chunks, segs), block(SCT);
-    hipLaunchKernelGGL(scatter_kernel<EMBED>, grid, block, 0, st, b.keys0, b.params, b.hist, N, n_chunks, b.bstart, b.pa,
-                       seg_len);
+    hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes, eta,
+                       phi, cfac, minmax, b.range, N, H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab);
     const dim3 grid4(NTOP, segs);
     if ((size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2))
-        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
-                           b.bstart, N, pos, seg_len);
+        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED, 64>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
+                           b.tab, N, n_chunks, pos);
     else
-        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_LARGE, EMBED>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
-                           b.bstart, N, pos, seg_len);
+        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_LARGE, EMBED, 1024>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb,
+                           b.params, b.tab, N, n_chunks, pos);
 }
-void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const int* seg_len = nullptr) {
-    if (N <= (1 << EMBED_SHIFT)) run_passes_impl<true>(b, segs, N, pos, st, seg_len);
-    else run_passes_impl<false>(b, segs, N, pos, st, seg_len);
+template <int MODE>
+void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj, const float* kproj,
+                const int64_t* codes, const float* eta, const float* phi, const float* cfac, const float* minmax, int H,
+                int t0, int Tl, const int* seg_len = nullptr) {
+    if (N <= (1 << EMBED_SHIFT))
+        run_passes_impl<MODE, true>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len);
+    else
+        run_passes_impl<MODE, false>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len);
 }
 
 }  // namespace
@@ -852,8 +922,8 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t sort_bytes(size_t segs, size_t N) {
     const size_t n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
-    return align256(segs * N * 4) + 2 * align256(segs * N * 8) + align256(segs * n_chunks * RADIX * 4) +
-           align256(segs * RADIX * 4) + align256(segs * 8) + align256(segs * sizeof(SegParams));
+    return 2 * align256(segs * N * 8) + align256(segs * n_chunks * TAB * 4) + align256(segs * 8) +
+           align256(segs * sizeof(SegParams));
 }
 
 extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) { return sort_bytes((size_t)2 * Tl * H, N); }
@@ -868,11 +938,8 @@ extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const in
     const int segs = 2 * Tl * H;
     if (N <= SMALL_CAP)
         return launch_small_sort<0>(segs, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, N, H, t0, Tl, qpos);
-    const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(sort_ws, segs, N);
-    hipLaunchKernelGGL(keygen_hist_kernel<false>, dim3(n_chunks, segs), dim3(SORT_THREADS), 0, st, qproj, kproj, codes,
-                       nullptr, nullptr, nullptr, minmax, N, H, t0, Tl, b.keys0, b.hist, b.params, n_chunks);
-    run_passes(b, segs, N, qpos, st);
+    run_passes<0>(b, segs, N, qpos, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, H, t0, Tl);
     return hept_launch_status();
 }
 
@@ -887,13 +954,10 @@ extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, cons
     const int segs = 2 * Tl * H;
     if (N <= SMALL_CAP)
         return launch_small_sort<1>(segs, st, qproj, kproj, nullptr, eta_idx, phi_idx, cfac, minmax, N, H, t0, Tl, qpos);
-    const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(sort_ws, segs, N);
     hipLaunchKernelGGL(src_bound_kernel, dim3(Tl * H), dim3(SORT_THREADS), 0, st, eta_idx, phi_idx, cfac, N, H, t0,
                        minmax);
-    hipLaunchKernelGGL(keygen_hist_kernel<true>, dim3(n_chunks, segs), dim3(SORT_THREADS), 0, st, qproj, kproj, nullptr,
-                       eta_idx, phi_idx, cfac, minmax, N, H, t0, Tl, b.keys0, b.hist, b.params, n_chunks);
-    run_passes(b, segs, N, qpos, st);
+    run_passes<1>(b, segs, N, qpos, st, qproj, kproj, nullptr, eta_idx, phi_idx, cfac, minmax, H, t0, Tl);
     return hept_launch_status();
 }
 
@@ -911,9 +975,7 @@ int segmented_argsort_impl(const float* keys, int S, int L, const int* seg_len, 
     const SortBuffers b = carve_sort(ws, S, L);
     if (hipMemsetAsync(b.range, 0xFF, (size_t)S * 8, st) != hipSuccess) return HEPT_ERR_LAUNCH;
     hipLaunchKernelGGL(raw_range_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, seg_len, b.range);
-    hipLaunchKernelGGL(raw_keygen_hist_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, seg_len, b.range,
-                       b.params, b.keys0, b.hist, n_chunks);
-    run_passes(b, S, L, pos, st, seg_len);
+    run_passes<2>(b, S, L, pos, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 1, seg_len);
     return hept_launch_status();
 }
 }  // namespace
