@@ -30,7 +30,11 @@ struct RawRow {
     __device__ __forceinline__ void load(const float* __restrict__ row) {
         const u32x4* src = reinterpret_cast<const u32x4*>(row);
 #pragma unroll
+#ifdef HEPT_CMB_NT_LOADS
+        for (int i = 0; i < PIECES; ++i) q[i] = __builtin_nontemporal_load(src + i);
+#else
         for (int i = 0; i < PIECES; ++i) q[i] = src[i];
+#endif
     }
     // x[0..27] += widened row; returns the denominator
     __device__ __forceinline__ float add_to(float (&x)[28], int D) const {
@@ -174,13 +178,12 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (tile != tile_first) {   // (the first tile's rows were requested before the weight staging)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                if (t < tpre && hp0 < HP) cur[t].load(row_of(hp0) + (size_t)t * tstride);
-        }
+        // (the first tile's rows were requested before the weight staging; a wave that takes several tiles requests the
+        //  next tile's first rows while it finishes the current one)
+        const int tile_next = tile + (SPLIT ? (int)gridDim.x : (int)gridDim.x * CMB_WAVES);
         for (int hp = hp0; hp < HP; hp += hstep) {
             const bool more = hp + hstep < HP;
+            const bool wrap = !more && tile_next < n_tiles;   // the last head pair of a tile that is not the wave's last
             // packed rows: the next head pair's rows are requested before the current pair is unpacked.  f32 rows are
             // 21 x 16 B per head pair and lane: holding two sets put the kernel at 256 VGPRs + 120 AGPRs, ONE wave per
             // SIMD and therefore two rounds of workgroups; there the current set is summed first and the next set is
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             if constexpr (P16) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
-                    if (more && t < tpre) nxt[t].load(row_of(hp + hstep) + (size_t)t * tstride);
+                    if ((more || wrap) && t < tpre)
+                        nxt[t].load((more ? row_of(hp + hstep) : row_at(tile_next, hp0)) + (size_t)t * tstride);
             }
             // this head's weight column, requested before the rows are unpacked (LDS latency hides under the VALU work)
             float wv[28];
@@ -213,7 +217,8 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             if constexpr (!P16) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
-                    if (more && t < tpre) cur[t].load(row_of(hp + hstep) + (size_t)t * tstride);
+                    if ((more || wrap) && t < tpre)
+                        cur[t].load((more ? row_of(hp + hstep) : row_at(tile_next, hp0)) + (size_t)t * tstride);
             }
             const float inv = 1.0f / den;
 #pragma unroll
@@ -679,7 +684,10 @@ int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int 
                            Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px);
     } else {
         const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
-        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, false, PUSH>), dim3(wgs < 2048 ? wgs : 2048), dim3(CMB_THREADS),
+#ifndef HEPT_CMB_MAX_WGS
+#define HEPT_CMB_MAX_WGS 2048
+#endif
+        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, false, PUSH>), dim3(wgs < HEPT_CMB_MAX_WGS ? wgs : HEPT_CMB_MAX_WGS), dim3(CMB_THREADS),
                            lds, st, part, Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px);
     }
     return hept_launch_status();
