@@ -534,7 +534,8 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
 // logits per block) instead of 4 x 4 of 32 x 32 (16 384).  The split-bf16 kernel is bound by instruction issue (MFMA +
 // split / exp VALU), so its time follows the padded area.  Taken when ceil(B / 16) is odd, i.e. when the last 32-row
 // tile would be less than half full.  (The 16-bit-tile kernels are bound by their gathers, not by issue: the same
-// tiling was built for them, measured at B = 100 -- 90.2 us against 89.9 us -- and not kept.)
+// tiling was built for them, measured at B = 100 -- 90.2 us against 89.9 us -- and not kept; so was a three-wave
+// workgroup whose first wave serves the 4 tail queries in a pass of its own: bit-identical rows, 100 us against 89.)
 //
 // One wave = two query tiles (16 queries each) x all NT16 key tiles; K^ / V bf16 planes are staged 64 keys at a time
 // exactly as in block_attn_split_kernel.  Per key tile: X = K^ . Q^T is SIX 16x16x32 MFMAs (the row's 32 columns are the whole K
