@@ -113,6 +113,32 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x
                                                    0, 0);
 }
 
+// ---- wave-wide scan / reductions on DPP (one VALU instruction per step; __shfl_up / __shfl_xor compile to ds_bpermute
+// plus address arithmetic, ~4 VALU and an LDS round trip per step).  gfx9 DPP: row_shr within rows of 16 lanes, then
+// row_bcast:15 (rows 1 and 3 take the last lane of the row before them) and row_bcast:31 (rows 2, 3 take lane 31).
+__device__ __forceinline__ unsigned int hept_wave_scan_add(unsigned int x) {   // inclusive prefix sum over the 64 lanes
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);   // row_bcast:15 -> rows 1, 3
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ __forceinline__ unsigned int hept_wave_sum(unsigned int x) {   // the same value in every lane
+    return (unsigned int)__builtin_amdgcn_readlane((int)hept_wave_scan_add(x), 63);
+}
+__device__ __forceinline__ unsigned int hept_wave_max(unsigned int x) {
+    auto mx = [](unsigned int a, unsigned int b) { return a > b ? a : b; };
+    x = mx(x, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true));
+    x = mx(x, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true));
+    x = mx(x, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true));
+    x = mx(x, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true));
+    x = mx(x, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true));
+    x = mx(x, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true));
+    return (unsigned int)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // ---- entry points shared between translation units (not part of the C ABI) ---------------------------------------------
 // hept_prep_hash / hept_prep_hash_fused with the RPE weight math folded in (prep_hash.hip): K == 0: `sqrt_w` is
 // sqrt_w (H, C); K > 0: it is w_rpe.weight (H*D, (C-1)*K) and the kernels compute the scale in their prologue.

@@ -253,12 +253,7 @@ __global__ __launch_bounds__(SCT) void chunk_sort_kernel(
     __syncthreads();
     // digit `tid`: exclusive prefix over the digits -> first local position of the digit
     const unsigned int total = digit ? cnt_s[tid] : 0u;
-    unsigned int incl = total;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int y = __shfl_up(incl, off);
-        if (lane >= off) incl += y;
-    }
+    const unsigned int incl = hept_wave_scan_add(total);
     if (digit && lane == 63) wsum_s[w] = incl;
     __syncthreads();
     const int n_valid = max(0, min(SORT_CHUNK, len - base));
@@ -350,23 +345,14 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         // every wave builds the table by itself (same values, written twice): no barrier before the lookups
         unsigned int a0 = 0, a1 = 0;
         if (lane < n_chunks) { a0 = btab[(size_t)lane * TAB]; a1 = btab[(size_t)lane * TAB + 1]; }
-        unsigned int incl = a1 - a0, ssum = a0, lmax = a1 - a0;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int y = __shfl_up(incl, off);
-            if (lane >= off) incl += y;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            ssum += __shfl_xor(ssum, off);
-            lmax = max(lmax, (unsigned int)__shfl_xor((int)lmax, off));
-        }
-        longest = (int)lmax;
+        const unsigned int incl = hept_wave_scan_add(a1 - a0);
+        const unsigned int ssum = hept_wave_sum(a0);
+        longest = (int)hept_wave_max(a1 - a0);
         if (lane < n_chunks) {
             roff_s[lane] = incl - (a1 - a0);
             rbase_s[lane] = (unsigned int)lane * SORT_CHUNK + a0;
         }
-        nb = (int)__shfl(incl, 63);
+        nb = __builtin_amdgcn_readlane((int)incl, 63);
         start = (int)ssum;
         if (lane == 0) roff_s[n_chunks] = (unsigned int)nb;
     } else {
@@ -459,6 +445,10 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
 #endif
     unsigned long long mine[ITEMS];
     unsigned long long vmask = 0;   // bit u: slot u holds a pair (ITEMS <= 64)
+    // slots in use anywhere in the workgroup (uniform): the passes below stop there instead of stepping through the
+    // predicated-off code of the empty slots (the kernel is bound by VALU issue)
+    const int n_slots = by_run ? min(ITEMS, (longest + (1 << lpr_log) - 1) >> lpr_log)
+                               : (n_reg + BKT_THREADS - 1) / BKT_THREADS;
     if (by_run) {
         const int rc = tid >> lpr_log, rl = tid & ((1 << lpr_log) - 1);
         int rlen = 0;
@@ -469,6 +459,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         }
 #pragma unroll
         for (int u = 0; u < ITEMS; ++u) {
+            if (ITEMS <= 16 && u >= n_slots) break;   // (longer register tiles: the early exit would keep the loop from unrolling)
             const int j = rl + (u << lpr_log);
             mine[u] = j < rlen ? rsrc[j] : 0ull;
             vmask |= j < rlen ? 1ull << u : 0ull;
@@ -476,6 +467,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     } else {
 #pragma unroll
         for (int u = 0; u < ITEMS; ++u) {
+            if (ITEMS <= 16 && u >= n_slots) break;   // (longer register tiles: the early exit would keep the loop from unrolling)
             const int i = u * BKT_THREADS + tid;
             mine[u] = i < n_reg ? pair_at((unsigned int)i) : 0ull;
             vmask |= i < n_reg ? 1ull << u : 0ull;
@@ -507,12 +499,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         unsigned int c[BKT_BINS_PER_THREAD], tot = 0;
 #pragma unroll
         for (int u = 0; u < BKT_BINS_PER_THREAD; ++u) { c[u] = bin_s[BKT_BINS_PER_THREAD * tid + u]; tot += c[u]; }
-        unsigned int incl = tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int y = __shfl_up(incl, off);
-            if (lane >= off) incl += y;
-        }
+        const unsigned int incl = hept_wave_scan_add(tot);
         if (lane == 63) wsum_s[w] = incl;
         __syncthreads();
         unsigned int run = incl - tot;
@@ -530,8 +517,10 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     int n_low = nb;  // pairs in the lower half of the id bins (two-pass buckets)
     if (in_lds) {
 #pragma unroll
-        for (int u = 0; u < ITEMS; ++u)
+        for (int u = 0; u < ITEMS; ++u) {
+            if (ITEMS <= 16 && u >= n_slots) break;   // (longer register tiles: the early exit would keep the loop from unrolling)
             if (valid(u)) atomicAdd(&bin_s[lo_of(mine[u])], 1u);
+        }
         for_rest([&](unsigned long long p) { atomicAdd(&bin_s[lo_of(p)], 1u); });
         prefix_bins();
         if (nb > CAP) {
@@ -563,8 +552,10 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
                 __syncthreads();
             }
 #pragma unroll
-        for (int u = 0; u < ITEMS; ++u)
+        for (int u = 0; u < ITEMS; ++u) {
+            if (ITEMS <= 16 && u >= n_slots) break;   // (longer register tiles: the early exit would keep the loop from unrolling)
             if (valid(u)) atomicAdd(&bin_s[lo_of(mine[u])], 1u);
+        }
         for_rest([&](unsigned long long p) { atomicAdd(&bin_s[lo_of(p)], 1u); });
         prefix_bins();
     }
@@ -594,11 +585,13 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
             const unsigned int half = (unsigned int)ps;                  // bins [0, LOBINS/2) then [LOBINS/2, LOBINS)
             const int off = ps ? n_low : 0, cnt = n_pass == 2 ? (ps ? nb - n_low : n_low) : nb;
 #pragma unroll
-            for (int u = 0; u < ITEMS; ++u)
+            for (int u = 0; u < ITEMS; ++u) {
+                if (ITEMS <= 16 && u >= n_slots) break;   // (longer register tiles: the early exit would keep the loop from unrolling)
                 if (valid(u)) {
                     const unsigned int d = lo_of(mine[u]);
                     if (n_pass == 1 || (d >> (TOP_SHIFT - 1)) == half) tile_s[atomicAdd(&bin_s[d], 1u) - off] = mine[u];
                 }
+            }
             for_rest([&](unsigned long long p) {
                 const unsigned int d = lo_of(p);
                 if (n_pass == 1 || (d >> (TOP_SHIFT - 1)) == half) tile_s[atomicAdd(&bin_s[d], 1u) - off] = p;
@@ -610,8 +603,10 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     } else {
         unsigned long long* g = scratch + (size_t)seg * N + start;
 #pragma unroll
-        for (int u = 0; u < ITEMS; ++u)
+        for (int u = 0; u < ITEMS; ++u) {
+            if (ITEMS <= 16 && u >= n_slots) break;   // (longer register tiles: the early exit would keep the loop from unrolling)
             if (valid(u)) g[atomicAdd(&bin_s[lo_of(mine[u])], 1u)] = mine[u];
+        }
         for_rest([&](unsigned long long p) { g[atomicAdd(&bin_s[lo_of(p)], 1u)] = p; });
         __threadfence_block();
         __syncthreads();
@@ -816,12 +811,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
         unsigned int c[BPT], tot = 0;
 #pragma unroll
         for (int u = 0; u < BPT; ++u) { c[u] = bin_s[BPT * tid + u]; tot += c[u]; }
-        unsigned int incl = tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int y = __shfl_up(incl, off);
-            if (lane >= off) incl += y;
-        }
+        const unsigned int incl = hept_wave_scan_add(tot);
         if (lane == 63) wsum_s[w] = incl;
         __syncthreads();
         unsigned int run = incl - tot;
