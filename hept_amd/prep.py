@@ -130,14 +130,19 @@ def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Di
     # packed codes must stay below 2^24 (they are sorted as exact fp32 keys): the largest region counts per axis are read
     # from the tensor on EVERY call -- no cache keyed on a version counter that `.data` updates do not bump -- and ride
     # in the boundaries' device-to-host copy, so the check costs no extra synchronisation
-    reg_hi = torch.ceil(regions.amax(dim=(0, 2))).to(edges.dtype)
-    host = torch.cat([edges, reg_hi]).cpu()
-    sizes = host[:n_clouds + 1].diff()
+    # (two launches: the maxima, and a concatenation that promotes the boundaries to float32 -- exact below 2^24 points)
+    if n_raw < (1 << 24):
+        host = torch.cat([edges, regions.amax(dim=(0, 2))]).cpu()
+    else:
+        host = torch.cat([edges.double(), regions.amax(dim=(0, 2)).double()]).cpu()
+    sizes = host[:n_clouds + 1].diff().long()
     if int(sizes.min()) < 1:
         raise ValueError("every cloud id in [0, batch.max()] must own at least one point")
     padded = ((sizes + block_size - 1) // block_size) * block_size
     max_cloud, n_pad = int(sizes.max()), int(padded.sum())
-    bits = sum((int(host[n_clouds + 1 + a]) + 1).bit_length() for a in (0, 1))
+    import math
+
+    bits = sum((int(math.ceil(float(host[n_clouds + 1 + a]))) + 1).bit_length() for a in (0, 1))
     if (n_clouds << bits) >= (1 << 24):
         raise ValueError("AND codes would exceed 2^24: too many clouds x regions for the fp32-keyed pad sort")
     pad_start = torch.cat([torch.zeros(1, dtype=torch.int64), padded.cumsum(0)]).to(torch.int32).to(dev, non_blocking=True)
