@@ -61,12 +61,28 @@ template <int NT>
 __device__ __forceinline__ void rpe_scale_lds(const float* __restrict__ w, int H, int D, int C, int K,
                                               float* __restrict__ sw_s, float* __restrict__ term_s) {
     const int R = C - 1, RK = R * K, total = H * RK;
-    for (int i = threadIdx.x; i < total; i += NT) {
-        const int h = i / RK, rk = i - h * RK;
-        float s = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < D; ++d) s += w[(size_t)(h * D + d) * RK + rk];
-        term_s[i] = expf(fminf(s, 50.f));
+    // the loads of BOTH terms a thread may own (total <= 1024 = 4 NT at the least) are issued before the first sum: the
+    // prologue is a chain of L2 round trips, and 8 loads in flight per thread made it five of them (~3 us per launch)
+    constexpr int TPT = 1024 / NT;   // terms per thread at the largest supported total
+    for (int i0 = threadIdx.x; i0 < total; i0 += NT * TPT) {
+        float v[TPT][28];
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int i = i0 + u * NT;
+            const int h = i / RK, rk = i - h * RK;
+#pragma unroll
+            for (int d = 0; d < 28; ++d)
+                v[u][d] = (i < total && d < D) ? w[(size_t)(h * D + d) * RK + rk] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int i = i0 + u * NT;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 28; ++d)
+                if (d < D) s += v[u][d];      // ascending d, as rpe_scale_kernel
+            if (i < total) term_s[i] = expf(fminf(s, 50.f));
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < H * R; i += NT) {
