@@ -294,6 +294,11 @@ void block_attn_kernel(const char* __restrict__ qhat,
 // into registers, P in registers after the exp.  The norms -|q|^2/2, -|k|^2/2 ride in the product
 // through the two spare columns (30, 31) against a 1.0 on the other side.
 // Inputs, outputs and the (t, block, head) -> workgroup map are those of the f32-tile kernel.
+// (Round 3, the reference's own block_size 100 = three full 32-row tiles + 4 rows: both kernels were also built on 16-row
+//  tiles, v_mfma_f32_16x16x32_bf16 -- 7 x 7 tile pairs instead of 4 x 4 padded ones.  16-bit tiles: 90.2 us against 89.9 us
+//  (bound by the gathers, not by issue).  f32 split tiles, two query tiles per wave: 197 us against 213 us as a kernel
+//  timed back to back on cache-warm rows, but 357 us against 355 us per forward in place, where its gathers run cold --
+//  the one-tile-per-wave form was LDS-bound at 241 us.  Neither was kept: DESIGN.md section 6.)
 template <int NKT, bool FULL, int VP>
 __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float* __restrict__ qhat,
                                                                     const float* __restrict__ kvhat,
@@ -528,256 +533,6 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
     return hept_launch_status();
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// f32 tiles, 16-row MFMA tiles (v_mfma_f32_16x16x32_bf16), for blocks that 32-row tiles pad badly: the reference's own
-// block_size is 100 (src/configs/tracking/tracking_trans_hept.yaml:12) -- 7 x 7 tile pairs of 16 x 16 (12 544 padded
-// logits per block) instead of 4 x 4 of 32 x 32 (16 384).  The split-bf16 kernel is bound by instruction issue (MFMA +
-// split / exp VALU), so its time follows the padded area.  Taken when ceil(B / 16) is odd, i.e. when the last 32-row
-// tile would be less than half full.  (The 16-bit-tile kernels are bound by their gathers, not by issue: the same
-// tiling was built for them, measured at B = 100 -- 90.2 us against 89.9 us -- and not kept; so was a three-wave
-// workgroup whose first wave serves the 4 tail queries in a pass of its own: bit-identical rows, 100 us against 89.)
-//
-// One wave = two query tiles (16 queries each) x all NT16 key tiles; K^ / V bf16 planes are staged 64 keys at a time
-// exactly as in block_attn_split_kernel.  Per key tile: X = K^ . Q^T is SIX 16x16x32 MFMAs (the row's 32 columns are the whole K
-// dimension; norms ride in columns 30, 31), P = exp(min(X, 0)) -- 4 per lane.  Per PAIR of key tiles and 16-column half
-// of the output: Z += P^T-as-A . V, six MFMAs; the A operand takes 8 consecutive k per lane = the lane's 4 keys of
-// either tile, V comes through ds_read_b64_tr_b16 in that key order.  Lane group g = lane >> 4 holds accumulator rows
-// 4g .. 4g+3; the K^ rows are read through pi(i) = i with bits 2 and 3 exchanged, so that group g's keys are rows
-// {0,8,4,12}[g] + r of the tile and the two transposed V blocks of a 32-lane half lie 8 rows apart (conflict-free).
-template <int NT16>
-__global__ __launch_bounds__(64 * ((NT16 + 1) / 2)) void block_attn_split16_kernel(const float* __restrict__ qhat,
-                                                                                   const float* __restrict__ kvhat,
-                                                                                   const int* __restrict__ qpos,
-                                                                                   const int* __restrict__ kpos,
-                                                                                   float* __restrict__ part, int N, int H,
-                                                                                   int D, int B, int nb, HeadRange hr,
-                                                                                   PushArgs pa) {
-    if (pa.push_wgs > 0 && (int)blockIdx.x < pa.push_wgs) {   // see block_attn_kernel
-        reduce_push_body<false>(pa, (int)blockIdx.x);
-        return;
-    }
-    // one wave = TWO query tiles: every K^ / V fragment read from LDS serves both (one tile per wave reads twice the
-    // LDS bytes per MFMA of the 32-row-tile kernel and is bound by the LDS array: measured 241 us against 206 us)
-    constexpr int NW = (NT16 + 1) / 2;
-    constexpr int NT = 64 * NW;
-    constexpr int PROW = 64;                    // bytes of one 32-column bf16 plane row
-    constexpr int CK = 64;                      // keys staged at a time (4 key tiles): 24 KB of planes
-    constexpr int KEYS = 32 * NW;               // key tiles padded to an even count (zero rows)
-    constexpr int NCH = (KEYS + CK - 1) / CK;
-    constexpr int IPT = (CK * 8 + NT - 1) / NT; // 8-column items per thread and chunk
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_s = smem;                   // 3 planes [CK][32 bf16], 16-B chunks XOR-swizzled
-    char* v_s = smem + 3 * CK * PROW;   // 3 planes [CK][32 bf16], read transposed
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l16 = lane & 15;
-    const int bid = (int)blockIdx.x - pa.push_wgs;
-    const int h = hr.h0 + bid % hr.hg;
-    const int rest = bid / hr.hg;
-    const int b = rest % nb, t = rest / nb;
-    const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
-    const int* __restrict__ kp = kpos + seg;
-    const int* __restrict__ qp = qpos + seg;
-    const float* __restrict__ qbase = qhat + (size_t)h * N * 32;
-    const float* __restrict__ kvbase = kvhat + (size_t)h * N * 64;
-
-    // ---- gathered kvhat rows of chunk ch -> registers (one item = 8 consecutive columns; c < 4: K^, c >= 4: V)
-    float pre[IPT][8];
-    auto fetch = [&](int ch) {
-#pragma unroll
-        for (int it = 0; it < IPT; ++it) {
-            const int ci = it * NT + tid;
-            const int key = ch * CK + (ci >> 3), c = ci & 7;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pre[it][j] = 0.f;
-            if (ci < CK * 8 && key < B) {
-                const float* src = kvbase + (size_t)kp[key] * 64 + c * 8;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
-                pre[it][0] = a0[0]; pre[it][1] = a0[1]; pre[it][2] = a0[2]; pre[it][3] = a0[3];
-                pre[it][4] = a1[0]; pre[it][5] = a1[1]; pre[it][6] = a1[2]; pre[it][7] = a1[3];
-                if (c == 3) pre[it][6] = 1.f;  // k^ columns (30, 31) = (1, -|k|^2/2)
-            }
-        }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int it = 0; it < IPT; ++it) {
-            const int ci = it * NT + tid;
-            if (ci >= CK * 8) break;
-            const int row = ci >> 3, c = ci & 7;
-            u32x4 ph, pm, pl;
-            split3_bf16(pre[it], ph, pm, pl);
-            if (c < 4) {
-                const int off = row * PROW + ((c ^ ((row >> 2) & 3)) * 16);
-                *reinterpret_cast<u32x4*>(k_s + off) = ph;
-                *reinterpret_cast<u32x4*>(k_s + CK * PROW + off) = pm;
-                *reinterpret_cast<u32x4*>(k_s + 2 * CK * PROW + off) = pl;
-            } else {
-                const int off = row * PROW + (c - 4) * 16;
-                *reinterpret_cast<u32x4*>(v_s + off) = ph;
-                *reinterpret_cast<u32x4*>(v_s + CK * PROW + off) = pm;
-                *reinterpret_cast<u32x4*>(v_s + 2 * CK * PROW + off) = pl;
-            }
-        }
-    };
-    fetch(0);
-
-    // ---- this wave's 2 x 16 query rows -> three bf16 planes in registers (B-operand layout: lane = (query l16,
-    //      columns 8g .. 8g + 7))
-    const bool two = 2 * w + 1 < NT16;   // the wave's second query tile exists (uniform)
-    int qsrc[2];
-    u32x4 qh[2], qm[2], ql[2];
-#pragma unroll
-    for (int qe = 0; qe < 2; ++qe) {
-        const int qi = (2 * w + qe) * 16 + l16;
-        qsrc[qe] = qp[qi < B ? qi : 0];
-        const float* qrow = qbase + (size_t)qsrc[qe] * 32 + 8 * g;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(qrow);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(qrow + 4);
-        float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        if (g == 3) {   // the norms ride in the product: q^[30] = -|q|^2/2 meets k^[30] = 1, q^[31] = 1 meets -|k|^2/2
-            a[6] = a[7];
-            a[7] = 1.f;
-        }
-        split3_bf16(a, qh[qe], qm[qe], ql[qe]);
-    }
-
-    typedef __attribute__((ext_vector_type(4))) float f32x4v;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    auto mfma16 = [](const u32x4& a, const u32x4& bb, f32x4v c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), c, 0, 0, 0);
-    };
-    f32x4v z[2][2];
-#pragma unroll
-    for (int qe = 0; qe < 2; ++qe)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) z[qe][hf] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    // lane parts of the LDS addresses: K^ row pi(l16) of a tile, chunk g; V block rows {0,8,4,12}[g] + q, columns 4p..
-    const int krow = (l16 & 3) | ((l16 & 4) << 1) | ((l16 & 8) >> 1);
-    const int koff = krow * PROW + ((g ^ ((krow >> 2) & 3)) * 16);
-    const int gbase = ((g & 1) << 3) | ((g & 2) << 1);          // {0, 8, 4, 12}[g]
-    const int voff = (gbase + (l16 >> 2)) * PROW + (l16 & 3) * 8;
-
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        if (ch > 0) __syncthreads();       // every wave is done with the previous chunk's planes
-        stage();
-        if (ch + 1 < NCH) fetch(ch + 1);
-        __syncthreads();
-#pragma unroll
-        for (int kp2 = 0; kp2 < CK / 32; ++kp2) {
-            if (ch * CK + kp2 * 32 >= KEYS) break;   // compile-time after unrolling
-            float pa8[2][8];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int kt = ch * (CK / 16) + 2 * kp2 + e;   // key tile of the block
-                const int off = (2 * kp2 + e) * 16 * PROW + koff;
-                const u32x4 kh = *reinterpret_cast<const u32x4*>(k_s + off);
-                const u32x4 km = *reinterpret_cast<const u32x4*>(k_s + CK * PROW + off);
-                const u32x4 kl = *reinterpret_cast<const u32x4*>(k_s + 2 * CK * PROW + off);
-#pragma unroll
-                for (int qe = 0; qe < 2; ++qe) {
-                    if (qe == 1 && !two) break;   // uniform
-                    f32x4v x = {0.f, 0.f, 0.f, 0.f};
-                    x = mfma16(kl, qh[qe], x);
-                    x = mfma16(kh, ql[qe], x);
-                    x = mfma16(km, qm[qe], x);
-                    x = mfma16(km, qh[qe], x);
-                    x = mfma16(kh, qm[qe], x);
-                    x = mfma16(kh, qh[qe], x);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float p = fminf(__expf(x[r]), 1.f);          // = exp(min(x, 0)), see block_attn_kernel
-                        if ((kt + 1) * 16 > B && kt * 16 + gbase + r >= B) p = 0.f;   // padded keys carry no weight
-                        pa8[qe][4 * e + r] = p;
-                    }
-                }
-            }
-            u32x4 ph[2], pm[2], pl3[2];
-#pragma unroll
-            for (int qe = 0; qe < 2; ++qe) {
-                if (qe == 1 && !two) break;
-                split3_bf16(pa8[qe], ph[qe], pm[qe], pl3[qe]);
-            }
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                u32x4 vpl[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const char* vb = v_s + pl * CK * PROW + (2 * kp2) * 16 * PROW + voff + hf * 32;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vb));
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vb + 16 * PROW));
-                    const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    vpl[pl] = __builtin_bit_cast(u32x4, vv);
-                }
-#pragma unroll
-                for (int qe = 0; qe < 2; ++qe) {
-                    if (qe == 1 && !two) break;
-                    z[qe][hf] = mfma16(pl3[qe], vpl[0], z[qe][hf]);
-                    z[qe][hf] = mfma16(ph[qe], vpl[2], z[qe][hf]);
-                    z[qe][hf] = mfma16(pm[qe], vpl[1], z[qe][hf]);
-                    z[qe][hf] = mfma16(pm[qe], vpl[0], z[qe][hf]);
-                    z[qe][hf] = mfma16(ph[qe], vpl[1], z[qe][hf]);
-                    z[qe][hf] = mfma16(ph[qe], vpl[0], z[qe][hf]);
-                }
-            }
-        }
-    }
-
-    // ---- scatter: row = 32 floats = one 128-B line per query; lane (column 16 hf + l16, rows 4g + r)
-    float* __restrict__ pt = part + (size_t)t * hr.tstride_rows * 32 + (size_t)(h - hr.hsub) * 32;
-#pragma unroll
-    for (int qe = 0; qe < 2; ++qe) {
-        if (qe == 1 && !two) break;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q2 = (2 * w + qe) * 16 + 4 * g + r;
-            const int dst = __shfl(qsrc[qe], 4 * g + r);  // lane l16 holds the source row of query l16 of the tile
-            if (q2 < B) {
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int col = 16 * hf + l16;
-                    float val = z[qe][hf][r];
-                    if (col == D) val += 1e-20f;  // example/hept.py:14
-                    if (pa.direct) {   // see block_attn_kernel
-                        bool remote;
-                        char* rowp = direct_row(pa, dst, h - hr.h0, 128, remote) + col * 4;
-                        if (remote) store4_system(rowp, __float_as_uint(val));
-                        else *reinterpret_cast<float*>(rowp) = val;
-                    } else {
-                        pt[(size_t)dst * hr.hout * 32 + col] = val;
-                    }
-                }
-            }
-        }
-    }
-    if (pa.direct) signal_when_all_done(pa.counter, pa.peers, pa.world, pa.flag_idx, pa.epoch);
-}
-
-int launch_attn_split16(int nt16, dim3 grid, hipStream_t st, const float* qhat, const float* kvhat, const int* qpos,
-                        const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
-    constexpr size_t lds = (size_t)6 * 64 * 64;   // six planes of 64 keys
-#define HEPT_SPLIT16_CASE(K)                                                                                          \
-    case K:                                                                                                           \
-        hipLaunchKernelGGL((block_attn_split16_kernel<K>), grid, dim3(64 * ((K + 1) / 2)), lds, st, qhat, kvhat, qpos, kpos, part, N, \
-                           H, D, B, nb, hr, pa);                                                                      \
-        break;
-    switch (nt16) {
-        HEPT_SPLIT16_CASE(1)
-        HEPT_SPLIT16_CASE(3)
-        HEPT_SPLIT16_CASE(5)
-        HEPT_SPLIT16_CASE(7)
-        HEPT_SPLIT16_CASE(9)
-        HEPT_SPLIT16_CASE(11)
-        HEPT_SPLIT16_CASE(13)
-        HEPT_SPLIT16_CASE(15)
-        default:
-            return HEPT_ERR_SHAPE;
-    }
-#undef HEPT_SPLIT16_CASE
-    return hept_launch_status();
-}
-
 template <bool BF16, bool P16, bool F16QK, bool FULL>
 int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
                 const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
@@ -856,11 +611,6 @@ int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, co
         const float* qf = (const float*)qhat;
         const float* kf = (const float*)kvhat;
         if (B == 32 * nkt) return launch_attn_split<true, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr, pa);
-#ifndef HEPT_ATTN_NO_TILE16
-        // 16-row tiles when the last 32-row tile would be less than half full (ceil(B / 16) odd): B = 100 -> 7 x 7
-        if ((((B + 15) / 16) & 1) != 0)
-            return launch_attn_split16((B + 15) / 16, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr, pa);
-#endif
         return launch_attn_split<false, 3>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr, pa);
     }
     if (precision == HEPT_PREC_F32_MFMA)

@@ -159,8 +159,11 @@ int hept_combine_groups(const float* part, int part_precision, int Tl, int N, in
                         const float* out_bias, float* out, void* stream);
 
 /* Whole operator for tables [t0, t0+Tl): everything above in one call.
- * K == 0 (every whole-operator entry point): `w_rpe` is not the (H*D, (C-1)*K) weight but the (H, C) result of
- * hept_rpe_scale on it -- a caller whose w_rpe.weight is constant (inference) computes it once and saves the launch.
+ * K > 0: `w_rpe` is w_rpe.weight (H*D, (C-1)*K); its scale sqrt_w (H, C) (example/hept.py:22-25) is computed inside
+ * the row builder's prologue on EVERY call -- nothing derived from a parameter is remembered between calls, so an
+ * in-place update of the weight is always seen (the reference recomputes it every forward as well); H*(C-1)*K <= 1024.
+ * K == 0 (every whole-operator entry point): `w_rpe` is the (H, C) result of hept_rpe_scale instead -- for a caller
+ * that manages the scale itself.
  * hept_forward writes out (N, D); hept_forward_partial stops at acc (N, H, row) in the row format
  * acc_precision (HEPT_PREC_F32, or hept_part_precision(precision, D)). */
 int hept_forward(const float* q, const float* k, const float* v, const float* coords,
@@ -228,9 +231,16 @@ size_t hept_exchange_bytes(int N, int H, int D, int world, int precision);
  * rank that finishes its point, raises an epoch flag there when a head group is complete, polls its own flags before
  * the combine, stores its finished output slice into every rank's buffer and copies the gathered output to out_full
  * once every slice has arrived (xbuf is not used).  Calls are collective: every rank makes the same sequence.
- * A wait is bounded (20 s, sticky): hept_comm_status reports bit 0 (rows) / bit 1 (output) after a timeout, and the
- * results of that call are undefined -- fall back to HEPT_TRANSPORT_RCCL.  hept_comm_create_local makes a
- * communicator without RCCL (one-sided transport only; at most 16 ranks). */
+ * One local table per rank (Tl == 1, BASELINE config 4): the block attention itself stores every finished row into
+ * the owner's buffer (16-byte pieces of 64-byte rows) and raises the flags -- no table sum, no separate push.
+ * A wait is bounded (20 s, HEPT_P2P_TIMEOUT_S; sticky).  After a timeout the step's output is written as NaN on the
+ * rank that timed out and the slice it sends to the others is NaN as well -- a lost or slow peer never turns into
+ * plausible numbers -- and every later hept_forward_sharded on that communicator returns HEPT_ERR_COMM at once (the
+ * kernel that timed out wrote a host-mapped status word: no device synchronisation is needed to see it).
+ * hept_comm_status reports bit 0 (rows) / bit 1 (output) / bit 2 (a step failed on the host after taking its epoch).
+ * hept_comm_reset_status clears the failure AND restarts the protocol (epoch, flags, counters): every rank must call
+ * it, with a host barrier before the next exchange -- or fall back to HEPT_TRANSPORT_RCCL.  hept_comm_create_local
+ * makes a communicator without RCCL (one-sided transport only; at most 16 ranks). */
 #define HEPT_TRANSPORT_RCCL 0
 #define HEPT_TRANSPORT_ONE_SIDED 1
 #define HEPT_IPC_HANDLE_BYTES 64
@@ -240,7 +250,7 @@ int hept_comm_p2p_alloc(hept_comm* comm, size_t bytes, void* handle_out);
 int hept_comm_p2p_open(hept_comm* comm, const void* handles);
 int hept_comm_p2p_ready(const hept_comm* comm, size_t bytes);
 int hept_comm_status(hept_comm* comm, int* status);
-int hept_comm_reset_status(hept_comm* comm);   /* forget a recorded timeout (synchronises the device) */
+int hept_comm_reset_status(hept_comm* comm);   /* collective restart after a failure (synchronises the device) */
 /* debugging aid: this rank's HEPT_P2P_FLAG_BYTES bytes of arrival flags ([head group][source rank] u32 at byte 0,
  * output flags [source rank] u32 at byte 2048; each holds the epoch of the last arrival) and its own epoch */
 #define HEPT_P2P_FLAG_BYTES 4096
