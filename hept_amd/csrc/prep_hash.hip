@@ -381,12 +381,29 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
             hi = fmaxf(hi, r[1]);
             c = fmaxf(c, r[2]);
         }
-        // layout [Tl][H][HEPT_PREP_GRID][4]: the sort kernels reduce one (t,h) row with contiguous 16-B loads
-        *reinterpret_cast<f32x4*>(minmax + (((size_t)t * H + hh) * HEPT_PREP_GRID + slot) * 4) = f32x4{lo, hi, c, 0.f};
+        // layout [Tl][H][HEPT_PREP_GRID][4]: the sort kernels reduce one (t,h) row with contiguous 16-B loads.  The
+        // launch may have fewer workgroups per role than the role has slots: the spare slots get neutral values
+        f32x4* mrow = reinterpret_cast<f32x4*>(minmax + ((size_t)t * H + hh) * HEPT_PREP_GRID * 4);
+        mrow[slot] = f32x4{lo, hi, c, 0.f};
+        for (int s2 = slot + (int)gridDim.x; s2 < (slot / (HEPT_PREP_GRID / 2) + 1) * (HEPT_PREP_GRID / 2); s2 += (int)gridDim.x)
+            mrow[s2] = f32x4{INFINITY, -INFINITY, 0.f, 0.f};
     }
 }
 
-constexpr int PREP_WGS_PER_ROLE = HEPT_PREP_GRID / 2;  // q and k roles fill the HEPT_PREP_GRID partial slots
+constexpr int PREP_SLOTS_PER_ROLE = HEPT_PREP_GRID / 2;  // q and k roles fill the HEPT_PREP_GRID partial slots
+// Workgroups per role of a launch (<= the slots of a role; spare slots get neutral values): 3 x 341 = 1023 workgroups are
+// ONE round at four per CU -- 3 x 512 was a round and a half, and every q- / k-role workgroup pays the prologue (alpha
+// slab, the RPE weight math): 57.4 -> 54.8 us at tracking-60k.  Short clouds launch only the workgroups that get a tile.
+#ifndef HEPT_PREP_WGS
+#define HEPT_PREP_WGS 341
+#endif
+constexpr int PREP_WGS_PER_ROLE = HEPT_PREP_WGS;
+static_assert(PREP_WGS_PER_ROLE <= PREP_SLOTS_PER_ROLE, "every workgroup owns a partial slot");
+inline int prep_wgs(int N) {
+    const int tiles = (N + PREP_POINTS - 1) / PREP_POINTS, per_wg = PREP_THREADS / HEPT_WAVE;
+    const int want = (tiles + per_wg - 1) / per_wg;
+    return want < PREP_WGS_PER_ROLE ? (want < 1 ? 1 : want) : PREP_WGS_PER_ROLE;
+}
 
 template <int D, int C, int TILE, int TMAX>
 __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
                                  red_s, tile_s, minmax, blockIdx.x);
     else if (role == 1)
         prep_role<D, C, TILE, 1, TMAX>(k, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
-                                 red_s, tile_s, minmax, PREP_WGS_PER_ROLE + blockIdx.x);
+                                 red_s, tile_s, minmax, PREP_SLOTS_PER_ROLE + blockIdx.x);
     else
         prep_role<D, C, TILE, 2, TMAX>(v, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
                                  red_s, tile_s, minmax, 0);
@@ -466,7 +483,7 @@ void prep_fused_kernel(
                                        qproj, red_s, tile_s, minmax, blockIdx.x, fin);
     else if (role == 1)
         prep_role<D, C, TILE, 1, TMAX, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
-                                       kproj, red_s, tile_s, minmax, PREP_WGS_PER_ROLE + blockIdx.x, fin);
+                                       kproj, red_s, tile_s, minmax, PREP_SLOTS_PER_ROLE + blockIdx.x, fin);
     else
         prep_role<D, C, TILE, 2, TMAX, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
                                        nullptr, red_s, tile_s, minmax, 0, fin);
@@ -477,7 +494,7 @@ int launch_prep_fused(const float* x, const float* ln_w, const float* ln_b, floa
                       const float* wv, const float* coords, const float* sqrt_w, int K, const float* alpha,
                       const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision, void* qhat,
                       void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
-    const dim3 grid(PREP_WGS_PER_ROLE, 3);
+    const dim3 grid(prep_wgs(N), 3);
     // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
 #define HEPT_FUSED_LAUNCH(TILE, TMAX)                                                                                  \
     hipLaunchKernelGGL((prep_fused_kernel<C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, x, ln_w, ln_b, eps, wq, wk, \
@@ -500,7 +517,7 @@ int launch_prep(const float* q, const float* k, const float* v, const float* coo
                 const float* alpha, const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision,
                 void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
     // q- and k-role workgroups each write one of the HEPT_PREP_GRID partial slots the sort kernel reduces
-    const dim3 grid(PREP_WGS_PER_ROLE, 3);
+    const dim3 grid(prep_wgs(N), 3);
     // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
 #define HEPT_PREP_LAUNCH(TILE, TMAX)                                                                                 \
     hipLaunchKernelGGL((prep_hash_kernel<D, C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w, \
