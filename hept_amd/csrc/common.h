@@ -151,3 +151,7 @@ int hept_prep_hash_fused_rpe(const float* x, const float* norm_w, const float* n
                              const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T,
                              int t0, int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj,
                              float* minmax, void* stream);
+// hept_segmented_argsort for a caller that knows finite bounds of its keys (prepare.hip: packed code keys): the
+// per-segment range pass (a fill and a kernel) is skipped; any bounds give the exact stable sort
+int hept_segmented_argsort_bounded(const float* keys, int S, int L, float lo, float hi, void* ws, int32_t* pos,
+                                   void* stream);

@@ -30,10 +30,23 @@ __global__ __launch_bounds__(PT) void coord_keys_kernel(const float* __restrict_
     if (j < n_c) keys[(size_t)seg * L + j] = coords[(size_t)(s + j) * C + a];
 }
 
-// rank[a][point] = position of the point in its cloud's ascending order of coordinate a
+__device__ __forceinline__ void row_bits_body(const int* __restrict__ cloud_start, int n_clouds,
+                                              const float* __restrict__ regions, int T, int H,
+                                              int* __restrict__ row_max, int row, int lane);
+
+// rank[a][point] = position of the point in its cloud's ascending order of coordinate a.  The launch also carries, as
+// the blocks of one more grid row (blockIdx.y == S), the row maxima of the region ids (row_bits_body below: a few
+// dozen waves that depend on the cloud sizes only -- a launch of their own cost ~7 us of this launch-bound call)
 __global__ __launch_bounds__(PT) void rank_scatter_kernel(const int* __restrict__ pos,
                                                           const int* __restrict__ cloud_start, int L, int n_raw,
-                                                          int* __restrict__ rank) {
+                                                          int* __restrict__ rank, int S, int n_clouds,
+                                                          const float* __restrict__ regions, int T, int H,
+                                                          int* __restrict__ row_max) {
+    if ((int)blockIdx.y == S) {
+        for (int row = blockIdx.x * (PT / 64) + (threadIdx.x >> 6); row < T * H; row += gridDim.x * (PT / 64))
+            row_bits_body(cloud_start, n_clouds, regions, T, H, row_max, row, threadIdx.x & 63);
+        return;
+    }
     const int seg = blockIdx.y, c = seg >> 1, a = seg & 1;
     const int r = blockIdx.x * PT + threadIdx.x;
     const int s = cloud_start[c], n_c = cloud_start[c + 1] - s;
@@ -57,12 +70,26 @@ __device__ __forceinline__ int cloud_of(const int* __restrict__ cloud_start, int
     return lo;
 }
 
+// Sort key of the table-0 / head-0 codes.  A bare float(code) would hand the sort ~150 distinct values for 60 000
+// points: tie groups of 400, which its in-group ranking pays for quadratically (60 us for this one segment).  The
+// stable order wanted is (code, index), so the key carries the leading index bits below the code,
+//     key = code << k | index >> s,      k = 24 - bits(code),  s = bits(index) - k   (both >= 0),
+// exact in fp32 (< 2^24), monotone in (code, index): equal keys are now runs of at most 2^s consecutive indices and
+// the final order is unchanged.  Every key lies in [0, 2^24): the sort is told so and skips its range pass.
+__device__ __forceinline__ float code_sort_key(int64_t code, int n, int n_raw, int n_clouds, int packed_max_row0) {
+    const int code_bits = bit_length(n_clouds - 1) + bit_length(packed_max_row0);   // codes < 2^24 (checked by the caller)
+    const int k = code_bits < 24 ? 24 - code_bits : 0;
+    const int idx_bits = bit_length(n_raw - 1);
+    const int sh = idx_bits > k ? idx_bits - k : 0;
+    return (float)((code << k) | (int64_t)(n >> sh));
+}
+
 // final codes of one (table, head) row: (cloud << bits1) | (phi_region << bits0) | eta_region, the bit widths from
 // row_bits_kernel
 __global__ __launch_bounds__(PT) void codes_kernel(const int* __restrict__ rank, const int* __restrict__ cloud_start,
                                                    int n_clouds, int n_raw, const float* __restrict__ regions, int T,
                                                    int H, const int* __restrict__ row_max /* [2][T*H] */,
-                                                   int64_t* __restrict__ codes_raw) {
+                                                   int64_t* __restrict__ codes_raw, float* __restrict__ code_keys) {
     const int row = blockIdx.y, t = row / H, h = row % H;
     const int n = blockIdx.x * PT + threadIdx.x;
     if (n >= n_raw) return;
@@ -71,20 +98,22 @@ __global__ __launch_bounds__(PT) void codes_kernel(const int* __restrict__ rank,
     const int eta = region_of(rank[n], n_c, regions[((size_t)t * 2 + 0) * H + h]);
     const int phi = region_of(rank[(size_t)n_raw + n], n_c, regions[((size_t)t * 2 + 1) * H + h]);
     const int p1 = (phi << bit_length(row_max[row])) | eta;
-    codes_raw[(size_t)row * n_raw + n] = ((int64_t)c << bit_length(row_max[(size_t)T * H + row])) | (int64_t)p1;
+    const int64_t code = ((int64_t)c << bit_length(row_max[(size_t)T * H + row])) | (int64_t)p1;
+    codes_raw[(size_t)row * n_raw + n] = code;
+    if (row == 0) code_keys[n] = code_sort_key(code, n, n_raw, n_clouds, row_max[(size_t)T * H]);
 }
 
 // Largest region ids of a row without touching the points: ranks run 0 .. n_c - 1 in every cloud and region_of is
 // monotone in the rank, so the row maximum is the maximum over the clouds of region_of(n_c - 1).  The packing only
 // needs bit lengths: bit_length((phi << b) | eta) = bit_length(phi) + b for phi >= 1 (region ids start at 1), so
 // row_max[1][row] = (phi_max << b) | eta_max has the bit length of the true maximum of the packed values.
-__global__ __launch_bounds__(64) void row_bits_kernel(const int* __restrict__ cloud_start, int n_clouds,
-                                                      const float* __restrict__ regions, int T, int H,
-                                                      int* __restrict__ row_max /* [2][T*H] */) {
-    const int row = blockIdx.x, t = row / H, h = row % H;
+__device__ __forceinline__ void row_bits_body(const int* __restrict__ cloud_start, int n_clouds,
+                                              const float* __restrict__ regions, int T, int H,
+                                              int* __restrict__ row_max /* [2][T*H] */, int row, int lane) {
+    const int t = row / H, h = row % H;
     const float r_eta = regions[((size_t)t * 2 + 0) * H + h], r_phi = regions[((size_t)t * 2 + 1) * H + h];
     int eta = 0, phi = 0;
-    for (int c = threadIdx.x; c < n_clouds; c += 64) {
+    for (int c = lane; c < n_clouds; c += 64) {
         const int n_c = cloud_start[c + 1] - cloud_start[c];
         if (n_c > 0) {
             eta = max(eta, region_of(n_c - 1, n_c, r_eta));
@@ -96,28 +125,10 @@ __global__ __launch_bounds__(64) void row_bits_kernel(const int* __restrict__ cl
         eta = max(eta, __shfl_xor(eta, off));
         phi = max(phi, __shfl_xor(phi, off));
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         row_max[row] = eta;
         row_max[(size_t)T * H + row] = (phi << bit_length(eta)) | eta;
     }
-}
-
-// Sort key of the table-0 / head-0 codes.  A bare float(code) would hand the sort ~150 distinct values for 60 000
-// points: tie groups of 400, which its in-group ranking pays for quadratically (60 us for this one segment).  The
-// stable order wanted is (code, index), so the key carries the leading index bits below the code,
-//     key = code << k | index >> s,      k = 24 - bits(code),  s = bits(index) - k   (both >= 0),
-// exact in fp32 (< 2^24), monotone in (code, index): equal keys are now runs of at most 2^s consecutive indices and
-// the final order is unchanged.
-__global__ __launch_bounds__(PT) void code_keys_kernel(const int64_t* __restrict__ codes_row0, int n_raw, int n_clouds,
-                                                       const int* __restrict__ row_max, int rows,
-                                                       float* __restrict__ keys) {
-    const int n = blockIdx.x * PT + threadIdx.x;
-    if (n >= n_raw) return;
-    const int code_bits = bit_length(n_clouds - 1) + bit_length(row_max[rows]);   // codes < 2^24 (checked by the caller)
-    const int k = code_bits < 24 ? 24 - code_bits : 0;
-    const int idx_bits = bit_length(n_raw - 1);
-    const int sh = idx_bits > k ? idx_bits - k : 0;
-    keys[n] = (float)((codes_row0[n] << k) | (int64_t)(n >> sh));
 }
 
 // one thread per padded slot: gather index, un-pad mask, padded coords; blockIdx.y > 0: padded codes of one row
@@ -283,13 +294,11 @@ extern "C" int hept_prepare_input(const float* coords, int C, const int32_t* clo
     hipLaunchKernelGGL(coord_keys_kernel, gridL, dim3(PT), 0, st, coords, C, cloud_start, L, keys, seg_len);
     int rc = hept_segmented_argsort_ragged(keys, S, L, seg_len, sort_ws, pos, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(rank_scatter_kernel, gridL, dim3(PT), 0, st, pos, cloud_start, L, n_raw, rank);
-    hipLaunchKernelGGL(row_bits_kernel, dim3(rows), dim3(64), 0, st, cloud_start, n_clouds, regions, T, H, row_max);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(gridL.x, S + 1), dim3(PT), 0, st, pos, cloud_start, L, n_raw, rank, S,
+                       n_clouds, regions, T, H, row_max);
     hipLaunchKernelGGL(codes_kernel, gridN, dim3(PT), 0, st, rank, cloud_start, n_clouds, n_raw, regions, T, H, row_max,
-                       codes_raw);
-    hipLaunchKernelGGL(code_keys_kernel, dim3((n_raw + PT - 1) / PT), dim3(PT), 0, st, codes_raw, n_raw, n_clouds, row_max,
-                       rows, ckeys);
-    rc = hept_segmented_argsort(ckeys, 1, n_raw, sort_ws, by_code, stream);
+                       codes_raw, ckeys);
+    rc = hept_segmented_argsort_bounded(ckeys, 1, n_raw, 0.f, 16777216.f, sort_ws, by_code, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(pad_gather_kernel, dim3((n_pad + PT - 1) / PT, rows + 1), dim3(PT), 0, st, cloud_start, pad_start,
                        n_clouds, n_raw, n_pad, B, by_code, coords, C, codes_raw, rows, pad_seq, unpad, coords_pad,

@@ -113,8 +113,8 @@ template <int MODE, bool EMBED>
 __global__ __launch_bounds__(SCT) void chunk_sort_kernel(
     const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
     const float* __restrict__ eta_idx, const float* __restrict__ phi_idx, const float* __restrict__ cfac,
-    const float* __restrict__ minmax, const unsigned int* __restrict__ range_bits, int N, int H, int t0, int Tl,
-    int n_chunks, const int* __restrict__ seg_len, SegParams* __restrict__ seg_params,
+    const float* __restrict__ minmax, const unsigned int* __restrict__ range_bits, float range_lo, float range_hi, int N,
+    int H, int t0, int Tl, int n_chunks, const int* __restrict__ seg_len, SegParams* __restrict__ seg_params,
     unsigned long long* __restrict__ pairs, unsigned int* __restrict__ tab) {
     __shared__ unsigned long long stage_s[SORT_CHUNK];   // the chunk, digit-sorted (32 KiB)
     __shared__ unsigned int cnt_s[RADIX];                // keys of the chunk per digit
@@ -174,10 +174,16 @@ __global__ __launch_bounds__(SCT) void chunk_sort_kernel(
     // ---- key range of the segment -> id map (every workgroup of a segment computes the same two numbers)
     float lo, span = 0.f, scale;
     if constexpr (MODE == 2) {
-        const unsigned int lo_b = range_bits[2 * seg], nhi_b = range_bits[2 * seg + 1];
-        const bool none = lo_b == 0xFFFFFFFFu && nhi_b == 0xFFFFFFFFu;  // no finite key in the segment
-        lo = none ? 0.f : from_ordered(lo_b);
-        const float hi = none ? 0.f : from_ordered(~nhi_b);
+        float hi;
+        if (range_bits) {
+            const unsigned int lo_b = range_bits[2 * seg], nhi_b = range_bits[2 * seg + 1];
+            const bool none = lo_b == 0xFFFFFFFFu && nhi_b == 0xFFFFFFFFu;  // no finite key in the segment
+            lo = none ? 0.f : from_ordered(lo_b);
+            hi = none ? 0.f : from_ordered(~nhi_b);
+        } else {   // the caller knows bounds of its keys (any bounds give an exact sort; tight ones balanced buckets)
+            lo = range_lo;
+            hi = range_hi;
+        }
         const float width = hi - lo;
         scale = width > 0.f ? (float)ID_BUCKETS / width : 0.f;
     } else {
@@ -884,10 +890,11 @@ constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segme
 template <int MODE, bool EMBED>
 void run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj,
                      const float* kproj, const int64_t* codes, const float* eta, const float* phi, const float* cfac,
-                     const float* minmax, int H, int t0, int Tl, const int* seg_len) {
+                     const float* minmax, int H, int t0, int Tl, const int* seg_len, const float* bounds) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes, eta,
-                       phi, cfac, minmax, b.range, N, H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab);
+                       phi, cfac, minmax, bounds ? nullptr : b.range, bounds ? bounds[0] : 0.f, bounds ? bounds[1] : 0.f, N,
+                       H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab);
     const dim3 grid4(NTOP, segs);
     if ((size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2))
         hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED, 64>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
@@ -899,11 +906,13 @@ void run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_
 template <int MODE>
 void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj, const float* kproj,
                 const int64_t* codes, const float* eta, const float* phi, const float* cfac, const float* minmax, int H,
-                int t0, int Tl, const int* seg_len = nullptr) {
+                int t0, int Tl, const int* seg_len = nullptr, const float* bounds = nullptr) {
     if (N <= (1 << EMBED_SHIFT))
-        run_passes_impl<MODE, true>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len);
+        run_passes_impl<MODE, true>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len,
+                                    bounds);
     else
-        run_passes_impl<MODE, false>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len);
+        run_passes_impl<MODE, false>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len,
+                                     bounds);
 }
 
 }  // namespace
@@ -954,7 +963,8 @@ extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, cons
 extern "C" size_t hept_argsort_workspace_bytes(int S, int L) { return sort_bytes((size_t)S, (size_t)L); }
 
 namespace {
-int segmented_argsort_impl(const float* keys, int S, int L, const int* seg_len, void* ws, int32_t* pos, void* stream) {
+int segmented_argsort_impl(const float* keys, int S, int L, const int* seg_len, void* ws, int32_t* pos, void* stream,
+                           const float* bounds = nullptr) {
     if (!keys || !ws || !pos) return HEPT_ERR_ARG;
     if (S < 1 || L < 1) return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -963,12 +973,21 @@ int segmented_argsort_impl(const float* keys, int S, int L, const int* seg_len, 
                                     seg_len);
     const int n_chunks = (L + SORT_CHUNK - 1) / SORT_CHUNK;
     const SortBuffers b = carve_sort(ws, S, L);
-    if (hipMemsetAsync(b.range, 0xFF, (size_t)S * 8, st) != hipSuccess) return HEPT_ERR_LAUNCH;
-    hipLaunchKernelGGL(raw_range_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, seg_len, b.range);
-    run_passes<2>(b, S, L, pos, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 1, seg_len);
+    if (!bounds) {   // the key range of every segment: two more launches that a caller with known bounds saves
+        if (hipMemsetAsync(b.range, 0xFF, (size_t)S * 8, st) != hipSuccess) return HEPT_ERR_LAUNCH;
+        hipLaunchKernelGGL(raw_range_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, seg_len, b.range);
+    }
+    run_passes<2>(b, S, L, pos, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 1, seg_len, bounds);
     return hept_launch_status();
 }
 }  // namespace
+
+// internal (common.h): every key lies in [lo, hi] (finite) -- the range pass is skipped
+int hept_segmented_argsort_bounded(const float* keys, int S, int L, float lo, float hi, void* ws, int32_t* pos,
+                                   void* stream) {
+    const float bounds[2] = {lo, hi};
+    return segmented_argsort_impl(keys, S, L, nullptr, ws, pos, stream, bounds);
+}
 
 extern "C" int hept_segmented_argsort(const float* keys, int S, int L, void* ws, int32_t* pos, void* stream) {
     return segmented_argsort_impl(keys, S, L, nullptr, ws, pos, stream);

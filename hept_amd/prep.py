@@ -105,6 +105,9 @@ def _rank_within_cloud(values: torch.Tensor, batch: torch.Tensor, raw_start: tor
     return rank - raw_start[batch]
 
 
+_MAX_CLOUDS_ONE_TRIP = 255
+
+
 def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
     """``prepare_input`` on the GPU through the C ABI (``hept_prepare_input``, ``csrc/prepare.hip``).
 
@@ -122,19 +125,25 @@ def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Di
     coords_c = coords.contiguous().float()
     n_raw, c_dim = coords_c.shape
     dev = coords.device
-    # Two host round trips, both needed to size the outputs: the last cloud id, then the cloud boundaries (`batch`
-    # is sorted, so they are a searchsorted; the device copy of the boundaries is the kernel's cloud_start as it is).
-    n_clouds = int(batch[-1]) + 1
-    edges = torch.searchsorted(batch.contiguous(), torch.arange(n_clouds + 1, device=dev, dtype=batch.dtype))
-    cloud_start = edges.to(torch.int32)
-    # packed codes must stay below 2^24 (they are sorted as exact fp32 keys): the largest region counts per axis are read
-    # from the tensor on EVERY call -- no cache keyed on a version counter that `.data` updates do not bump -- and ride
-    # in the boundaries' device-to-host copy, so the check costs no extra synchronisation
-    # (two launches: the maxima, and a concatenation that promotes the boundaries to float32 -- exact below 2^24 points)
-    if n_raw < (1 << 24):
-        host = torch.cat([edges, regions.amax(dim=(0, 2))]).cpu()
-    else:
-        host = torch.cat([edges.double(), regions.amax(dim=(0, 2)).double()]).cpu()
+    # ONE host round trip (needed to size the outputs): the cloud boundaries of up to _MAX_CLOUDS_ONE_TRIP clouds are
+    # searched on the device (`batch` is sorted, so they are a searchsorted; boundaries past the last cloud equal
+    # n_raw) and travel together with the region maxima; the cloud count is read off the boundaries on the host.  A
+    # batch of more clouds pays a second trip for its count.
+    # The region maxima: packed codes must stay below 2^24 (they are sorted as exact fp32 keys), and the largest region
+    # counts per axis are read from the tensor on EVERY call -- no cache keyed on a version counter that `.data` updates
+    # do not bump.  (The concatenation promotes the boundaries to float32 -- exact below 2^24 points.)
+    probe = _MAX_CLOUDS_ONE_TRIP
+    wide = n_raw >= (1 << 24)
+    while True:
+        edges = torch.searchsorted(batch.contiguous(), torch.arange(probe + 1, device=dev, dtype=batch.dtype))
+        reg_hi = regions.amax(dim=(0, 2))
+        host = (torch.cat([edges.double(), reg_hi.double()]) if wide else torch.cat([edges, reg_hi])).cpu()
+        if int(host[probe]) >= n_raw:
+            break
+        probe = int(batch[-1]) + 1      # more clouds than the probe: ask for the count
+    n_clouds = int((host[:probe + 1] < n_raw).sum())
+    host = torch.cat([host[:n_clouds + 1], host[probe + 1:]])
+    cloud_start = edges[:n_clouds + 1].to(torch.int32)
     sizes = host[:n_clouds + 1].diff().long()
     if int(sizes.min()) < 1:
         raise ValueError("every cloud id in [0, batch.max()] must own at least one point")
