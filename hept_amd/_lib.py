@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 # (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
@@ -86,6 +86,13 @@ SIGNATURES = {
     "hept_comm_reset_status": (c_int, [_P]),
     "hept_prepare_src_workspace_bytes": (c_size_t, [c_int]),
     "hept_prepare_input_src": (c_int, [_P, c_int, _P] + [c_int] * 3 + [_P, c_int, c_int, _P, c_size_t] + [_P] * 5),
+    "hept_rows_wgrad_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "hept_rows_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "hept_ln_scratch_bytes": (c_size_t, [c_int]),
+    "hept_ln_bwd": (c_int, [_P] * 4 + [c_float, c_int, c_int] + [_P] * 5 + [c_size_t, _P]),
+    "hept_ln_ffn_fwd": (c_int, [_P] * 3 + [c_float] + [_P] * 4 + [c_int, c_int, _P, _P]),
+    "hept_ln_ffn_bwd_scratch_bytes": (c_size_t, [c_int]),
+    "hept_ln_ffn_bwd": (c_int, [_P] * 4 + [c_float] + [_P] * 4 + [c_int, c_int] + [_P] * 8 + [c_size_t, _P]),
     "hept_profile_enable": (c_int, [c_int, c_int]),
     "hept_profile_read": (c_int, [_P, _P]),
     "hept_profile_stride": (c_int, [c_int]),

@@ -9,8 +9,10 @@ of a reference checkpoint load with ``strict=True``.
 In eval mode under ``torch.no_grad()`` the whole block is ONE C call (``hept_attn_block_forward``): LayerNorm and the
 q/k/v projections are computed while the rows of the operator are staged (q, k, v never exist in HBM: 138 MB written
 and read back per layer at tracking-60k in the unfused form), and the residual, ``norm2`` and the feed-forward run in
-the epilogue of the combine kernel.  In training mode (dropout active, gradients) the block is composed of torch
-modules around :class:`hept_amd.HEPTAttention`, exactly like the reference.
+the epilogue of the combine kernel.  In training mode (dropout active, gradients) the rest of the block is composed of
+torch modules exactly like the reference, but ``norm1`` and the three projections are folded into the operator's row
+builder as one autograd node (``autograd.HeptPartialSumsFused``): q, k, v are never written to HBM in the forward, and
+the backward adds the small dense products behind the HIP gradients of the block attention.
 """
 from __future__ import annotations
 
@@ -50,14 +52,30 @@ class Attn(nn.Module):
         return (x.is_cuda and not self.training and not torch.is_grad_enabled() and self.dim_per_head == 24
                 and self.num_heads == 8 and self.attn.n_hashes <= 8 and self.attn.sharding is None)
 
+    # training / grad-enabled calls: LayerNorm + projections + operator as one autograd node (False: compose modules)
+    fuse_training = True
+
     def forward(self, x, kwargs):
         if not self._fused_ok(x):
             # reference composition, example/transformer.py:154-165 (training: dropout + autograd)
-            x_normed = self.norm1(x)
-            q, k, v = self.w_q(x_normed), self.w_k(x_normed), self.w_v(x_normed)
-            aggr_out = self.attn(q, k, v, pe=kwargs["coords"], w_rpe=self.w_rpe, **kwargs)
+            if self.fuse_training and torch.is_grad_enabled() and self.attn._train_fused_ok(x, kwargs):
+                # the same composition with norm1 / w_q / w_k / w_v folded into the operator's row builder: q, k, v
+                # never exist in HBM, gradients reach the same parameters (autograd.HeptPartialSumsFused)
+                aggr_out = self.attn._forward_train_fused(x, self.norm1, self.w_q, self.w_k, self.w_v,
+                                                          w_rpe=self.w_rpe, **kwargs)
+            else:
+                x_normed = self.norm1(x)
+                q, k, v = self.w_q(x_normed), self.w_k(x_normed), self.w_v(x_normed)
+                aggr_out = self.attn(q, k, v, pe=kwargs["coords"], w_rpe=self.w_rpe, **kwargs)
             x = x + self.dropout(aggr_out)
-            ff_output = self.ff(self.norm2(x))
+            if (self.fuse_training and torch.is_grad_enabled() and x.is_cuda and self.dim_per_head == 24
+                    and x.dtype == torch.float32):
+                from .autograd import LnFfn   # norm2 + ff.0 + ReLU + ff.2 as one autograd node (HIP both ways)
+
+                ff_output = LnFfn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, self.ff[0].weight,
+                                        self.ff[0].bias, self.ff[2].weight, self.ff[2].bias)
+            else:
+                ff_output = self.ff(self.norm2(x))
             return x + self.dropout(ff_output)
         a = self.attn
         if torch.compiler.is_compiling():

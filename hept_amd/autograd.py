@@ -14,7 +14,8 @@ import torch
 
 from . import ops
 
-__all__ = ["HeptPartialSums", "HeptCombine", "RpeScale", "rpe_scale_torch", "ReplicatedGrad", "sum_over_ranks"]
+__all__ = ["HeptPartialSums", "HeptPartialSumsFused", "HeptCombine", "LnFfn", "RpeScale", "rpe_scale_torch", "ReplicatedGrad",
+           "sum_over_ranks"]
 
 
 class ReplicatedGrad(torch.autograd.Function):
@@ -141,6 +142,57 @@ class HeptPartialSums(torch.autograd.Function):
         return dq, dk, dv, dcoords, dsw, None, None, None, None, None
 
 
+class HeptPartialSumsFused(torch.autograd.Function):
+    """The ``Attn`` block's front end and the operator as ONE autograd node (training mode, SURVEY.md §8 f-4 x f-2):
+    (x, norm1, w_q / w_k / w_v, coords, sqrt_w) -> acc (N, H, 32).
+
+    Forward: ``hept_prep_hash_fused`` -- LayerNorm and the three bias-free projections are computed while the rows of
+    the operator are staged (reference ``example/transformer.py:155-156``); q, k, v (3 x 46 MB at tracking-60k) are
+    never written or read back -- then the sort, the block attention and the table sum as in :class:`HeptPartialSums`.
+    Backward: the HIP backward of the block attention yields dq, dk, dv; the small dense part behind them (three
+    (N, 192) x (192, 24) products for d LayerNorm(x), three transposed ones for the weight gradients, the LayerNorm
+    backward) is plain torch on the saved ``x`` -- the normalised rows are recomputed, nothing of size (N, 192) is kept
+    between the passes."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, block_size, f32_mfma=False):
+        from ._lib import MAX_TABLES
+
+        n, d = x.shape
+        n_tables = alpha.shape[2]
+        qs, ks = [], []
+        for c0 in range(0, n_tables, MAX_TABLES):
+            tc = min(MAX_TABLES, n_tables - c0)
+            ph = ops.prep_hash_fused(x, ln_w, ln_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, "fp32", t0=c0, tl=tc)
+            qp, kp = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"], t0=c0)
+            qs.append(qp)
+            ks.append(kp)
+        qpos, kpos = (qs[0], ks[0]) if len(qs) == 1 else (torch.cat(qs), torch.cat(ks))
+        part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, block_size, f32_mfma=f32_mfma)
+        acc = ops.reduce_tables(part, d)
+        ctx.f32_mfma = f32_mfma
+        ctx.save_for_backward(ph["qhat"], ph["kvhat"], qpos, kpos, coords, sqrt_w, x, ln_w, ln_b, w_q, w_k, w_v)
+        ctx.dims = (d, coords.shape[1], block_size, float(eps))
+        return acc
+
+    @staticmethod
+    def backward(ctx, gacc):
+        qhat, kvhat, qpos, kpos, coords, sqrt_w, x, ln_w, ln_b, w_q, w_k, w_v = ctx.saved_tensors
+        d, c, block_size, eps = ctx.dims
+        dq, dk, dv, dcs, dsw = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size,
+                                                  f32_mfma=ctx.f32_mfma, coords=coords, raw_size=x.shape[0])
+        dxn = dq @ w_q + dk @ w_k + dv @ w_v                       # d of the three Linear(D, H*D): (N,192) x (192,24)
+        # LayerNorm backward + the normalised rows in one kernel; the three weight gradients dq^T.xn ... are 192 x 24
+        # outputs reduced over all points -- ~140 us each in rocBLAS at 60k points, ~15 us here (csrc/block_train.hip)
+        dx, xn_d, dlw, dlb = ops.ln_bwd(x, dxn, ln_w, ln_b, eps)                       # example/transformer.py:155
+        dwq, dwk, dwv = ops.rows_wgrad(dq, xn_d), ops.rows_wgrad(dk, xn_d), ops.rows_wgrad(dv, xn_d)
+        need = ctx.needs_input_grad
+        dcoords = (dcs * sqrt_w[None]).sum(dim=1) if need[7] else None
+        return (dx if need[0] else None, dlw if need[1] else None, dlb if need[2] else None, None,
+                dwq if need[4] else None, dwk if need[5] else None, dwv if need[6] else None, dcoords,
+                dsw if need[8] else None, None, None, None, None)
+
+
 class HeptCombine(torch.autograd.Function):
     """acc (N, H, 32), out_linear.weight, out_linear.bias -> out (N, D): the cross-table divide and ``out_linear``
     (reference ``example/hept.py:79-80``) as HIP kernels in both directions (``combine_out`` / ``combine_bwd``)."""
@@ -158,3 +210,21 @@ class HeptCombine(torch.autograd.Function):
         acc, weight = ctx.saved_tensors
         gacc, dw, db = ops.combine_bwd(acc, g_out.contiguous(), weight, need_bias=ctx.has_bias)
         return gacc, dw, db
+
+
+class LnFfn(torch.autograd.Function):
+    """``ff(norm2(x1))`` of the ``Attn`` block (reference ``example/transformer.py:162``) as one autograd node with HIP
+    kernels in both directions (``hept_ln_ffn_fwd`` / ``hept_ln_ffn_bwd``): per point a 24-wide LayerNorm and two
+    24 x 24 layers; the parameter gradients are fixed-order reductions over the points."""
+
+    @staticmethod
+    def forward(ctx, x1, ln_w, ln_b, eps, w1, b1, w2, b2):
+        ctx.save_for_backward(x1, ln_w, ln_b, w1, b1, w2, b2)
+        ctx.eps = float(eps)
+        return ops.ln_ffn_fwd(x1, ln_w, ln_b, eps, w1, b1, w2, b2)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x1, ln_w, ln_b, w1, b1, w2, b2 = ctx.saved_tensors
+        dx1, dlw, dlb, dw1, db1, dw2, db2 = ops.ln_ffn_bwd(x1, d_out.contiguous(), ln_w, ln_b, ctx.eps, w1, b1, w2, b2)
+        return dx1, dlw, dlb, None, dw1, db1, dw2, db2

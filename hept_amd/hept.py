@@ -207,6 +207,26 @@ class HEPTAttention(nn.Module):
         return sh.finish(acc, lambda part, n0, cnt: ops.combine_out(part, d, self.out_linear.weight,
                                                                      self.out_linear.bias, n0, cnt))
 
+    def _train_fused_ok(self, x, kwargs) -> bool:
+        """Whether the training-mode ``Attn`` block may hand its LayerNorm and projections to the fused row builder"""
+        return (x.is_cuda and self.dim_per_head == 24 and self.num_heads == 8 and self.sharding is None
+                and "combined_shifts" in kwargs and kwargs["coords"].shape[1] in (2, 4, 6)
+                and x.dim() == 2 and x.shape[0] % self.block_size == 0)
+
+    def _forward_train_fused(self, x, norm1, w_q, w_k, w_v, **kwargs):
+        """Training mode of the ``Attn`` block (``hept_amd.Attn``): LayerNorm + the three projections + the operator as
+        one autograd node whose forward never materialises q, k, v (``autograd.HeptPartialSumsFused``); returns the
+        operator's output (N, D), reference ``example/transformer.py:155-159``."""
+        from .autograd import HeptCombine, HeptPartialSumsFused, RpeScale
+
+        h, d = self.num_heads, self.dim_per_head
+        sqrt_w = RpeScale.apply(kwargs["w_rpe"].weight.float(), h, d, self.num_w_per_dist)
+        acc = HeptPartialSumsFused.apply(x.float(), norm1.weight.float(), norm1.bias.float(), norm1.eps, w_q.weight.float(),
+                                         w_k.weight.float(), w_v.weight.float(), kwargs["coords"].float(), sqrt_w,
+                                         self.e2lsh.alpha.detach(), kwargs["combined_shifts"], self.block_size,
+                                         self.precision == "fp32_mfma")
+        return HeptCombine.apply(acc, self.out_linear.weight, self.out_linear.bias).to(x.dtype)
+
     def _forward_train(self, query, key, value, **kwargs):
         """Differentiable path: HIP forward/backward of the block attention inside autograd (f32 tiles)."""
         from .autograd import HeptPartialSums, RpeScale, ReplicatedGrad, sum_over_ranks

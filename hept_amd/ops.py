@@ -19,7 +19,8 @@ __all__ = [
     "forward", "forward_partial", "workspace_bytes", "profile_enable", "profile_read", "unpack_part",
     "segmented_argsort", "block_attn_bwd", "sort_tables_src", "forward_src", "forward_partial_src", "geo_args",
     "packed_partials", "prep_hash_fused", "combine_ffn", "attn_block_forward", "combine_bwd", "rpe_scale_bwd",
-    "partial_begin", "partial_heads", "combine_groups", "forward_sharded",
+    "partial_begin", "partial_heads", "combine_groups", "forward_sharded", "rows_wgrad", "ln_bwd", "ln_ffn_fwd",
+    "ln_ffn_bwd",
 ]
 
 
@@ -666,6 +667,72 @@ def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out
                                           *tail)
     _lib.check(rc, "hept_forward_sharded")
     return out_full[:n]
+
+
+# ---- the dense tail of the Attn block's training step (csrc/block_train.hip; rows of 24 floats)
+@_on_device
+def rows_wgrad(d_y: torch.Tensor, x: torch.Tensor, need_bias: bool = False):
+    """Weight gradient of a ``Linear(24 -> O)``: ``d_y.t() @ x`` (O, 24) (and the column sums of ``d_y`` for the bias)
+    with a fixed-order two-stage reduction over the points -- rocBLAS runs this shape at ~140 us for 60k points."""
+    lib = _lib.load()
+    d_y, x = _f32c(d_y, "d_y"), _f32c(x, "x")
+    n, o = d_y.shape
+    if x.shape != (n, 24):
+        raise ValueError(f"x must be ({n}, 24), got {tuple(x.shape)}")
+    dw = torch.empty(o, 24, device=x.device, dtype=torch.float32)
+    db = torch.empty(o, device=x.device, dtype=torch.float32) if need_bias else None
+    scratch = torch.empty(int(lib.hept_rows_wgrad_scratch_bytes(n, o)), device=x.device, dtype=torch.uint8)
+    _lib.check(lib.hept_rows_wgrad(d_y.data_ptr(), x.data_ptr(), n, o, 24, dw.data_ptr(),
+                                   db.data_ptr() if db is not None else None, scratch.data_ptr(), scratch.numel(),
+                                   _stream(x)), "hept_rows_wgrad")
+    return (dw, db) if need_bias else dw
+
+
+@_on_device
+def ln_bwd(x: torch.Tensor, d_xn: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float):
+    """LayerNorm(24) backward: returns (dx, xn, d_ln_w, d_ln_b) -- ``xn`` = the normalised rows (recomputed)."""
+    lib = _lib.load()
+    x, d_xn, ln_w, ln_b = (_f32c(t, nm) for t, nm in ((x, "x"), (d_xn, "d_xn"), (ln_w, "ln.weight"), (ln_b, "ln.bias")))
+    n, d = x.shape
+    dx, xn = torch.empty_like(x), torch.empty_like(x)
+    dlw, dlb = torch.empty_like(ln_w), torch.empty_like(ln_b)
+    scratch = torch.empty(int(lib.hept_ln_scratch_bytes(n)), device=x.device, dtype=torch.uint8)
+    _lib.check(lib.hept_ln_bwd(x.data_ptr(), d_xn.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), float(eps), n, d,
+                               dx.data_ptr(), xn.data_ptr(), dlw.data_ptr(), dlb.data_ptr(), scratch.data_ptr(),
+                               scratch.numel(), _stream(x)), "hept_ln_bwd")
+    return dx, xn, dlw, dlb
+
+
+@_on_device
+def ln_ffn_fwd(x1, ln_w, ln_b, eps, w1, b1, w2, b2) -> torch.Tensor:
+    """``ff.2(relu(ff.0(norm2(x1))))`` (reference ``example/transformer.py:162``) in one kernel; (N, 24)."""
+    lib = _lib.load()
+    ts = [_f32c(t, nm) for t, nm in ((x1, "x1"), (ln_w, "norm2.weight"), (ln_b, "norm2.bias"), (w1, "ff.0.weight"),
+                                     (b1, "ff.0.bias"), (w2, "ff.2.weight"), (b2, "ff.2.bias"))]
+    x1, ln_w, ln_b, w1, b1, w2, b2 = ts
+    n, d = x1.shape
+    out = torch.empty_like(x1)
+    _lib.check(lib.hept_ln_ffn_fwd(x1.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), float(eps), w1.data_ptr(),
+                                   b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), n, d, out.data_ptr(), _stream(x1)),
+               "hept_ln_ffn_fwd")
+    return out
+
+
+@_on_device
+def ln_ffn_bwd(x1, d_out, ln_w, ln_b, eps, w1, b1, w2, b2):
+    """Backward of :func:`ln_ffn_fwd`: (d_x1, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2)."""
+    lib = _lib.load()
+    ts = [_f32c(t, nm) for t, nm in ((x1, "x1"), (d_out, "d_out"), (ln_w, "norm2.weight"), (ln_b, "norm2.bias"),
+                                     (w1, "ff.0.weight"), (b1, "ff.0.bias"), (w2, "ff.2.weight"), (b2, "ff.2.bias"))]
+    x1, d_out, ln_w, ln_b, w1, b1, w2, b2 = ts
+    n, d = x1.shape
+    outs = [torch.empty_like(t) for t in (x1, ln_w, ln_b, w1, b1, w2, b2)]
+    scratch = torch.empty(int(lib.hept_ln_ffn_bwd_scratch_bytes(n)), device=x1.device, dtype=torch.uint8)
+    _lib.check(lib.hept_ln_ffn_bwd(x1.data_ptr(), d_out.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), float(eps),
+                                   w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), n, d,
+                                   *[t.data_ptr() for t in outs], scratch.data_ptr(), scratch.numel(), _stream(x1)),
+               "hept_ln_ffn_bwd")
+    return tuple(outs)
 
 
 def profile_enable(mode: int, max_calls: int = 0, stride: int = 1) -> None:

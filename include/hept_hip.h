@@ -385,6 +385,28 @@ int hept_prepare_input_src(const float* x, int F, const float* coords, int C, in
                            const float* regions, int T, int H, void* workspace, size_t workspace_bytes,
                            float* x_pad, float* coords_pad, float* eta_idx, float* phi_idx, void* stream);
 
+/* The small dense pieces around the operator in the TRAINING step of the Attn block (example/transformer.py:154-165
+ * under autograd; csrc/block_train.hip).  Activation rows are D = J = 24 floats.  Reductions over the points are
+ * two-stage with a fixed association: results do not depend on scheduling.
+ *   hept_rows_wgrad   d_weight (O, 24) = dY^T . X and d_bias (O) = column sums of dY (NULL: skipped): the weight
+ *                     gradient of a Linear(24 -> O) with input rows X (N, 24) and output gradient dY (N, O)
+ *   hept_ln_bwd       LayerNorm(24) backward from x and dxn = d LayerNorm(x): dx, the normalised rows xn, d_ln_w, d_ln_b
+ *   hept_ln_ffn_fwd   out = ff.2(relu(ff.0(norm2(x1))))            (:162; the residual and the dropouts stay outside)
+ *   hept_ln_ffn_bwd   its backward: d_x1 and the gradients of norm2.weight/bias, ff.0.weight/bias, ff.2.weight/bias */
+size_t hept_rows_wgrad_scratch_bytes(int N, int O);
+int hept_rows_wgrad(const float* dY, const float* X, int N, int O, int J, float* d_weight, float* d_bias,
+                    void* scratch, size_t scratch_bytes, void* stream);
+size_t hept_ln_scratch_bytes(int N);
+int hept_ln_bwd(const float* x, const float* dxn, const float* ln_w, const float* ln_b, float eps, int N, int D,
+                float* dx, float* xn, float* d_ln_w, float* d_ln_b, void* scratch, size_t scratch_bytes, void* stream);
+int hept_ln_ffn_fwd(const float* x1, const float* ln_w, const float* ln_b, float eps, const float* w1, const float* b1,
+                    const float* w2, const float* b2, int N, int D, float* out, void* stream);
+size_t hept_ln_ffn_bwd_scratch_bytes(int N);
+int hept_ln_ffn_bwd(const float* x1, const float* d_out, const float* ln_w, const float* ln_b, float eps,
+                    const float* w1, const float* b1, const float* w2, const float* b2, int N, int D, float* d_x1,
+                    float* d_ln_w, float* d_ln_b, float* d_w1, float* d_b1, float* d_w2, float* d_b2, void* scratch,
+                    size_t scratch_bytes, void* stream);
+
 /* Optional stage timing with HIP events recorded on the caller's stream inside hept_forward /
  * hept_forward_partial (nothing like it exists in the reference; used by bench.py for the roofline).
  * mode 0: off (default).  mode 1: bracket the block_attn kernel only (2 events per call).
