@@ -191,7 +191,8 @@ constexpr int LN_THREADS = 256;
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dxn,
                                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                             float eps, int N, float* __restrict__ dx,
-                                                            float* __restrict__ xn_out, float* __restrict__ partial) {
+                                                            float* __restrict__ xn_out, float* __restrict__ partial,
+                                                            float* __restrict__ dump) {
     __shared__ float w_s[2 * BT_D];
     __shared__ float wave_s[(LN_THREADS / 64) * 2 * BT_D];
     if (threadIdx.x < BT_D) { w_s[threadIdx.x] = ln_w[threadIdx.x]; w_s[BT_D + threadIdx.x] = ln_b[threadIdx.x]; }
@@ -205,12 +206,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restr
     float rstd;
     ln_stats(xr, eps, xhat, rstd);
     ln_backward(dz, xhat, rstd, w_s, out);
-    if (valid) {
-        out.store(dx + row);
+    // (lanes past the last point store into a dump row: a branch around the stores makes the compiler copy the whole
+    //  register rows per store -- 256 VGPRs and scratch in the ffn kernel below)
+    out.store(valid ? dx + row : dump);
 #pragma unroll
-        for (int j = 0; j < BT_D; ++j) out.v[j] = fmaf(xhat.v[j], w_s[j], w_s[BT_D + j]);
-        out.store(xn_out + row);
-    }
+    for (int j = 0; j < BT_D; ++j) out.v[j] = fmaf(xhat.v[j], w_s[j], w_s[BT_D + j]);
+    out.store(valid ? xn_out + row : dump);
     ln_param_partials<LN_THREADS>(dz, xhat, valid, wave_s, partial);
 }
 
@@ -244,6 +245,9 @@ __device__ __forceinline__ void ffn_hidden(const Row& xhat, const float* __restr
 #pragma unroll
         for (int j = 0; j < BT_D; ++j) acc = fmaf(wr[j], z.v[j], acc);
         a.v[u] = acc;
+        // keep the 576 weight reads of a layer from being hoisted in front of its fma chains (left alone the backward
+        // kernel takes 256 VGPRs and 3 KB of scratch per lane: 118 us for 60k points instead of ~15)
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_ffn_fwd_kernel(const float* __r
 #pragma unroll
         for (int u = 0; u < BT_D; ++u) acc = fmaf(wr[u], fmaxf(a.v[u], 0.f), acc);
         o.v[i] = acc;
+        __builtin_amdgcn_sched_barrier(0);
     }
     o.store(out + (size_t)n * BT_D);
 }
@@ -276,47 +281,59 @@ __global__ __launch_bounds__(LN_THREADS) void ln_ffn_bwd_kernel(const float* __r
                                                                 const float* __restrict__ d_out, FfnW p, int N,
                                                                 float* __restrict__ dx1, float* __restrict__ z_out,
                                                                 float* __restrict__ h_out, float* __restrict__ dh_out,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, float* __restrict__ dump) {
     __shared__ float s[FFN_W];
     __shared__ float wave_s[(LN_THREADS / 64) * 2 * BT_D];
     stage_ffn(p, s);
     const int n = blockIdx.x * LN_THREADS + threadIdx.x;
     const bool valid = n < N;
     const size_t row = (size_t)(valid ? n : N - 1) * BT_D;
-    Row xr, xhat, z, a, go, dh, dz, dx;
-    xr.load(x1 + row);
-    go.load(d_out + row);
+    // (phase by phase, every row stored as soon as it is final, so that at most ~four rows are live at a time: with all
+    //  eight rows and the hoisted weight reads live the kernel took 256 VGPRs and 3 KB of scratch per lane)
+    Row xhat, dz;
     float rstd;
-    ln_stats(xr, p.eps, xhat, rstd);
-    ffn_hidden(xhat, s, z, a);
-    // dh = (W2^T d_out) * [a > 0]
+    unsigned int relu_mask = 0;   // bit u: ff.0 output u is positive
+    {
+        Row xr, z, a;
+        xr.load(x1 + row);
+        ln_stats(xr, p.eps, xhat, rstd);
+        ffn_hidden(xhat, s, z, a);
+        z.store(valid ? z_out + row : dump);
 #pragma unroll
-    for (int u = 0; u < BT_D; ++u) dh.v[u] = 0.f;
-#pragma unroll
-    for (int i = 0; i < BT_D; ++i) {
-        const float* wr = s + BT_D * BT_D + i * BT_D;
-#pragma unroll
-        for (int u = 0; u < BT_D; ++u) dh.v[u] = fmaf(wr[u], go.v[i], dh.v[u]);
+        for (int u = 0; u < BT_D; ++u) {
+            relu_mask |= a.v[u] > 0.f ? 1u << u : 0u;
+            a.v[u] = fmaxf(a.v[u], 0.f);
+        }
+        a.store(valid ? h_out + row : dump);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        Row go, dh;
+        go.load(d_out + row);
+        // dh = (W2^T d_out) * [a > 0]
 #pragma unroll
-    for (int u = 0; u < BT_D; ++u) dh.v[u] = a.v[u] > 0.f ? dh.v[u] : 0.f;
-    // dz = W1^T dh
+        for (int u = 0; u < BT_D; ++u) {
+            float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < BT_D; ++j) dz.v[j] = 0.f;
+            for (int i = 0; i < BT_D; ++i) acc = fmaf(s[BT_D * BT_D + i * BT_D + u], go.v[i], acc);
+            dh.v[u] = (relu_mask >> u) & 1u ? acc : 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dh.store(valid ? dh_out + row : dump);
+        // dz = W1^T dh
 #pragma unroll
-    for (int u = 0; u < BT_D; ++u) {
-        const float* wr = s + u * BT_D;
+        for (int j = 0; j < BT_D; ++j) {
+            float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < BT_D; ++j) dz.v[j] = fmaf(wr[j], dh.v[u], dz.v[j]);
+            for (int u = 0; u < BT_D; ++u) acc = fmaf(s[u * BT_D + j], dh.v[u], acc);
+            dz.v[j] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    ln_backward(dz, xhat, rstd, s + 2 * BT_D * BT_D + 2 * BT_D, dx);
-    if (valid) {
-        dx.store(dx1 + row);
-        z.store(z_out + row);
-        dh.store(dh_out + row);
-#pragma unroll
-        for (int u = 0; u < BT_D; ++u) a.v[u] = fmaxf(a.v[u], 0.f);
-        a.store(h_out + row);
+    {
+        Row dx;
+        ln_backward(dz, xhat, rstd, s + 2 * BT_D * BT_D + 2 * BT_D, dx);
+        dx.store(valid ? dx1 + row : dump);
     }
     ln_param_partials<LN_THREADS>(dz, xhat, valid, wave_s, partial);
 }
@@ -357,8 +374,11 @@ extern "C" int hept_rows_wgrad(const float* dY, const float* X, int N, int O, in
     return wgrad_launch(dY, X, N, O, d_weight, d_bias, static_cast<float*>(scratch), (hipStream_t)stream);
 }
 
-extern "C" size_t hept_ln_scratch_bytes(int N) {
-    return N < 1 ? 0 : al256((size_t)n_wgs_rows(N) * 2 * BT_D * sizeof(float));
+extern "C" size_t hept_ln_scratch_bytes(int N) {   // LayerNorm parameter partials + one dump row
+    return N < 1 ? 0 : al256((size_t)n_wgs_rows(N) * 2 * BT_D * sizeof(float)) + 256;
+}
+static inline float* ln_dump_row(float* partial, int N) {
+    return partial + al256((size_t)n_wgs_rows(N) * 2 * BT_D * sizeof(float)) / sizeof(float);
 }
 
 // LayerNorm(24) backward (example/transformer.py:155 under autograd): dx (N, 24), the normalised rows xn (N, 24),
@@ -372,7 +392,8 @@ extern "C" int hept_ln_bwd(const float* x, const float* dxn, const float* ln_w, 
     hipStream_t st = (hipStream_t)stream;
     float* partial = static_cast<float*>(scratch);
     const int wgs = n_wgs_rows(N);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(wgs), dim3(LN_THREADS), 0, st, x, dxn, ln_w, ln_b, eps, N, dx, xn, partial);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(wgs), dim3(LN_THREADS), 0, st, x, dxn, ln_w, ln_b, eps, N, dx, xn, partial,
+                       ln_dump_row(partial, N));
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * BT_D + HEPT_FSUM_OUT - 1) / HEPT_FSUM_OUT), dim3(256), 0, st, partial,
                        wgs, 2 * BT_D, d_ln_w, d_ln_b, BT_D);
     return hept_launch_status();
@@ -414,7 +435,8 @@ extern "C" int hept_ln_ffn_bwd(const float* x1, const float* d_out, const float*
     float* wg_part = reinterpret_cast<float*>(ws + 3 * rows + hept_ln_scratch_bytes(N));
     const FfnW p{ln_w, ln_b, w1, b1, w2, b2, eps};
     const int wgs = n_wgs_rows(N);
-    hipLaunchKernelGGL(ln_ffn_bwd_kernel, dim3(wgs), dim3(LN_THREADS), 0, st, x1, d_out, p, N, d_x1, z, h, dh, ln_part);
+    hipLaunchKernelGGL(ln_ffn_bwd_kernel, dim3(wgs), dim3(LN_THREADS), 0, st, x1, d_out, p, N, d_x1, z, h, dh, ln_part,
+                       ln_dump_row(ln_part, N));
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * BT_D + HEPT_FSUM_OUT - 1) / HEPT_FSUM_OUT), dim3(256), 0, st, ln_part,
                        wgs, 2 * BT_D, d_ln_w, d_ln_b, BT_D);
     int rc = wgrad_launch(d_out, h, N, BT_D, d_w2, d_b2, wg_part, st);   // ff.2: out = W2 h + b2
