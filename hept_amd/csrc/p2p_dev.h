@@ -68,7 +68,9 @@ __device__ __forceinline__ void record_timeout(unsigned int* status, unsigned in
     unsigned int* host = reinterpret_cast<unsigned int*>(
         (unsigned long long)status[HEPT_STATE_HOSTPTR - HEPT_STATE_STATUS] |
         ((unsigned long long)status[HEPT_STATE_HOSTPTR - HEPT_STATE_STATUS + 1] << 32));
-    if (host) __hip_atomic_fetch_or(host, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (a plain system-scope store, not an atomic OR: read-modify-write atomics on host memory need PCIe atomics; the
+    //  host only asks "non-zero?", the exact bits are read from the device word by hept_comm_status)
+    if (host) __hip_atomic_store(host, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ bool status_bad(const unsigned int* status) {
     return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
