@@ -44,6 +44,8 @@ python3 tools/micro/combine_time.py bf16 2>&1 | grep "us per" >> $O/sort_and_com
 python3 tools/micro/combine_time.py fp32 2>&1 | grep "us per" >> $O/sort_and_combine_micro.txt
 python3 tools/attn_block_bench.py > $O/attn_block.txt 2>&1
 python3 tools/train_step_bench.py >> $O/attn_block.txt 2>&1
+python3 tools/attn_block_train_bench.py >> $O/attn_block.txt 2>&1
+python3 tools/host_overhead.py > $O/host_overhead.txt 2>&1
 python3 tools/model_latency.py > $O/model_and_prepare.txt 2>&1
 python3 tools/prepare_input_bench.py >> $O/model_and_prepare.txt 2>&1
 cd /tmp
