@@ -83,6 +83,12 @@ struct GeoShift {
     int raw_size = -1;
 };
 
+// HEPT_NO_ROW_RIDERS=1: the row builder keeps its v role (A/B measurements; read once)
+inline bool row_riders_off() {
+    static const bool off = [] { const char* e = getenv("HEPT_NO_ROW_RIDERS"); return e && *e && *e != '0'; }();
+    return off;
+}
+
 // everything before the block attention, for tables [t0, t0 + Tl): parameter math, augmented rows + hashes, sort.
 // Leaves qhat / kvhat and the permutations (w.pos: q then k, (Tl, H, N) each) in the workspace.
 int run_begin(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
@@ -96,19 +102,26 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
     int rc = HEPT_OK;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)Tl * H * N;
+    // The v half of the kvhat rows does not depend on anything this call computes: when the sort has a bucket-sort launch
+    // (segments longer than the one-workgroup sort) that launch -- a latency-bound chain that leaves the memory system
+    // idle -- carries it as rider workgroups, and the row builder runs its q and k roles only (sort_tables.hip: RowsJob)
+    const int raw_size = geo.eta ? geo.raw_size : N;
+    const bool ride = Tl <= HEPT_MAX_TABLES && hept_sort_carries_rows(N, H, D) && !row_riders_off();
+    const HeptRowsJob job{v, w.kvhat, N, raw_size, H, D, precision};
+    const HeptRowsJob* rows = ride ? &job : nullptr;
     for (int c0 = 0; c0 < Tl; c0 += HEPT_MAX_TABLES) {   // chunks of tables (the rows are rewritten identically)
         const int tc = Tl - c0 < HEPT_MAX_TABLES ? Tl - c0 : HEPT_MAX_TABLES;
-        rc = hept_prep_hash_rpe(q, k, v, coords, w_rpe, K, alpha, codes, N, geo.eta ? geo.raw_size : N, H, D, C, T,
-                                t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream);
+        rc = hept_prep_hash_rpe(q, k, v, coords, w_rpe, K, alpha, codes, N, raw_size, H, D, C, T,
+                                t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream, ride ? 2 : 3);
         if (rc) return rc;
         if (c0 == 0) prof_mark(1, st);
         // the sort writes one (2, tc, H, N) array: straight into w.pos when the call is a single chunk
         int32_t* cq = Tl <= HEPT_MAX_TABLES ? qpos : w.pos_chunk;
         int32_t* ck = cq + (size_t)tc * H * N;
-        rc = geo.eta ? hept_sort_tables_src(w.qproj, w.kproj, geo.eta, geo.phi, geo.cfac, w.minmax, N, H, T, t0 + c0, tc,
-                                            w.sort_ws, cq, ck, stream)
-                     : hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0 + c0, tc, w.sort_ws, cq, ck,
-                                        stream);
+        rc = geo.eta ? hept_sort_tables_src_rows(w.qproj, w.kproj, geo.eta, geo.phi, geo.cfac, w.minmax, N, H, T, t0 + c0,
+                                                 tc, w.sort_ws, cq, ck, rows, stream)
+                     : hept_sort_tables_rows(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0 + c0, tc, w.sort_ws, cq, ck,
+                                             rows, stream);
         if (rc) return rc;
         if (cq != qpos) {
             const size_t off = (size_t)c0 * H * N, bytes = (size_t)tc * H * N * 4;

@@ -397,12 +397,16 @@ constexpr int PREP_SLOTS_PER_ROLE = HEPT_PREP_GRID / 2;  // q and k roles fill t
 #ifndef HEPT_PREP_WGS
 #define HEPT_PREP_WGS 341
 #endif
+// ... and 2 x 512 when the v rows are written elsewhere (roles == 2: riders of the bucket-sort launch, sort_tables.hip)
+#ifndef HEPT_PREP_WGS2
+#define HEPT_PREP_WGS2 512
+#endif
 constexpr int PREP_WGS_PER_ROLE = HEPT_PREP_WGS;
-static_assert(PREP_WGS_PER_ROLE <= PREP_SLOTS_PER_ROLE, "every workgroup owns a partial slot");
-inline int prep_wgs(int N) {
+static_assert(PREP_WGS_PER_ROLE <= PREP_SLOTS_PER_ROLE && HEPT_PREP_WGS2 <= PREP_SLOTS_PER_ROLE, "every workgroup owns a partial slot");
+inline int prep_wgs(int N, int roles = 3) {
     const int tiles = (N + PREP_POINTS - 1) / PREP_POINTS, per_wg = PREP_THREADS / HEPT_WAVE;
-    const int want = (tiles + per_wg - 1) / per_wg;
-    return want < PREP_WGS_PER_ROLE ? (want < 1 ? 1 : want) : PREP_WGS_PER_ROLE;
+    const int want = (tiles + per_wg - 1) / per_wg, cap = roles == 2 ? HEPT_PREP_WGS2 : PREP_WGS_PER_ROLE;
+    return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 
 template <int D, int C, int TILE, int TMAX>
@@ -515,9 +519,9 @@ int launch_prep_fused(const float* x, const float* ln_w, const float* ln_b, floa
 template <int D, int C>
 int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                 const float* alpha, const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision,
-                void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
+                void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st, int roles) {
     // q- and k-role workgroups each write one of the HEPT_PREP_GRID partial slots the sort kernel reduces
-    const dim3 grid(prep_wgs(N), 3);
+    const dim3 grid(prep_wgs(N, roles), roles);
     // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
 #define HEPT_PREP_LAUNCH(TILE, TMAX)                                                                                 \
     hipLaunchKernelGGL((prep_hash_kernel<D, C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w, \
@@ -677,8 +681,8 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
 int launch_prep_generic(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                         const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
                         int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
-                        hipStream_t st) {
-    const dim3 grid(HEPT_PREP_GRID / 2, 3);   // q- and k-role workgroups each own one partial slot
+                        hipStream_t st, int roles) {
+    const dim3 grid(HEPT_PREP_GRID / 2, roles);   // q- and k-role workgroups each own one partial slot
     if (precision == HEPT_PREC_BF16)
         hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_BF16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
                            K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
@@ -714,7 +718,8 @@ extern "C" int hept_rpe_scale_bwd(const float* w_rpe, const float* d_sqrt_w, int
 int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                        const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
                        int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
-                       void* stream) {
+                       void* stream, int roles) {
+    if (roles != 2 && roles != 3) return HEPT_ERR_ARG;
     if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
     if (K < 0 || (K > 0 && (C < 2 || H * (C - 1) * K > 1024))) return HEPT_ERR_SHAPE;
     if (!q || !k || !v || !coords || !sqrt_w || !alpha || !qhat || !kvhat || !qproj || !kproj || !minmax)
@@ -728,7 +733,7 @@ int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const flo
 #define HEPT_PREP_CASE(DD, CC)                                                                             \
     if (H == 8 && D == DD && C == CC)                                                                      \
         return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, K, alpha, codes, N, raw_size, T, t0, Tl, precision, \
-                                   qhat, kvhat, qproj, kproj, minmax, st);
+                                   qhat, kvhat, qproj, kproj, minmax, st, roles);
     HEPT_PREP_CASE(24, 6)
     HEPT_PREP_CASE(24, 4)
     HEPT_PREP_CASE(24, 2)
@@ -737,7 +742,7 @@ int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const flo
     HEPT_PREP_CASE(8, 4)
 #undef HEPT_PREP_CASE
     return launch_prep_generic(q, k, v, coords, sqrt_w, K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, precision, qhat,
-                               kvhat, qproj, kproj, minmax, st);
+                               kvhat, qproj, kproj, minmax, st, roles);
 }
 
 extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
@@ -745,7 +750,7 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
                               int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat, void* kvhat,
                               float* qproj, float* kproj, float* minmax, void* stream) {
     return hept_prep_hash_rpe(q, k, v, coords, sqrt_w, 0, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, precision, qhat,
-                              kvhat, qproj, kproj, minmax, stream);
+                              kvhat, qproj, kproj, minmax, stream, 3);
 }
 
 // internal (common.h): K as in hept_prep_hash_rpe

@@ -316,6 +316,96 @@ __global__ __launch_bounds__(SCT) void chunk_sort_kernel(
 // CAP^2 compares.
 constexpr int BKT_THREADS = HEPT_BKT_THREADS;
 constexpr int BKT_WAVES = BKT_THREADS / HEPT_WAVE;
+
+// ---- riders: the v half of the kvhat rows, written by workgroups that travel in the KB launch -------------------------
+// KB is a chain of short dependent steps per workgroup: it moves 35 MB in 21 us and leaves the memory system idle most
+// of that time.  The v role of the row builder (prep_hash.hip: [v | 1.0 at column D | 0 ..] per (head, point)) is the
+// opposite -- a pure format conversion of 77 MB with no dependence on anything the forward computes -- so the first
+// `vy` rows of the KB grid do it instead of sorting: no LDS and no more registers than KB itself (the launch's
+// resources stay KB's).  Same values as the v role (the same bf16 conversion).  Measured at tracking-60k (bf16 / f32
+// tiles): row builder 55.2 -> 46.2 / 65.2 -> 53.2 us, sort 37.2 -> 44.3 / 38.0 -> 47.7 us, forward -2.3 us; the riders
+// alone take ~20 us (a rider wave is its own chain of load -> convert -> store trips), so more of them (8 grid rows:
+// +4 us) or fewer (2: +1 us) are both worse than 3, and the q / k roles that stay behind run at 3.9 TB/s instead of
+// the three roles' 4.7 -- the v role was already filling their gaps.
+struct RowsJob {
+    const float* v;     // (N, H * D) fp32
+    char* kvhat;        // (H, N, 2 * qrow bytes): v half at byte qrow of a row
+    int N, raw_size;    // rows >= raw_size are padding: v = 0 (src variant)
+    int H, D4;          // D / 4
+    int f32;            // 1: f32 tile rows (qrow = 128 B), 0: 16-bit rows (qrow = 64 B)
+    int vy;             // grid rows (of gridDim.x workgroups each) that are riders; 0: none
+};
+#ifndef HEPT_ROWS_RIDERS
+#define HEPT_ROWS_RIDERS 3
+#endif
+template <int H_>   // 0: run-time head count
+__device__ __forceinline__ void rows_rider(const RowsJob& jb, unsigned int wg, unsigned int n_wgs) {
+    // A wave takes a tile of 8 consecutive points (one contiguous run of v) at a time.  A row half is PPR 16-B pieces
+    // (4 of 8 bf16 values, or 8 of 4 floats); lane order inside the tile is [head][point][piece]: a store instruction
+    // writes whole 64-B / 128-B row halves of consecutive points of one head -- the pattern of the row builder's
+    // copy-out -- and piece k of row (h, n) reads v[n][h*D + 8k ..] (bf16) or [.. + 4k ..] (f32): elements below D are
+    // data, element D is the 1.0 that makes P.V produce the denominator, the rest zeros.  All loads of a tile are in
+    // flight before the first conversion (trips of 2 / 4 instructions: the riders must not raise the launch's register
+    // count above KB's own); the 128-B lines of the run are shared by the wave's instructions through L1.
+    const unsigned int H = H_ ? H_ : (unsigned int)jb.H, D = 4u * (unsigned int)jb.D4, HD = H * D;
+    const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned int ntiles = ((unsigned int)jb.N + 7u) >> 3;
+    const unsigned int wave = wg * BKT_WAVES + wv, n_waves = n_wgs * BKT_WAVES;
+    if (jb.f32) {
+        constexpr unsigned int PPR = 8, IT = 4;   // pieces per row half; wave instructions per trip (16 at H = 8 per tile: 4 trips)
+        for (unsigned int tile = wave; tile < ntiles; tile += n_waves) {
+            const unsigned int n0 = tile << 3;
+            for (unsigned int i0 = 0; i0 < H * 8 * PPR; i0 += 64 * IT) {
+                f32x4 x[IT];
+                unsigned int hd[IT], n[IT], k[IT];
+#pragma unroll
+                for (unsigned int u = 0; u < IT; ++u) {
+                    const unsigned int i = i0 + u * 64 + lane;
+                    k[u] = i & (PPR - 1);
+                    n[u] = n0 + ((i / PPR) & 7u);
+                    hd[u] = i / (8 * PPR);
+                    const bool data = hd[u] < H && n[u] < (unsigned int)jb.raw_size && 4 * k[u] < D;
+                    x[u] = data ? *reinterpret_cast<const f32x4*>(jb.v + (size_t)n[u] * HD + hd[u] * D + 4 * k[u])
+                                : f32x4{4 * k[u] == D ? 1.f : 0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (unsigned int u = 0; u < IT; ++u)
+                    if (hd[u] < H && n[u] < (unsigned int)jb.N)
+                        *reinterpret_cast<f32x4*>(jb.kvhat + ((size_t)hd[u] * jb.N + n[u]) * 256 + 128 + k[u] * 16) = x[u];
+            }
+        }
+    } else {
+        constexpr unsigned int PPR = 4, IT = 2;   // (register budget: the launch's VGPR count must stay KB's)
+        for (unsigned int tile = wave; tile < ntiles; tile += n_waves) {
+            const unsigned int n0 = tile << 3;
+            for (unsigned int i0 = 0; i0 < H * 8 * PPR; i0 += 64 * IT) {
+                f32x4 x[IT][2];
+                unsigned int hd[IT], n[IT], k[IT];
+#pragma unroll
+                for (unsigned int u = 0; u < IT; ++u) {
+                    const unsigned int i = i0 + u * 64 + lane;
+                    k[u] = i & (PPR - 1);
+                    n[u] = n0 + ((i / PPR) & 7u);
+                    hd[u] = i / (8 * PPR);
+                    const bool row = hd[u] < H && n[u] < (unsigned int)jb.raw_size;
+                    const float* src = jb.v + (size_t)n[u] * HD + hd[u] * D + 8 * k[u];
+                    x[u][0] = (row && 8 * k[u] < D) ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    x[u][1] = (row && 8 * k[u] + 4 < D) ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    // the 1.0 of column D (D % 4 == 0: the first element of one of the two quads)
+                    if (8 * k[u] == D) x[u][0][0] = 1.f;
+                    if (8 * k[u] + 4 == D) x[u][1][0] = 1.f;
+                }
+#pragma unroll
+                for (unsigned int u = 0; u < IT; ++u)
+                    if (hd[u] < H && n[u] < (unsigned int)jb.N)
+                        *reinterpret_cast<u32x4*>(jb.kvhat + ((size_t)hd[u] * jb.N + n[u]) * 128 + 64 + k[u] * 16) =
+                            u32x4{hept_pack_bf16(x[u][0][0], x[u][0][1]), hept_pack_bf16(x[u][0][2], x[u][0][3]),
+                                  hept_pack_bf16(x[u][1][0], x[u][1][1]), hept_pack_bf16(x[u][1][2], x[u][1][3])};
+            }
+        }
+    }
+}
+
 constexpr int BKT_BINS_PER_THREAD = LOBINS / BKT_THREADS;
 static_assert(LOBINS % BKT_THREADS == 0, "every thread owns the same number of bins");
 // MAXR = chunks whose run offsets fit the kernel's LDS table (64: every wave builds the table by itself with one
@@ -326,15 +416,25 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
                                                                   unsigned long long* __restrict__ scratch,
                                                                   const SegParams* __restrict__ seg_params,
                                                                   const unsigned int* __restrict__ tab, int N,
-                                                                  int n_chunks, int* __restrict__ pos_out) {
+                                                                  int n_chunks, int* __restrict__ pos_out,
+                                                                  RowsJob rows) {
     static_assert(CAP >= LOBINS, "the tile also holds the splitters of the streaming path");
+    if ((int)blockIdx.y < rows.vy) {   // uniform: a rider workgroup (the first rows of the grid: dispatched first)
+        const unsigned int wg = blockIdx.y * gridDim.x + blockIdx.x, n_wgs = (unsigned int)rows.vy * gridDim.x;
+        if (rows.H == 8) rows_rider<8>(rows, wg, n_wgs);
+        else rows_rider<0>(rows, wg, n_wgs);
+        return;
+    }
+#ifdef HEPT_RIDERS_ONLY   // measurement builds: what the riders cost by themselves
+    if (rows.vy > 0) return;
+#endif
     __shared__ unsigned long long tile_s[CAP];
     __shared__ unsigned int cur_s[LOBINS + 1];  // [0] stays 0; bin d lives at [d + 1]
     __shared__ unsigned int wsum_s[BKT_WAVES];
     __shared__ unsigned int roff_s[MAXR + 1];   // pairs of the bucket in runs 0 .. c-1
     __shared__ unsigned int rbase_s[MAXR + 1];  // first pair of run c, as an index into the segment's pairs; [MAXR]: start
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int seg = blockIdx.y, bucket = blockIdx.x;
+    const int seg = (int)blockIdx.y - rows.vy, bucket = blockIdx.x;
     const unsigned long long* seg_pairs = pairs + (size_t)seg * N;
     const unsigned int* btab = tab + (size_t)seg * n_chunks * TAB + bucket;   // + c * TAB: [first, end) of run c
     unsigned int* bin_s = cur_s + 1;
@@ -890,29 +990,47 @@ constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segme
 template <int MODE, bool EMBED>
 void run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj,
                      const float* kproj, const int64_t* codes, const float* eta, const float* phi, const float* cfac,
-                     const float* minmax, int H, int t0, int Tl, const int* seg_len, const float* bounds) {
+                     const float* minmax, int H, int t0, int Tl, const int* seg_len, const float* bounds,
+                     const RowsJob& rows) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes, eta,
                        phi, cfac, minmax, bounds ? nullptr : b.range, bounds ? bounds[0] : 0.f, bounds ? bounds[1] : 0.f, N,
                        H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab);
-    const dim3 grid4(NTOP, segs);
+    const dim3 grid4(NTOP, segs + rows.vy);   // rider rows first
     if ((size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2))
         hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED, 64>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
-                           b.tab, N, n_chunks, pos);
+                           b.tab, N, n_chunks, pos, rows);
     else
         hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_LARGE, EMBED, 1024>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb,
-                           b.params, b.tab, N, n_chunks, pos);
+                           b.params, b.tab, N, n_chunks, pos, rows);
 }
 template <int MODE>
 void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj, const float* kproj,
                 const int64_t* codes, const float* eta, const float* phi, const float* cfac, const float* minmax, int H,
-                int t0, int Tl, const int* seg_len = nullptr, const float* bounds = nullptr) {
+                int t0, int Tl, const int* seg_len = nullptr, const float* bounds = nullptr,
+                const RowsJob& rows = RowsJob{}) {
     if (N <= (1 << EMBED_SHIFT))
         run_passes_impl<MODE, true>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len,
-                                    bounds);
+                                    bounds, rows);
     else
         run_passes_impl<MODE, false>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len,
-                                     bounds);
+                                     bounds, rows);
+}
+
+// the job of the rider workgroups, from the description a caller in another translation unit hands over
+RowsJob rows_job(const HeptRowsJob* r) {
+    RowsJob jb{};
+    if (!r) return jb;
+    jb.v = r->v;
+    jb.kvhat = reinterpret_cast<char*>(r->kvhat);
+    jb.N = r->N;
+    jb.raw_size = r->raw_size;
+    jb.H = r->H;
+    jb.D4 = r->D / 4;
+    jb.f32 = (r->precision == HEPT_PREC_F32 || r->precision == HEPT_PREC_F32_MFMA) ? 1 : 0;
+    static const int vy = [] { const char* e = getenv("HEPT_ROW_RIDERS"); const int n = e ? atoi(e) : 0; return n > 0 && n <= 64 ? n : HEPT_ROWS_RIDERS; }();
+    jb.vy = vy;   // (HEPT_ROW_RIDERS=<grid rows>: tuning; read once)
+    return jb;
 }
 
 }  // namespace
@@ -927,10 +1045,23 @@ static size_t sort_bytes(size_t segs, size_t N) {
 
 extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) { return sort_bytes((size_t)2 * Tl * H, N); }
 
+// internal (common.h): the sort of N-key segments is the KA / KB pair, whose KB launch can carry the v rows
+bool hept_sort_carries_rows(int N, int H, int D) {
+    return N > SMALL_CAP && D >= 4 && D % 4 == 0 && D <= 28 && H >= 1 && (unsigned long long)N * H * (D / 4) < (1ull << 32);
+}
+
 extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* codes, const float* minmax,
                                 int N, int H, int T, int t0, int Tl, void* sort_ws, int32_t* qpos, int32_t* kpos,
                                 void* stream) {
+    return hept_sort_tables_rows(qproj, kproj, codes, minmax, N, H, T, t0, Tl, sort_ws, qpos, kpos, nullptr, stream);
+}
+
+// internal (common.h): hept_sort_tables whose bucket-sort launch also writes the v rows described by `rows` (or null)
+int hept_sort_tables_rows(const float* qproj, const float* kproj, const int64_t* codes, const float* minmax, int N, int H,
+                          int T, int t0, int Tl, void* sort_ws, int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows,
+                          void* stream) {
     if (!qproj || !kproj || !codes || !minmax || !sort_ws || !qpos || !kpos) return HEPT_ERR_ARG;
+    if (rows && (!rows->v || !rows->kvhat || rows->N != N || !hept_sort_carries_rows(N, rows->H, rows->D))) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
     if (kpos != qpos + (size_t)Tl * H * N) return HEPT_ERR_ARG;  // one (2,Tl,H,N) array: q then k
     hipStream_t st = (hipStream_t)stream;
@@ -938,15 +1069,24 @@ extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const in
     if (N <= SMALL_CAP)
         return launch_small_sort<0>(segs, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, N, H, t0, Tl, qpos);
     const SortBuffers b = carve_sort(sort_ws, segs, N);
-    run_passes<0>(b, segs, N, qpos, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, H, t0, Tl);
+    run_passes<0>(b, segs, N, qpos, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, H, t0, Tl, nullptr, nullptr,
+                  rows_job(rows));
     return hept_launch_status();
 }
 
 extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, const float* eta_idx,
                                     const float* phi_idx, const float* cfac, float* minmax, int N, int H, int T,
                                     int t0, int Tl, void* sort_ws, int32_t* qpos, int32_t* kpos, void* stream) {
+    return hept_sort_tables_src_rows(qproj, kproj, eta_idx, phi_idx, cfac, minmax, N, H, T, t0, Tl, sort_ws, qpos, kpos,
+                                     nullptr, stream);
+}
+
+int hept_sort_tables_src_rows(const float* qproj, const float* kproj, const float* eta_idx, const float* phi_idx,
+                              const float* cfac, float* minmax, int N, int H, int T, int t0, int Tl, void* sort_ws,
+                              int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows, void* stream) {
     if (!qproj || !kproj || !eta_idx || !phi_idx || !cfac || !minmax || !sort_ws || !qpos || !kpos)
         return HEPT_ERR_ARG;
+    if (rows && (!rows->v || !rows->kvhat || rows->N != N || !hept_sort_carries_rows(N, rows->H, rows->D))) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
     if (kpos != qpos + (size_t)Tl * H * N) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -956,7 +1096,8 @@ extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, cons
     const SortBuffers b = carve_sort(sort_ws, segs, N);
     hipLaunchKernelGGL(src_bound_kernel, dim3(Tl * H), dim3(SORT_THREADS), 0, st, eta_idx, phi_idx, cfac, N, H, t0,
                        minmax);
-    run_passes<1>(b, segs, N, qpos, st, qproj, kproj, nullptr, eta_idx, phi_idx, cfac, minmax, H, t0, Tl);
+    run_passes<1>(b, segs, N, qpos, st, qproj, kproj, nullptr, eta_idx, phi_idx, cfac, minmax, H, t0, Tl, nullptr, nullptr,
+                  rows_job(rows));
     return hept_launch_status();
 }
 

@@ -304,6 +304,33 @@ def test_edge_cases(gpu_device):
                     g["out_weight"], g["out_bias"], block_size=512, w_per_dist=10)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_v_rows_written_by_the_bucket_sort_launch(precision, gpu_device):
+    """Clouds longer than the one-workgroup sort: the v half of the kvhat rows is written by rider workgroups of the
+    bucket-sort launch (csrc/sort_tables.hip: RowsJob) and the row builder runs its q and k roles only.  Shapes that
+    stress the riders' tiling: a point count that is not a multiple of their 8-point tile, another head count (the
+    generic row builder), head dimensions whose 16-bit rows end inside a 16-byte piece (D = 20) or early (D = 8, 16)."""
+    from hept_amd.synthetic import make_inputs
+
+    for sizes, b, heads, d, c in (([6300], 100, 8, 24, 6), ([3100, 3300], 100, 4, 16, 4), ([6500], 100, 8, 20, 6),
+                                  ([6400], 64, 16, 8, 4), ([7000], 40, 3, 12, 2)):
+        inp = make_inputs(sizes, block_size=b, n_hashes=2, num_heads=heads, h_dim=d, coords_dim=c, seed=b + d,
+                          cluster_size=6)
+        inp["block_size"] = b
+        g = _gpu(inp, gpu_device)
+        got = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
+                          g["out_weight"], g["out_bias"], block_size=b, w_per_dist=10, precision=precision).cpu()
+        kw = dict(tile_dtype=torch.bfloat16) if precision == "bf16" else {}
+        want = ho.forward(inp["q"], inp["k"], inp["v"], inp["coords"], inp["combined_shifts"], inp["w_rpe_weight"],
+                          inp["alpha"], inp["out_weight"], inp["out_bias"], block_size=b, w_per_dist=10, keep=False,
+                          **kw)["out"]
+        assert bool(torch.isfinite(got).all()), (sizes, heads, d)
+        if precision == "fp32":
+            assert _rows_ok(got, want, 1e-5) >= 0.995, (sizes, heads, d)
+        else:
+            assert _rows_ok(got, want, atol=5e-3, rtol=8e-3) >= 0.995, (sizes, heads, d)
+
+
 def test_random_shapes_against_the_oracle(gpu_device):
     """tests/op_stress.py: random block sizes (8..256, mostly not multiples of 32), 1..8 tables, every supported
     (head_dim, coords_dim) pair, 1..3 clouds; fp32 and bf16 tiles against the oracle."""

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/attn_sweep.txt
 mkdir -p $R/gpurun_out; : > $OUT
 for flags in "" "$@"; do
   /opt/rocm/bin/hipcc $BASE $flags -c block_attn.hip -o block_attn.o 2>> $OUT || { echo "BUILD FAILED: $flags" >> $OUT; continue; }
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libhept_hip.so prep_hash.o sort_tables.o block_attn.o block_attn_bwd.o combine.o prepare.o comm.o p2p.o capi.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libhept_hip.so prep_hash.o sort_tables.o block_attn.o block_attn_bwd.o combine.o block_train.o prepare.o comm.o p2p.o capi.o -ldl
   python3 $R/tools/micro/attn_time.py $BS "[$flags]" 2>&1 | grep "us per" >> $OUT
 done
 cat $OUT

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prep_sweep.txt
 mkdir -p $R/gpurun_out; : > $OUT
 for flags in "" "$@" ""; do
   /opt/rocm/bin/hipcc $BASE $flags -c prep_hash.hip -o prep_hash.o 2>> $OUT || { echo "BUILD FAILED: $flags" >> $OUT; continue; }
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libhept_hip.so prep_hash.o sort_tables.o block_attn.o block_attn_bwd.o combine.o prepare.o comm.o p2p.o capi.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libhept_hip.so prep_hash.o sort_tables.o block_attn.o block_attn_bwd.o combine.o block_train.o prepare.o comm.o p2p.o capi.o -ldl
   (cd $R; echo "[$flags] $(python3 bench.py --no-extra --no-cpu-baseline --stages 2>&1 | grep -E 'stage ms|ms_per_step' | sed 's/.*"ms_per_step": \([0-9.]*\).*/ms_per_step \1/' | tr '\n' ' ')") >> $OUT
 done
 cat $OUT

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/sort_sweep.txt
 mkdir -p $R/gpurun_out; : > $OUT
 for flags in "" "$@"; do
   /opt/rocm/bin/hipcc $BASE $flags -c sort_tables.hip -o sort_tables.o 2>> $OUT || { echo "BUILD FAILED: $flags" >> $OUT; continue; }
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libhept_hip.so prep_hash.o sort_tables.o block_attn.o block_attn_bwd.o combine.o prepare.o comm.o p2p.o capi.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libhept_hip.so prep_hash.o sort_tables.o block_attn.o block_attn_bwd.o combine.o block_train.o prepare.o comm.o p2p.o capi.o -ldl
   python3 $R/tools/micro/sort_time.py tracking-60k "[$flags]" >> $OUT 2>&1
   python3 $R/tools/micro/sort_time.py pileup-8clouds "[$flags]" >> $OUT 2>&1
 done
