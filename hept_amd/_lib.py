@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 # (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
@@ -57,6 +57,7 @@ SIGNATURES = {
     "hept_combine_ffn": (c_int, [_P] + [c_int] * 7 + [_P] * 5 + [c_float] + [_P] * 6),
     "hept_attn_block_forward": (c_int, [_P] * 4 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_combine_bwd_scratch_bytes": (c_size_t, [c_int]),
+    "hept_combine_bwd_scratch_bytes_shape": (c_size_t, [c_int] * 3),
     "hept_combine_bwd": (c_int, [_P] * 3 + [c_int] * 3 + [_P] * 4 + [c_size_t, _P]),
     "hept_forward_src": (c_int, [_P] * 7 + [c_int] + [_P] * 4 + [c_int] * 8 + [_P, c_size_t, _P, _P]),
     "hept_forward_partial_src": (c_int, [_P] * 7 + [c_int] + [_P] * 2 + [c_int] * 11 + [_P, c_size_t, _P, _P]),

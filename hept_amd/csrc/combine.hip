@@ -602,6 +602,83 @@ __global__ __launch_bounds__(256) void combine_bwd_weight_sum_kernel(const float
     }
 }
 
+// ---- the same backward for any head count / head dimension (H <= 16, D <= 27; reference example/hept.py:34-41 accepts
+// any): the same formulas with run-time loops, one thread per (point, head) row / per column of d_weight.  Not tuned.
+__global__ __launch_bounds__(256) void combine_bwd_rows_generic_kernel(const float* __restrict__ acc,
+                                                                       const float* __restrict__ g_out,
+                                                                       const float* __restrict__ W, int N, int H, int D,
+                                                                       float* __restrict__ gacc) {
+    extern __shared__ float wg_s[];   // W (D, H*D) as stored
+    const int tid = threadIdx.x, HD = H * D;
+    for (int i = tid; i < D * HD; i += 256) wg_s[i] = W[i];
+    __syncthreads();
+    const size_t n_rows = (size_t)N * H;
+    for (size_t row = (size_t)blockIdx.x * 256 + tid; row < n_rows; row += (size_t)gridDim.x * 256) {
+        const int h = (int)(row % H);
+        const size_t n = row / H;
+        const float* a = acc + row * 32;
+        const float* g = g_out + n * D;
+        float* out = gacc + row * 32;
+        const float inv = 1.0f / a[D];
+        float dot = 0.f;
+        for (int j = 0; j < D; ++j) {
+            float s = 0.f;
+            for (int c = 0; c < D; ++c) s = fmaf(wg_s[c * HD + h * D + j], g[c], s);
+            dot = fmaf(s, a[j], dot);
+            out[j] = s * inv;
+        }
+        out[D] = -dot * inv * inv;
+        for (int j = D + 1; j < 32; ++j) out[j] = 0.f;
+    }
+}
+
+// partial[wg][c][col] (c == D: bias sums in columns < D), pitch (D + 1) * H * D per workgroup of CBW_POINTS points
+__global__ __launch_bounds__(256) void combine_bwd_weight_generic_kernel(const float* __restrict__ acc,
+                                                                         const float* __restrict__ g_out, int N, int H,
+                                                                         int D, float* __restrict__ partial) {
+    __shared__ float g_s[CBW_POINTS * 27];
+    const int HD = H * D;
+    const int n_begin = blockIdx.x * CBW_POINTS, n_end = min(N, n_begin + CBW_POINTS), cnt = n_end - n_begin;
+    for (int i = threadIdx.x; i < cnt * D; i += 256) g_s[i] = g_out[(size_t)n_begin * D + i];
+    __syncthreads();
+    float* mine = partial + (size_t)blockIdx.x * (D + 1) * HD;
+    for (int col = threadIdx.x; col < HD; col += 256) {
+        const int h = col / D, j = col - h * D;
+        float s[27];
+#pragma unroll
+        for (int c = 0; c < 27; ++c) s[c] = 0.f;
+        float sb = 0.f;
+        for (int n = n_begin; n < n_end; ++n) {
+            const float* arow = acc + ((size_t)n * H + h) * 32;
+            const float ph = arow[j] / arow[D];
+            const float* gr = g_s + (n - n_begin) * D;
+#pragma unroll
+            for (int c = 0; c < 27; ++c)
+                if (c < D) s[c] = fmaf(gr[c], ph, s[c]);
+            if (col < D) sb += gr[col];
+        }
+#pragma unroll
+        for (int c = 0; c < 27; ++c)
+            if (c < D) mine[c * HD + col] = s[c];
+        mine[D * HD + col] = col < D ? sb : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void combine_bwd_weight_sum_generic_kernel(const float* __restrict__ partial, int n_wgs,
+                                                                             int HD, int D, float* __restrict__ d_weight,
+                                                                             float* __restrict__ d_bias) {
+    __shared__ float red_s[HEPT_FSUM_SLICES * HEPT_FSUM_OUT];
+    const int total = (D + 1) * HD;
+    const int i = blockIdx.x * HEPT_FSUM_OUT + threadIdx.x % HEPT_FSUM_OUT;
+    const bool valid = i < total;
+    const float tot = hept_fixed_sum(partial, n_wgs, (size_t)total, i, valid, red_s);
+    if (threadIdx.x < HEPT_FSUM_OUT && valid) {
+        const int c = i / HD, col = i - c * HD;
+        if (c < D) d_weight[(size_t)c * HD + col] = tot;
+        else if (col < D && d_bias) d_bias[col] = tot;
+    }
+}
+
 }  // namespace
 
 extern "C" int hept_reduce_tables(const float* part, int part_precision, int Tl, int N, int H, int D, float* acc,
@@ -753,23 +830,39 @@ extern "C" int hept_combine_ffn(const float* part, int part_precision, int Tl, i
     return HEPT_ERR_SHAPE;
 }
 
-extern "C" size_t hept_combine_bwd_scratch_bytes(int N) {
-    return N < 1 ? 0 : (size_t)((N + CBW_POINTS - 1) / CBW_POINTS) * (CB_D + 1) * 192 * sizeof(float);
+static bool combine_bwd_tuned(int H, int D) { return D == CB_D && H <= 8; }   // the shipped models' rows
+
+extern "C" size_t hept_combine_bwd_scratch_bytes_shape(int N, int H, int D) {
+    if (N < 1 || H < 1 || D < 1) return 0;
+    const size_t wgs = (size_t)((N + CBW_POINTS - 1) / CBW_POINTS);
+    return wgs * (combine_bwd_tuned(H, D) ? (size_t)(CB_D + 1) * 192 : (size_t)(D + 1) * H * D) * sizeof(float);
 }
+
+extern "C" size_t hept_combine_bwd_scratch_bytes(int N) { return hept_combine_bwd_scratch_bytes_shape(N, 8, CB_D); }
 
 extern "C" int hept_combine_bwd(const float* acc, const float* g_out, const float* out_weight, int N, int H, int D,
                                 float* gacc, float* d_weight, float* d_bias, void* scratch, size_t scratch_bytes,
                                 void* stream) {
     if (!acc || !g_out || !out_weight || !gacc || !d_weight || !scratch) return HEPT_ERR_ARG;
-    if (N < 1 || H < 1 || H > 8 || D != CB_D) return HEPT_ERR_SHAPE;
-    if (scratch_bytes < hept_combine_bwd_scratch_bytes(N)) return HEPT_ERR_ARG;
+    if (N < 1 || H < 1 || H > 16 || D < 1 || D > 27) return HEPT_ERR_SHAPE;
+    if (scratch_bytes < hept_combine_bwd_scratch_bytes_shape(N, H, D)) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t n_rows = (size_t)N * H;
     const size_t blocks = (n_rows + 255) / 256;
-    hipLaunchKernelGGL(combine_bwd_rows_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, acc,
-                       g_out, out_weight, N, H, gacc);
     const int n_wgs = (N + CBW_POINTS - 1) / CBW_POINTS;
     float* partial = static_cast<float*>(scratch);
+    if (!combine_bwd_tuned(H, D)) {
+        const size_t lds = (size_t)D * H * D * sizeof(float);   // <= 46.7 KB
+        hipLaunchKernelGGL(combine_bwd_rows_generic_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), lds,
+                           st, acc, g_out, out_weight, N, H, D, gacc);
+        hipLaunchKernelGGL(combine_bwd_weight_generic_kernel, dim3(n_wgs), dim3(256), 0, st, acc, g_out, N, H, D, partial);
+        const int total = (D + 1) * H * D;
+        hipLaunchKernelGGL(combine_bwd_weight_sum_generic_kernel, dim3((total + HEPT_FSUM_OUT - 1) / HEPT_FSUM_OUT),
+                           dim3(256), 0, st, partial, n_wgs, H * D, D, d_weight, d_bias);
+        return hept_launch_status();
+    }
+    hipLaunchKernelGGL(combine_bwd_rows_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, acc,
+                       g_out, out_weight, N, H, gacc);
     hipLaunchKernelGGL(combine_bwd_weight_kernel, dim3(n_wgs), dim3(192 * CBW_GROUPS), 0, st, acc, g_out, N, H, partial);
     hipLaunchKernelGGL(combine_bwd_weight_sum_kernel, dim3((CB_D + 1) * 192 / HEPT_FSUM_OUT), dim3(256), 0, st, partial,
                        n_wgs, H * D, d_weight, d_bias);

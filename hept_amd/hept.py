@@ -264,11 +264,8 @@ class HEPTAttention(nn.Module):
         acc = HeptPartialSums.apply(q2, k2, v2, coords, sqrt_w, alpha, codes, self.block_size, geo, f32_mfma)
         if sh is not None and sh.world > 1:
             acc = sum_over_ranks(acc, sh.group)
-        if d == 24 and h <= 8:   # hept_combine_bwd is built for the shipped models' rows; other shapes: torch ops
-            from .autograd import HeptCombine
+        from .autograd import HeptCombine
 
-            out = HeptCombine.apply(acc, self.out_linear.weight, self.out_linear.bias)   # example/hept.py:79-80
-        else:
-            per_head = acc[..., :d] / acc[..., d:d + 1]                  # example/hept.py:79
-            out = self.out_linear(per_head.reshape(n, h * d))            # example/hept.py:80
+        # example/hept.py:79-80, HIP in both directions for every supported head count / head dimension
+        out = HeptCombine.apply(acc, self.out_linear.weight, self.out_linear.bias)
         return out.to(query.dtype)

@@ -317,7 +317,7 @@ def combine_bwd(acc: torch.Tensor, g_out: torch.Tensor, out_weight: torch.Tensor
     gacc = torch.empty_like(acc)
     dw = torch.empty_like(w)
     db = torch.empty(d, device=acc.device, dtype=torch.float32) if need_bias else None
-    scratch = torch.empty(int(lib.hept_combine_bwd_scratch_bytes(n)), device=acc.device, dtype=torch.uint8)
+    scratch = torch.empty(int(lib.hept_combine_bwd_scratch_bytes_shape(n, h, d)), device=acc.device, dtype=torch.uint8)
     _lib.check(lib.hept_combine_bwd(acc.data_ptr(), g_out.data_ptr(), w.data_ptr(), n, h, d, gacc.data_ptr(),
                                     dw.data_ptr(), db.data_ptr() if db is not None else None, scratch.data_ptr(),
                                     scratch.numel(), _stream(acc)), "hept_combine_bwd")

@@ -351,9 +351,11 @@ int hept_rpe_scale_bwd(const float* w_rpe, const float* d_sqrt_w, int H, int D, 
                        void* stream);
 /* backward of hept_combine_out on table-summed f32 rows acc (N, H, 32) (example/hept.py:79-80 under autograd):
  * given g_out (N, D) writes gacc (N, H, 32) = gradient of acc, d_weight (D, H*D) and d_bias (D, may be NULL).
- * D == 24, H <= 8. */
-/* scratch: hept_combine_bwd_scratch_bytes(N) bytes (per-workgroup partial sums of d_weight / d_bias, added in a
- * fixed order by a second kernel: the gradients are bit-identical from run to run). */
+ * Any H <= 16, D <= 27 (the reference takes any, example/hept.py:34-41); D == 24 with H <= 8 takes the tuned kernels. */
+/* scratch: hept_combine_bwd_scratch_bytes_shape(N, H, D) bytes (per-workgroup partial sums of d_weight / d_bias, added
+ * in a fixed order by a second kernel: the gradients are bit-identical from run to run).
+ * hept_combine_bwd_scratch_bytes(N) is the same for H = 8, D = 24. */
+size_t hept_combine_bwd_scratch_bytes_shape(int N, int H, int D);
 size_t hept_combine_bwd_scratch_bytes(int N);
 int hept_combine_bwd(const float* acc, const float* g_out, const float* out_weight, int N, int H, int D,
                      float* gacc, float* d_weight, float* d_bias, void* scratch, size_t scratch_bytes,
