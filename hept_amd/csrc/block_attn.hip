@@ -38,6 +38,21 @@ namespace {
 // many workgroups a CU holds.  16-bit tiles: 8 waves per SIMD (<= 64 VGPRs, no spills; 87 -> 80 us at tracking-60k);
 // f32 tiles carry twice the fragments: 6 waves per SIMD, 4 for their ragged-tile variants (masks in registers).  The
 // ragged 16-bit variants fit 64 VGPRs as well (B = 100, the reference's yaml: 97 -> see DESIGN.md section 6).
+// pr = min(exp(x), 1) for the 16 logits of an accumulator (= exp(min(x, 0)): exp is monotone, exp(0) = 1).  The kernels
+// issue a VALU instruction every other cycle they are resident (64 % VALU-busy at tracking-60k), and the plain form is
+// three per logit (v_mul by log2(e), v_exp, v_min): here the multiply is packed (v_pk_mul_f32, two logits per
+// instruction; the same IEEE product) and the upper bound is the clamp bit of v_exp itself ([0, 1]: exp is never
+// negative) -- 1.5 instructions per logit, the same values.
+__device__ __forceinline__ void exp_clamped(const f32x16& x, float (&pr)[16]) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x2_t t = f32x2_t{x[2 * j], x[2 * j + 1]} * f32x2_t{1.442695041f, 1.442695041f};   // 0x3FB8AA3B, as __expf
+        pr[2 * j] = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(t[0]), 0.f), 1.f);
+        pr[2 * j + 1] = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(t[1]), 0.f), 1.f);
+    }
+}
+
 template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL>
 __global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(BF16 ? 8 : (FULL ? 6 : 4), BF16 ? 8 : (FULL ? 6 : 4))))
 void block_attn_kernel(const char* __restrict__ qhat,
@@ -156,8 +171,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
         // exp(min(x, 0)) written as min(exp(x), 1): identical value for every x (exp is monotone, exp(0) = 1),
         // and v_min on the v_exp result needs no NaN-canonicalising v_max in front of it
         float pr[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = fminf(__expf(x[r]), 1.f);
+        exp_clamped(x, pr);
         if (!FULL && (kt + 1) * 32 > B) {  // ragged last tile (B not a multiple of 32): padded keys carry no weight
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -442,8 +456,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
             const f32x16 x = xs[kl];
 
             float pr[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pr[r] = fminf(__expf(x[r]), 1.f);
+            exp_clamped(x, pr);
             if (!FULL && (kt + 1) * 32 > B) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)

@@ -1046,8 +1046,10 @@ static size_t sort_bytes(size_t segs, size_t N) {
 extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) { return sort_bytes((size_t)2 * Tl * H, N); }
 
 // internal (common.h): the sort of N-key segments is the KA / KB pair, whose KB launch can carry the v rows
+// (segments of the small-tile bucket kernel only: the large-tile one runs two waves per SIMD at 218 VGPRs, and riders
+//  in it cost 1.5 % at 480k and 1.9M points instead of saving anything)
 bool hept_sort_carries_rows(int N, int H, int D) {
-    return N > SMALL_CAP && D >= 4 && D % 4 == 0 && D <= 28 && H >= 1 && (unsigned long long)N * H * (D / 4) < (1ull << 32);
+    return N > SMALL_CAP && (size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2) && D >= 4 && D % 4 == 0 && D <= 28 && H >= 1;
 }
 
 extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const int64_t* codes, const float* minmax,

@@ -1,9 +1,11 @@
-"""Sanity run far above the benchmark size (480k and 1.92M points in one cloud): finishes, finite, memory use."""
+"""Sanity run far above the benchmark size (480k and 1.92M points in one cloud): finishes, finite, memory use.
+The checksums of two runs, one with HEPT_NO_ROW_RIDERS=1 (the row builder writes the v rows itself), must be equal."""
 import sys, os, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from hept_amd import HEPTAttention
 from hept_amd.synthetic import make_inputs
 dev = torch.device("cuda", 0)
+torch.manual_seed(0)   # the module parameters: the same in every run
 for n_raw in (480000, 1920000):
     inp = make_inputs([n_raw], block_size=128, n_hashes=3, seed=1)
     g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
@@ -22,6 +24,7 @@ for n_raw in (480000, 1920000):
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
     print(f"N_raw={n_raw}: {dt*1e3:.3f} ms/forward, {n_raw/dt/1e6:.1f} M points/s, finite={bool(torch.isfinite(out).all())}, "
-          f"mem={torch.cuda.max_memory_allocated()/2**30:.2f} GiB", flush=True)
+          f"mem={torch.cuda.max_memory_allocated()/2**30:.2f} GiB, "
+          f"checksum={float(out.double().sum()):.10e} / {float(out.double().abs().sum()):.10e}", flush=True)
     del g, inp, m
     torch.cuda.empty_cache()
