@@ -38,21 +38,6 @@ namespace {
 // many workgroups a CU holds.  16-bit tiles: 8 waves per SIMD (<= 64 VGPRs, no spills; 87 -> 80 us at tracking-60k);
 // f32 tiles carry twice the fragments: 6 waves per SIMD, 4 for their ragged-tile variants (masks in registers).  The
 // ragged 16-bit variants fit 64 VGPRs as well (B = 100, the reference's yaml: 97 -> see DESIGN.md section 6).
-// pr = min(exp(x), 1) for the 16 logits of an accumulator (= exp(min(x, 0)): exp is monotone, exp(0) = 1).  The kernels
-// issue a VALU instruction every other cycle they are resident (64 % VALU-busy at tracking-60k), and the plain form is
-// three per logit (v_mul by log2(e), v_exp, v_min): here the multiply is packed (v_pk_mul_f32, two logits per
-// instruction; the same IEEE product) and the upper bound is the clamp bit of v_exp itself ([0, 1]: exp is never
-// negative) -- 1.5 instructions per logit, the same values.
-__device__ __forceinline__ void exp_clamped(const f32x16& x, float (&pr)[16]) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const f32x2_t t = f32x2_t{x[2 * j], x[2 * j + 1]} * f32x2_t{1.442695041f, 1.442695041f};   // 0x3FB8AA3B, as __expf
-        pr[2 * j] = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(t[0]), 0.f), 1.f);
-        pr[2 * j + 1] = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(t[1]), 0.f), 1.f);
-    }
-}
-
 template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL>
 __global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(BF16 ? 8 : (FULL ? 6 : 4), BF16 ? 8 : (FULL ? 6 : 4))))
 void block_attn_kernel(const char* __restrict__ qhat,

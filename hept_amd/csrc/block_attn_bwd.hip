@@ -369,10 +369,11 @@ void block_attn_bwd_split_kernel(
                 x = mfma6(a_s, PL, off, q3[s], x);  // X^T = K^ . Q^T (+ both norms)
                 y = mfma6(b_s, PL, off, g3[s], y);  // Y^T = V . G^T
             }
-            float ds[16];
+            float ds[16], pe[16];
+            exp_clamped(x, pe);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                ds[r] = x[r] <= 0.f ? __expf(x[r]) * y[r] : 0.f;  // exp(x) <= 1 wherever the clamp passes the gradient
+                ds[r] = x[r] <= 0.f ? pe[r] * y[r] : 0.f;  // exp(x) <= 1 wherever the clamp passes the gradient
                 if (!FULL && (kt * 32 + hept_acc_row(r, hh) >= B || !own_ok)) ds[r] = 0.f;
             }
 #pragma unroll
@@ -444,9 +445,9 @@ void block_attn_bwd_split_kernel(
                 y = mfma6(b_s, PL, off, v3[s], y);  // Y = G . V^T
             }
             float pr[16], ds[16];
+            exp_clamped(x, pr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pr[r] = fminf(__expf(x[r]), 1.f);
                 if (!FULL && (qt * 32 + hept_acc_row(r, hh) >= B || !own_ok)) pr[r] = 0.f;
                 ds[r] = x[r] <= 0.f ? pr[r] * y[r] : 0.f;
             }

@@ -113,6 +113,21 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x
                                                    0, 0);
 }
 
+// pr = min(exp(x), 1) for the 16 logits of an accumulator (= exp(min(x, 0)): exp is monotone, exp(0) = 1).  The kernels
+// issue a VALU instruction every other cycle they are resident (64 % VALU-busy at tracking-60k), and the plain form is
+// three per logit (v_mul by log2(e), v_exp, v_min): here the multiply is packed (v_pk_mul_f32, two logits per
+// instruction; the same IEEE product) and the upper bound is the clamp bit of v_exp itself ([0, 1]: exp is never
+// negative) -- 1.5 instructions per logit, the same values.
+__device__ __forceinline__ void exp_clamped(const f32x16& x, float (&pr)[16]) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x2_t t = f32x2_t{x[2 * j], x[2 * j + 1]} * f32x2_t{1.442695041f, 1.442695041f};   // 0x3FB8AA3B, as __expf
+        pr[2 * j] = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(t[0]), 0.f), 1.f);
+        pr[2 * j + 1] = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(t[1]), 0.f), 1.f);
+    }
+}
+
 // ---- wave-wide scan / reductions on DPP (one VALU instruction per step; __shfl_up / __shfl_xor compile to ds_bpermute
 // plus address arithmetic, ~4 VALU and an LDS round trip per step).  gfx9 DPP: row_shr within rows of 16 lanes, then
 // row_bcast:15 (rows 1 and 3 take the last lane of the row before them) and row_bcast:31 (rows 2, 3 take lane 31).
