@@ -409,8 +409,12 @@ inline int prep_wgs(int N, int roles = 3) {
     return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 
+// (fp16 q^/k^ rows, 4 table slots: left alone the allocation takes 135 VGPRs = 3 waves per SIMD where the bf16 build
+//  takes 128; held to 4 waves like it -- the LDS allows 4 workgroups per CU)
 template <int D, int C, int TILE, int TMAX>
-__global__ __launch_bounds__(PREP_THREADS) void prep_hash_kernel(
+__global__ __launch_bounds__(PREP_THREADS)
+__attribute__((amdgpu_waves_per_eu((TILE == HEPT_PREC_MIXED16 && TMAX == 4) ? 4 : 1, (TILE == HEPT_PREC_MIXED16 && TMAX == 4) ? 4 : 8)))
+void prep_hash_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, int K, const float* __restrict__ alpha,
     const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
