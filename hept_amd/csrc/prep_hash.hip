@@ -128,7 +128,8 @@ __global__ __launch_bounds__(1024) void rpe_scale_bwd_kernel(const float* __rest
 // Streaming transform, one lane per (point, head) row, three wave ROLES selected by blockIdx.y:
 //   role 0 (q): q row + coords -> q^ row, q hashes, hash min/max, largest AND code
 //   role 1 (k): k row + coords -> k^ half of the kvhat row, k hashes, hash min/max
-//   role 2 (v): v row          -> v half of the kvhat row ([v | 1.0 at column D | 0])
+//   role 2 (v): v row          -> v half of the kvhat row ([v | 1.0 at column D | 0]); not launched (roles == 2) when the
+//               bucket-sort launch of the same forward writes these rows (sort_tables.hip: RowsJob)
 // A wave covers 8 consecutive points x 8 heads = one contiguous 6-KiB run of the (N, H*D) input and, per
 // head, one contiguous run of 8 output rows.  Both sides go through a wave-private LDS buffer so that
 // every global access is a full-width, fully coalesced 16 B per lane (LDS executes one wave's accesses

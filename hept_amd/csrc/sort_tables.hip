@@ -1,5 +1,6 @@
 // sort_tables: AND-shifted sort keys + exact stable segmented sort: one counting pass on the top bits of a monotone
-// bucket id, then every bucket is finished inside LDS.  Three kernels.
+// bucket id, then every bucket is finished inside LDS.  Two kernels; the second one also carries the v rows of the row
+// builder as rider workgroups (RowsJob below).
 //
 // Replaces, for tables [t0, t0+Tl) (reference file:line):
 //   hash_shift = max - min            example/hept_utils.py:70
