@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 # (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
@@ -67,6 +67,7 @@ SIGNATURES = {
     "hept_rpe_scale_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "hept_prepare_workspace_bytes": (c_size_t, [c_int] * 5),
     "hept_prepare_input": (c_int, [_P, c_int, _P, _P] + [c_int] * 4 + [_P] + [c_int] * 3 + [_P, c_size_t] + [_P] * 5),
+    "hept_prepare_probe": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
     "hept_comm_unique_id": (c_int, [_P]),
     "hept_comm_create": (c_int, [_P, c_int, c_int, _P]),
     "hept_comm_destroy": (c_int, [_P]),

@@ -243,6 +243,95 @@ extern "C" int hept_prepare_input_src(const float* x, int F, const float* coords
     return hept_launch_status();
 }
 
+// ---- the caller's only host round trip (hept_prepare_probe) -----------------------------------------------------------
+// What the host has to know before it can size the outputs of hept_prepare_input: the number of clouds, the longest
+// cloud, the padded length, and (for the "codes stay below 2^24" guard) the largest region count per axis -- read from
+// the tensors on every call.  One workgroup: thread i finds the first point of cloud i in the sorted batch vector
+// (lower bound), the cloud sizes / padded sizes are scanned in LDS, and the answers go to a host-mapped record; the
+// boundaries themselves stay on the device (cloud_start, pad_start: what hept_prepare_input takes).  Replaces four
+// torch launches, a device-to-host copy and a dozen host-side tensor operations per call.
+constexpr int PROBE_CLOUDS = 255;   // clouds the probe resolves (boundaries 0 .. 255); more: `overflow`, caller's slow path
+template <typename I>
+__device__ __forceinline__ int lower_bound_of(const I* __restrict__ v, int n, long long key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)v[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void probe_kernel(const void* __restrict__ batch, int batch_i64, int n_raw, int B,
+                                                    const float* __restrict__ regions, int T, int H,
+                                                    int* __restrict__ cloud_start, int* __restrict__ pad_start,
+                                                    int* __restrict__ host) {
+    __shared__ int edge_s[257], scan_s[256];
+    __shared__ float reg_s[2][256];
+    const int tid = threadIdx.x;
+    const int e = batch_i64 ? lower_bound_of(reinterpret_cast<const long long*>(batch), n_raw, tid)
+                            : lower_bound_of(reinterpret_cast<const int*>(batch), n_raw, tid);
+    edge_s[tid] = e;
+    if (tid == 0) edge_s[256] = n_raw;
+    // largest region count per axis (regions (T, 2, H))
+    float r0 = 0.f, r1 = 0.f;
+    for (int i = tid; i < T * H; i += 256) {
+        const int t = i / H, h = i - t * H;
+        r0 = fmaxf(r0, regions[((size_t)t * 2 + 0) * H + h]);
+        r1 = fmaxf(r1, regions[((size_t)t * 2 + 1) * H + h]);
+    }
+    reg_s[0][tid] = r0;
+    reg_s[1][tid] = r1;
+    __syncthreads();
+    // cloud tid exists when its first point lies inside the batch; clouds beyond the probe: overflow
+    const bool exists = tid < PROBE_CLOUDS && e < n_raw;
+    const int size = exists ? edge_s[tid + 1] - e : 0;      // (edge_s[255 + 1] = n_raw closes cloud 254's successor)
+    const int padded = ((size + B - 1) / B) * B;
+    scan_s[tid] = padded;
+    __syncthreads();
+    if (tid == 0) {   // 256 values: a serial scan is a few hundred cycles of one lane
+        int run = 0, n_clouds = 0, longest = 0, smallest = 1 << 30;
+        for (int c = 0; c < 256; ++c) {
+            const int first = edge_s[c];
+            const bool ex = c < PROBE_CLOUDS && first < n_raw;
+            const int sz = ex ? edge_s[c + 1] - first : 0;
+            pad_start[c] = run;
+            cloud_start[c] = first < n_raw ? first : n_raw;
+            if (ex) {
+                ++n_clouds;
+                longest = sz > longest ? sz : longest;
+                smallest = sz < smallest ? sz : smallest;
+            }
+            run += scan_s[c];
+        }
+        pad_start[256] = run;
+        cloud_start[256] = n_raw;
+        float m0 = 0.f, m1 = 0.f;
+        for (int i = 0; i < 256; ++i) { m0 = fmaxf(m0, reg_s[0][i]); m1 = fmaxf(m1, reg_s[1][i]); }
+        host[0] = n_clouds;
+        host[1] = run;                                  // n_pad
+        host[2] = longest;
+        host[3] = smallest;                             // < 1: a cloud id without points
+        host[4] = edge_s[PROBE_CLOUDS] < n_raw ? 1 : 0; // more clouds than the probe resolves
+        host[5] = __float_as_int(m0);
+        host[6] = __float_as_int(m1);
+        host[7] = 0x600DF00D;                           // written last: the record is complete
+        __threadfence_system();
+    }
+}
+
+extern "C" int hept_prepare_probe(const void* batch, int batch_is_i64, int n_raw, int B, const float* regions, int T,
+                                  int H, int32_t* cloud_start, int32_t* pad_start, int32_t* host_record, void* stream) {
+    if (!batch || !regions || !cloud_start || !pad_start || !host_record) return HEPT_ERR_ARG;
+    if (n_raw < 1 || B < 1 || T < 1 || H < 1) return HEPT_ERR_SHAPE;
+    void* dev_rec = nullptr;   // the device's address of the pinned host record
+    if (hipHostGetDevicePointer(&dev_rec, host_record, 0) != hipSuccess || !dev_rec) {
+        (void)hipGetLastError();
+        dev_rec = host_record;   // unified addressing: pinned host memory is reachable under its own address
+    }
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, batch, batch_is_i64, n_raw, B, regions,
+                       T, H, cloud_start, pad_start, reinterpret_cast<int*>(dev_rec));
+    return hept_launch_status();
+}
+
 extern "C" size_t hept_prepare_workspace_bytes(int n_raw, int n_clouds, int max_cloud, int T, int H) {
     const size_t S = (size_t)2 * n_clouds;
     const size_t sortL = (size_t)max_cloud > (size_t)n_raw / 1 ? (size_t)max_cloud : (size_t)max_cloud;

@@ -132,6 +132,34 @@ def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Di
     # The region maxima: packed codes must stay below 2^24 (they are sorted as exact fp32 keys), and the largest region
     # counts per axis are read from the tensor on EVERY call -- no cache keyed on a version counter that `.data` updates
     # do not bump.  (The concatenation promotes the boundaries to float32 -- exact below 2^24 points.)
+    import math
+
+    stream = torch.cuda.current_stream(dev)
+    if batch.dtype in (torch.int64, torch.int32) and n_raw < (1 << 30):
+        # the usual batch (at most 255 clouds): ONE small kernel finds the cloud boundaries, scans the padded sizes and
+        # reads the region maxima; the host waits for its 32-byte record in pinned memory and does no tensor work at all
+        # (csrc/prepare.hip: probe_kernel).  Anything it does not resolve takes the torch path below.
+        batch_c = batch.contiguous()
+        bounds = torch.empty(2 * 257, device=dev, dtype=torch.int32)       # cloud_start | pad_start
+        record = torch.zeros(8, dtype=torch.int32, pin_memory=True)
+        _lib.check(lib.hept_prepare_probe(batch_c.data_ptr(), 1 if batch.dtype == torch.int64 else 0, n_raw, block_size,
+                                          regions.data_ptr(), n_tables, num_heads, bounds.data_ptr(),
+                                          bounds[257:].data_ptr(), record.data_ptr(), stream.cuda_stream),
+                   "hept_prepare_probe")
+        stream.synchronize()
+        rec = record.tolist()
+        if rec[7] != 0x600DF00D:
+            raise RuntimeError("hept_prepare_probe: the host record was not written")
+        if not rec[4]:
+            n_clouds, n_pad, max_cloud, smallest = rec[0], rec[1], rec[2], rec[3]
+            if smallest < 1:
+                raise ValueError("every cloud id in [0, batch.max()] must own at least one point")
+            reg_hi = torch.tensor(rec[5:7], dtype=torch.int32).view(torch.float32).tolist()
+            bits = sum((int(math.ceil(float(v))) + 1).bit_length() for v in reg_hi)
+            if (n_clouds << bits) >= (1 << 24):
+                raise ValueError("AND codes would exceed 2^24: too many clouds x regions for the fp32-keyed pad sort")
+            return _prepare_outputs(lib, x, coords, coords_c, c_dim, bounds[:257], bounds[257:], n_clouds, n_raw,
+                                    max_cloud, n_pad, regions, n_tables, num_heads, block_size, stream)
     probe = _MAX_CLOUDS_ONE_TRIP
     wide = n_raw >= (1 << 24)
     while True:
@@ -155,6 +183,16 @@ def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Di
     if (n_clouds << bits) >= (1 << 24):
         raise ValueError("AND codes would exceed 2^24: too many clouds x regions for the fp32-keyed pad sort")
     pad_start = torch.cat([torch.zeros(1, dtype=torch.int64), padded.cumsum(0)]).to(torch.int32).to(dev, non_blocking=True)
+    return _prepare_outputs(lib, x, coords, coords_c, c_dim, cloud_start, pad_start, n_clouds, n_raw, max_cloud, n_pad,
+                            regions, n_tables, num_heads, block_size, stream)
+
+
+def _prepare_outputs(lib, x, coords, coords_c, c_dim, cloud_start, pad_start, n_clouds, n_raw, max_cloud, n_pad, regions,
+                     n_tables, num_heads, block_size, stream):
+    """The outputs of ``prepare_input`` once their sizes are known: one ``hept_prepare_input`` call and the feature
+    gather."""
+    from . import _lib
+
     dev = coords.device
     ws = torch.empty(int(lib.hept_prepare_workspace_bytes(n_raw, n_clouds, max_cloud, n_tables, num_heads)),
                      device=dev, dtype=torch.uint8)
@@ -165,8 +203,8 @@ def prepare_input_hip(x, coords, batch, helper_params) -> Tuple[torch.Tensor, Di
     _lib.check(lib.hept_prepare_input(coords_c.data_ptr(), c_dim, cloud_start.data_ptr(), pad_start.data_ptr(),
                                       n_clouds, n_raw, max_cloud, n_pad, regions.data_ptr(), n_tables, num_heads,
                                       block_size, ws.data_ptr(), ws.numel(), pad_seq.data_ptr(), unpad.data_ptr(),
-                                      coords_pad.data_ptr(), codes_pad.data_ptr(),
-                                      torch.cuda.current_stream(dev).cuda_stream), "hept_prepare_input")
+                                      coords_pad.data_ptr(), codes_pad.data_ptr(), stream.cuda_stream),
+               "hept_prepare_input")
     kwargs = {"combined_shifts": codes_pad, "coords": coords_pad.to(coords.dtype)}
     return x[pad_seq], kwargs, unpad.bool()
 

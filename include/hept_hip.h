@@ -370,6 +370,14 @@ int hept_combine_bwd(const float* acc, const float* g_out, const float* out_weig
  * Ties (equal coordinates / equal codes) are broken by ascending index; the reference's argsort leaves them
  * undefined.  Requires every packed code < 2^24. */
 size_t hept_prepare_workspace_bytes(int n_raw, int n_clouds, int max_cloud, int T, int H);
+/* The host round trip in front of hept_prepare_input (example/transformer.py:35-43 synchronises on the cloud sizes as
+ * well): one small kernel reads the sorted batch vector (i64 or i32, n_raw entries, cloud ids 0 .. n_clouds - 1) and
+ * regions (T, 2, H), leaves cloud_start / pad_start (257 i32 each, device) for hept_prepare_input and writes a record
+ * of 8 i32 into pinned host memory: [n_clouds, n_pad, longest cloud, smallest cloud (< 1: a cloud id without points),
+ * overflow (more than 255 clouds: not resolved, use another path), f32 bits of the largest region count of axis 0,
+ * of axis 1, 0x600DF00D].  The caller synchronises the stream and reads the record. */
+int hept_prepare_probe(const void* batch, int batch_is_i64, int n_raw, int B, const float* regions, int T, int H,
+                       int32_t* cloud_start, int32_t* pad_start, int32_t* host_record, void* stream);
 int hept_prepare_input(const float* coords, int C, const int32_t* cloud_start, const int32_t* pad_start,
                        int n_clouds, int n_raw, int max_cloud, int n_pad, const float* regions, int T, int H,
                        int B, void* workspace, size_t workspace_bytes, int64_t* pad_seq, unsigned char* unpad,

@@ -183,3 +183,36 @@ def test_region_table_updated_in_place_is_re_read(gpu_device):
     assert regions._version == v
     with pytest.raises(ValueError, match="2\\^24"):
         prepare_input_hip(*args)
+
+
+@pytest.mark.parametrize("n_clouds,dtype", [(1, torch.int64), (7, torch.int32), (255, torch.int64), (256, torch.int64),
+                                            (300, torch.int32)])
+def test_cloud_boundaries_from_the_probe_kernel(n_clouds, dtype, gpu_device):
+    """``hept_prepare_probe`` (one kernel + a 32-byte host record) sizes the outputs for batches of up to 255 clouds;
+    larger batches take the torch path.  Both against the host mirror, with int64 and int32 batch vectors and clouds of
+    very different sizes (1 point up to a few hundred)."""
+    g = torch.Generator().manual_seed(n_clouds)
+    sizes = torch.randint(1, 40, (n_clouds,), generator=g)
+    sizes[0] = 1
+    sizes[-1] = 333
+    batch = torch.repeat_interleave(torch.arange(n_clouds), sizes)
+    n_raw = int(sizes.sum())
+    coords = torch.randn(n_raw, 4, generator=g)
+    regions = torch.tensor([[[2.0] * cases.NUM_HEADS, [3.0] * cases.NUM_HEADS]] * 2)   # (T = 2, 2, H): 2 x 3 regions
+    helper = {"block_size": 16, "num_heads": cases.NUM_HEADS, "regions": regions}
+    pad_cpu, kw_cpu, mask_cpu = prepare_input(torch.arange(n_raw), coords, batch, helper)
+    helper_g = {"block_size": 16, "num_heads": cases.NUM_HEADS, "regions": regions.to(gpu_device)}
+    pad_gpu, kw_gpu, mask_gpu = prepare_input_hip(torch.arange(n_raw, device=gpu_device), coords.to(gpu_device),
+                                                  batch.to(gpu_device, dtype), helper_g)
+    assert torch.equal(pad_gpu.cpu(), pad_cpu) and torch.equal(mask_gpu.cpu(), mask_cpu)
+    assert torch.equal(kw_gpu["combined_shifts"].cpu(), kw_cpu["combined_shifts"])
+    assert torch.equal(kw_gpu["coords"].cpu(), kw_cpu["coords"])
+
+
+def test_a_cloud_id_without_points_is_an_error(gpu_device):
+    batch = torch.tensor([0] * 20 + [2] * 20)     # id 1 owns nothing
+    coords = torch.randn(40, 4)
+    helper = {"block_size": 8, "num_heads": cases.NUM_HEADS,
+              "regions": torch.full((2, 2, cases.NUM_HEADS), 2.0, device=gpu_device)}
+    with pytest.raises(ValueError, match="at least one point"):
+        prepare_input_hip(torch.arange(40, device=gpu_device), coords.to(gpu_device), batch.to(gpu_device), helper)
