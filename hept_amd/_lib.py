@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 # (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
@@ -63,7 +63,9 @@ SIGNATURES = {
     "hept_forward_partial_src": (c_int, [_P] * 7 + [c_int] + [_P] * 2 + [c_int] * 11 + [_P, c_size_t, _P, _P]),
     "hept_block_attn_bwd": (c_int, [_P] * 5 + [c_int] * 5 + [_P] * 3),
     "hept_block_attn_bwd_f32mfma": (c_int, [_P] * 5 + [c_int] * 5 + [_P] * 3),
+    "hept_block_attn_bwd_bf16": (c_int, [_P] * 5 + [c_int] * 5 + [_P] * 3),
     "hept_bwd_reduce": (c_int, [_P, _P] + [c_int] * 5 + [_P, c_int] + [_P] * 6),
+    "hept_bwd_reduce16": (c_int, [_P, _P] + [c_int] * 5 + [_P, c_int] + [_P] * 6),
     "hept_rpe_scale_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "hept_prepare_workspace_bytes": (c_size_t, [c_int] * 5),
     "hept_prepare_input": (c_int, [_P, c_int, _P, _P] + [c_int] * 4 + [_P] + [c_int] * 3 + [_P, c_size_t] + [_P] * 5),

@@ -85,13 +85,16 @@ class RpeScale(torch.autograd.Function):
 class HeptPartialSums(torch.autograd.Function):
     """(q, k, v, coords, sqrt_w) -> acc (N, H, 32) = sum over tables of [numer | denom | 0].
 
+    ``tiles``: "fp32" (the reference's arithmetic; split-bf16 products in both directions) or "bf16" (the rows and
+    kernels of the bf16 forward, one bf16 MFMA per product in the backward too -- ``HEPTAttention.train_tiles``).
+
     ``geo`` = (eta, phi, cfac, raw_size) selects the reference's src variant (``codes`` is then None): rows at and
     after ``raw_size`` are zero-filled in place by the reference (``src/models/attention/hept.py:89-91``), so no
     gradient flows into them.
     """
 
     @staticmethod
-    def forward(ctx, q, k, v, coords, sqrt_w, alpha, codes, block_size, geo=None, f32_mfma=False):
+    def forward(ctx, q, k, v, coords, sqrt_w, alpha, codes, block_size, geo=None, f32_mfma=False, tiles="fp32"):
         n, hd = q.shape
         h = alpha.shape[0]
         d = hd // h
@@ -104,11 +107,11 @@ class HeptPartialSums(torch.autograd.Function):
         for c0 in range(0, n_tables, MAX_TABLES):
             tc = min(MAX_TABLES, n_tables - c0)
             if geo is None:
-                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, "fp32", t0=c0, tl=tc)
+                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, tiles, t0=c0, tl=tc)
                 qp, kp = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"], t0=c0)
             else:
                 eta, phi, cfac, raw_size = geo
-                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, None, "fp32", t0=c0, tl=tc, raw_size=raw_size)
+                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, None, tiles, t0=c0, tl=tc, raw_size=raw_size)
                 qp, kp = ops.sort_tables_src(ph["qproj"], ph["kproj"], eta, phi, cfac, ph["minmax"], t0=c0)
             qs.append(qp)
             ks.append(kp)
@@ -139,7 +142,7 @@ class HeptPartialSums(torch.autograd.Function):
         if not ctx.needs_input_grad[4]:
             dsw = None
         dcoords = (dcs * sqrt_w[None]).sum(dim=1) if ctx.needs_input_grad[3] else None
-        return dq, dk, dv, dcoords, dsw, None, None, None, None, None
+        return dq, dk, dv, dcoords, dsw, None, None, None, None, None, None
 
 
 class HeptPartialSumsFused(torch.autograd.Function):
@@ -155,7 +158,8 @@ class HeptPartialSumsFused(torch.autograd.Function):
     between the passes."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, block_size, f32_mfma=False):
+    def forward(ctx, x, ln_w, ln_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, block_size, f32_mfma=False,
+                tiles="fp32"):
         from ._lib import MAX_TABLES
 
         n, d = x.shape
@@ -163,7 +167,7 @@ class HeptPartialSumsFused(torch.autograd.Function):
         qs, ks = [], []
         for c0 in range(0, n_tables, MAX_TABLES):
             tc = min(MAX_TABLES, n_tables - c0)
-            ph = ops.prep_hash_fused(x, ln_w, ln_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, "fp32", t0=c0, tl=tc)
+            ph = ops.prep_hash_fused(x, ln_w, ln_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, tiles, t0=c0, tl=tc)
             qp, kp = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"], t0=c0)
             qs.append(qp)
             ks.append(kp)
@@ -190,7 +194,7 @@ class HeptPartialSumsFused(torch.autograd.Function):
         dcoords = (dcs * sqrt_w[None]).sum(dim=1) if need[7] else None
         return (dx if need[0] else None, dlw if need[1] else None, dlb if need[2] else None, None,
                 dwq if need[4] else None, dwk if need[5] else None, dwv if need[6] else None, dcoords,
-                dsw if need[8] else None, None, None, None, None)
+                dsw if need[8] else None, None, None, None, None, None)
 
 
 class HeptCombine(torch.autograd.Function):

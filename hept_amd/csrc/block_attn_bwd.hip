@@ -488,10 +488,243 @@ void block_attn_bwd_split_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 16-bit tiles (HEPT_PREC_BF16 training, opt-in): the backward on the rows the bf16 forward gathers -- q^ rows of
+// 64 B, k^ | v rows of 128 B, the f32 norm in the last four bytes of a q^ / k^ row -- with ONE bf16 MFMA per product
+// where the kernel above issues five or six.  Same two phases and the same operand layouts as the split kernel on
+// single planes (PlaneLanes / plane_tr_frag / ElemLanes above), but all four tiles (Q^, K^, V, G) are resident at
+// once (32 KB at B = 128: no hand-over between the phases), the norms are added to the logits in f32 as the bf16
+// forward does (a norm rounded to bf16 would be off by 2^-9 |q|^2), and columns 30 / 31 of the staged tiles carry only
+// the 1.0 that makes the products return the row / column sums of dS: K^ (1, 0), Q^ (0, 1) -- their cross terms in
+// Q^.K^ vanish.  G (the upstream rows, f32) and the tile-level factors P, dS are rounded to bf16; every accumulation
+// is f32.  Gradients agree with the f32-tile backward to the accuracy of a bf16 forward (tests/test_gpu_backward.py).
+__device__ __forceinline__ float plane_elem1(const char* plane, const ElemLanes& e, int r) {
+    const int off = e.base[(r >> 2) & 1] + ((r & 3) + 8 * (r >> 2)) * BPROW;
+    return __uint_as_float((unsigned int)*reinterpret_cast<const unsigned short*>(plane + off) << 16);
+}
+__device__ __forceinline__ u32x4 pack8_bf16(const float* a) {
+    return u32x4{hept_pack_bf16(a[0], a[1]), hept_pack_bf16(a[2], a[3]), hept_pack_bf16(a[4], a[5]),
+                 hept_pack_bf16(a[6], a[7])};
+}
+
+// (The per-table gradient rows leave the kernel as bf16 too -- dq_part (T, N, H, 32) and dkv_part (T, N, H, 64) in
+//  bf16, two columns per dword: with f32 rows the kernel was bound by writing them, 553 MB at tracking-60k, 260 us, and
+//  the table sum by reading them back; the sum itself (hept_bwd_reduce16) is f32.)
+template <int NKT, bool FULL>
+__global__ __launch_bounds__(64 * NKT) void block_attn_bwd_bf16_kernel(
+    const char* __restrict__ qhat, const char* __restrict__ kvhat, const int* __restrict__ qpos,
+    const int* __restrict__ kpos, const float* __restrict__ gacc, unsigned int* __restrict__ dq_part,
+    unsigned int* __restrict__ dkv_part, int N, int H, int D, int B, int nb) {
+    constexpr int NT = 64 * NKT, ROWS = 32 * NKT, PL = ROWS * BPROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* q_s = smem;              // Q^ rows, columns (30, 31) = (0, 1.0)
+    char* k_s = smem + PL;         // K^ rows, columns (30, 31) = (1.0, 0)
+    char* v_s = smem + 2 * PL;     // [v | 1.0 at column D | 0]
+    char* g_s = smem + 3 * PL;     // upstream rows [d numer | d den | 0], rounded to bf16
+    float* qn_s = reinterpret_cast<float*>(smem + 4 * PL);
+    float* kn_s = qn_s + ROWS;
+    int* qidx_s = reinterpret_cast<int*>(kn_s + ROWS);
+    int* kidx_s = qidx_s + ROWS;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
+    const int bid = blockIdx.x;
+    const int h = bid % H, rest = bid / H, b = rest % nb, t = rest / nb;
+    const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
+    const int* __restrict__ qp = qpos + seg;
+    const int* __restrict__ kp = kpos + seg;
+
+    // ---- stage the four tiles: one item = a 16-B chunk (8 columns) of a gathered row
+    for (int ci = tid; ci < ROWS * 4; ci += NT) {
+        const int row = ci >> 2, c = ci & 3;
+        const bool ok = FULL || row < B;
+        const int src = ok ? qp[row] : 0;
+        u32x4 qv = {0u, 0u, 0u, 0u}, gv = {0u, 0u, 0u, 0u};
+        if (ok) {
+            qv = *reinterpret_cast<const u32x4*>(qhat + ((size_t)h * N + src) * 64 + c * 16);
+            const float* grow = gacc + ((size_t)src * H + h) * 32 + c * 8;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(grow), g1 = *reinterpret_cast<const f32x4*>(grow + 4);
+            gv = u32x4{hept_pack_bf16(g0[0], g0[1]), hept_pack_bf16(g0[2], g0[3]), hept_pack_bf16(g1[0], g1[1]),
+                       hept_pack_bf16(g1[2], g1[3])};
+        }
+        if (c == 3) {
+            qn_s[row] = __uint_as_float(qv[3]);
+            qidx_s[row] = ok ? src : -1;
+            qv[3] = ok ? 0x3F800000u : 0u;   // columns (30, 31) = (0, 1.0): column sums of dS ride in dS^T . Q^
+        }
+        *reinterpret_cast<u32x4*>(q_s + plane_chunk(row, c)) = qv;
+        *reinterpret_cast<u32x4*>(g_s + plane_chunk(row, c)) = gv;
+    }
+    for (int ci = tid; ci < ROWS * 8; ci += NT) {
+        const int row = ci >> 3, c = ci & 7;
+        const bool ok = FULL || row < B;
+        const int src = ok ? kp[row] : 0;
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (ok) x = *reinterpret_cast<const u32x4*>(kvhat + ((size_t)h * N + src) * 128 + c * 16);
+        if (c == 3) {
+            kn_s[row] = __uint_as_float(x[3]);
+            kidx_s[row] = ok ? src : -1;
+            x[3] = ok ? 0x00003F80u : 0u;    // columns (30, 31) = (1.0, 0): row sums of dS ride in dS . K^
+        }
+        *reinterpret_cast<u32x4*>((c < 4 ? k_s : v_s) + plane_chunk(row, c & 3)) = x;
+    }
+    __syncthreads();
+
+    const int own = w * 32 + li;  // the query (phase Q) / key (phase K) of this lane
+    const bool own_ok = FULL || own < B;
+    const PlaneLanes pl = plane_lanes(lane);
+    const ElemLanes el = elem_lanes(w, lane);
+
+    // =========================== phase Q: d q^ ===========================
+    {
+        u32x4 qown[2], gown[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qown[s] = *reinterpret_cast<const u32x4*>(q_s + w * 32 * BPROW + pl.row[s]);
+            gown[s] = *reinterpret_cast<const u32x4*>(g_s + w * 32 * BPROW + pl.row[s]);
+        }
+        const float qn = qn_s[own];
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (!FULL && kt * 32 >= B) break;
+            f32x16 x, y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x[r] = qn + kn_s[kt * 32 + hept_acc_row(r, hh)];
+                y[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = kt * 32 * BPROW + pl.row[s];
+                x = mfma_bf16(*reinterpret_cast<const u32x4*>(k_s + off), qown[s], x);  // X^T = K^ . Q^T (+ norms above)
+                y = mfma_bf16(*reinterpret_cast<const u32x4*>(v_s + off), gown[s], y);  // Y^T = V . G^T
+            }
+            float ds[16], pe[16];
+            exp_clamped(x, pe);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ds[r] = x[r] <= 0.f ? pe[r] * y[r] : 0.f;
+                if (!FULL && (kt * 32 + hept_acc_row(r, hh) >= B || !own_ok)) ds[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)   // Z += dS . K^ ; column 30 = rowsum(dS)
+                z = mfma_bf16(pack8_bf16(ds + 8 * s), plane_tr_frag(k_s, pl, (kt * 32 + 16 * s) * BPROW), z);
+        }
+        unsigned int* __restrict__ dst = dq_part + (size_t)t * N * H * 16 + (size_t)h * 16 + (li >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q2 = w * 32 + hept_acc_row(r, hh);
+            const float rs = __shfl(z[r], 30 + 32 * hh);
+            const float qv = plane_elem1(q_s, el, r);
+            const float mine = li < 30 ? z[r] - rs * qv : 0.f;
+            const float nbr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mine), 0xB1, 0xF,
+                                                                                 0xF, true));  // lane ^ 1
+            if ((FULL || q2 < B) && (li & 1) == 0) dst[(size_t)qidx_s[q2] * H * 16] = hept_pack_bf16(mine, nbr);
+        }
+    }
+
+    // =========================== phase K: d k^, d v ===========================
+    {
+        u32x4 kown[2], vown[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            kown[s] = *reinterpret_cast<const u32x4*>(k_s + w * 32 * BPROW + pl.row[s]);
+            vown[s] = *reinterpret_cast<const u32x4*>(v_s + w * 32 * BPROW + pl.row[s]);
+        }
+        const float kn = kn_s[own];
+        f32x16 zk, zv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { zk[r] = 0.f; zv[r] = 0.f; }
+#pragma unroll
+        for (int qt = 0; qt < NKT; ++qt) {
+            if (!FULL && qt * 32 >= B) break;
+            f32x16 x, y;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x[r] = qn_s[qt * 32 + hept_acc_row(r, hh)] + kn;
+                y[r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = qt * 32 * BPROW + pl.row[s];
+                x = mfma_bf16(*reinterpret_cast<const u32x4*>(q_s + off), kown[s], x);  // X = Q^ . K^T
+                y = mfma_bf16(*reinterpret_cast<const u32x4*>(g_s + off), vown[s], y);  // Y = G . V^T
+            }
+            float pr[16], ds[16];
+            exp_clamped(x, pr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!FULL && (qt * 32 + hept_acc_row(r, hh) >= B || !own_ok)) pr[r] = 0.f;
+                ds[r] = x[r] <= 0.f ? pr[r] * y[r] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int base = (qt * 32 + 16 * s) * BPROW;
+                zk = mfma_bf16(pack8_bf16(ds + 8 * s), plane_tr_frag(q_s, pl, base), zk);  // dS^T . Q^ ; column 31 = colsum(dS)
+                zv = mfma_bf16(pack8_bf16(pr + 8 * s), plane_tr_frag(g_s, pl, base), zv);  // P^T . G
+            }
+        }
+        unsigned int* __restrict__ dst = dkv_part + (size_t)t * N * H * 32 + (size_t)h * 32 + (li >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k2 = w * 32 + hept_acc_row(r, hh);
+            const float cs = __shfl(zk[r], 31 + 32 * hh);
+            const float kv = plane_elem1(k_s, el, r);
+            const float dkm = li < 30 ? zk[r] - cs * kv : 0.f, dvm = li < D ? zv[r] : 0.f;
+            const float dkn = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dkm), 0xB1, 0xF,
+                                                                                 0xF, true));
+            const float dvn = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dvm), 0xB1, 0xF,
+                                                                                 0xF, true));
+            if ((FULL || k2 < B) && (li & 1) == 0) {
+                unsigned int* row = dst + (size_t)kidx_s[k2] * H * 32;
+                row[0] = hept_pack_bf16(dkm, dkn);
+                row[16] = hept_pack_bf16(dvm, dvn);
+            }
+        }
+    }
+}
+
 // sum the per-table partial rows and undo the augmentation:
 //   dq,dk,dv (N, H*D);  dcs (N, H, C) = gradient of the scaled coordinates sqrt_w[h,c]*coords[n,c] (q^ and k^ share them)
 // One thread per (point, head, column): nine independent loads each, 60 000 workgroups -- the kernel runs at the
 // copy bandwidth (a variant that walked 16 points per workgroup to keep d_sqrt_w sums in registers ran at 60 % of it).
+// the same sum over bf16 partial rows (the 16-bit training tiles); f32 accumulation in table order.  One thread per
+// (point, head, column PAIR): dword loads (one element per thread was 2-byte loads: 3.2 TB/s).
+__global__ __launch_bounds__(256) void bwd_reduce16_kernel(const unsigned int* __restrict__ dq_part,
+                                                           const unsigned int* __restrict__ dkv_part, int Tl, int N,
+                                                           int H, int D, int C, int raw_size, float* __restrict__ dq,
+                                                           float* __restrict__ dk, float* __restrict__ dv,
+                                                           float* __restrict__ dcs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n, h, column pair)
+    const size_t total = (size_t)N * H * 16;
+    if (i >= total) return;
+    const int col = 2 * (int)(i & 15);
+    const size_t nh = i >> 4;  // n * H + h
+    float sq[2] = {0.f, 0.f}, sk[2] = {0.f, 0.f}, sv[2] = {0.f, 0.f};
+    for (int t = 0; t < Tl; ++t) {
+        const unsigned int a = dq_part[(size_t)t * total + i];
+        const unsigned int b = dkv_part[((size_t)t * N * H + nh) * 32 + (col >> 1)];
+        const unsigned int c = dkv_part[((size_t)t * N * H + nh) * 32 + 16 + (col >> 1)];
+        sq[0] += hept_bf16_lo(a); sq[1] += hept_bf16_hi(a);
+        sk[0] += hept_bf16_lo(b); sk[1] += hept_bf16_hi(b);
+        sv[0] += hept_bf16_lo(c); sv[1] += hept_bf16_hi(c);
+    }
+    if (nh >= (size_t)raw_size * H) sq[0] = sq[1] = sk[0] = sk[1] = sv[0] = sv[1] = 0.f;  // src variant: padding rows
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int cc = col + e;
+        if (cc < D) {
+            dq[nh * D + cc] = sq[e];
+            dk[nh * D + cc] = sk[e];
+            dv[nh * D + cc] = sv[e];
+        } else if (cc < D + C) {
+            dcs[nh * C + (cc - D)] = sq[e] + sk[e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void bwd_reduce_kernel(const float* __restrict__ dq_part,
                                                          const float* __restrict__ dkv_part, int Tl, int N, int H,
                                                          int D, int C, int raw_size, float* __restrict__ dq,
@@ -619,6 +852,37 @@ int launch_bwd_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, cons
     return hept_launch_status();
 }
 
+template <bool FULL>
+int launch_bwd_bf16(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
+                    const int* kpos, const float* gacc, unsigned int* dq_part, unsigned int* dkv_part, int N, int H, int D,
+                    int B, int nb) {
+#define HEPT_BWDH_CASE(K)                                                                                        \
+    case K: {                                                                                                    \
+        constexpr size_t lds = (size_t)4 * 32 * K * BPROW + 32 * K * 16;                                         \
+        static LdsRaised raised;                                                                                 \
+        if (lds > 65536 &&                                                                                       \
+            hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_bwd_bf16_kernel<K, FULL>), lds))    \
+            return HEPT_ERR_LAUNCH;                                                                              \
+        hipLaunchKernelGGL((block_attn_bwd_bf16_kernel<K, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat,      \
+                           qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);                                 \
+        break;                                                                                                   \
+    }
+    switch (nkt) {
+        HEPT_BWDH_CASE(1)
+        HEPT_BWDH_CASE(2)
+        HEPT_BWDH_CASE(3)
+        HEPT_BWDH_CASE(4)
+        HEPT_BWDH_CASE(5)
+        HEPT_BWDH_CASE(6)
+        HEPT_BWDH_CASE(7)
+        HEPT_BWDH_CASE(8)
+        default:
+            return HEPT_ERR_SHAPE;
+    }
+#undef HEPT_BWDH_CASE
+    return hept_launch_status();
+}
+
 int block_attn_bwd_impl(bool split, const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
                         const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part, float* dkv_part,
                         void* stream) {
@@ -650,24 +914,61 @@ extern "C" int hept_block_attn_bwd_f32mfma(const float* qhat, const float* kvhat
     return block_attn_bwd_impl(false, qhat, kvhat, qpos, kpos, gacc, N, H, D, Tl, B, dq_part, dkv_part, stream);
 }
 
-extern "C" int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
-                               const float* coords, int raw_size, float* dq, float* dk, float* dv, float* dcs,
-                               float* d_sqrt_w, void* stream) {
+extern "C" int hept_block_attn_bwd_bf16(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos,
+                                        const float* gacc, int N, int H, int D, int Tl, int B, void* dq_part16,
+                                        void* dkv_part16, void* stream) {
+    unsigned int* dq_part = reinterpret_cast<unsigned int*>(dq_part16);
+    unsigned int* dkv_part = reinterpret_cast<unsigned int*>(dkv_part16);
+    if (!qhat || !kvhat || !qpos || !kpos || !gacc || !dq_part || !dkv_part) return HEPT_ERR_ARG;
+    if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
+        return HEPT_ERR_SHAPE;
+    const int nb = N / B, nkt = (B + 31) / 32;
+    const dim3 grid((unsigned)((size_t)Tl * nb * H));
+    hipStream_t st = (hipStream_t)stream;
+    const char* q = reinterpret_cast<const char*>(qhat);
+    const char* kv = reinterpret_cast<const char*>(kvhat);
+    return B == 32 * nkt ? launch_bwd_bf16<true>(nkt, grid, st, q, kv, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb)
+                         : launch_bwd_bf16<false>(nkt, grid, st, q, kv, qpos, kpos, gacc, dq_part, dkv_part, N, H, D, B, nb);
+}
+
+namespace {
+int bwd_reduce_impl(bool rows16, const void* dq_part, const void* dkv_part, int Tl, int N, int H, int D, int C,
+                    const float* coords, int raw_size, float* dq, float* dk, float* dv, float* dcs, float* d_sqrt_w,
+                    void* stream) {
     if (!dq_part || !dkv_part || !dq || !dk || !dv || !dcs) return HEPT_ERR_ARG;
     if (d_sqrt_w && !coords) return HEPT_ERR_ARG;
     if (Tl < 1 || N < 1 || H < 1 || D < 1 || C < 1 || D + C > 30 || raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
     if (d_sqrt_w && H * C > 64) return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)N * H * 32;
-    hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dq_part, dkv_part, Tl,
-                       N, H, D, C, raw_size, dq, dk, dv, dcs);
+    if (rows16)
+        hipLaunchKernelGGL(bwd_reduce16_kernel, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned int*>(dq_part),
+                           reinterpret_cast<const unsigned int*>(dkv_part), Tl, N, H, D, C, raw_size, dq, dk, dv, dcs);
+    else
+        hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(dq_part), reinterpret_cast<const float*>(dkv_part), Tl, N, H, D,
+                           C, raw_size, dq, dk, dv, dcs);
     if (d_sqrt_w) {
         // per-workgroup partial sums live in dq_part: the reduction above was its last reader ((N+255)/256 * 64 floats
-        // of the Tl*N*H*32 it holds)
-        float* partial = const_cast<float*>(dq_part);
+        // of the Tl*N*H*32 values (f32 or bf16) it holds)
+        float* partial = reinterpret_cast<float*>(const_cast<void*>(dq_part));
         const int n_wgs = (N + DSW_POINTS - 1) / DSW_POINTS;
         hipLaunchKernelGGL(dsw_kernel, dim3((unsigned)n_wgs), dim3(256), 0, st, dcs, coords, N, H, C, partial);
         hipLaunchKernelGGL(dsw_sum_kernel, dim3(64 / HEPT_FSUM_OUT), dim3(256), 0, st, partial, n_wgs, H * C, d_sqrt_w);
     }
     return hept_launch_status();
+}
+}  // namespace
+
+extern "C" int hept_bwd_reduce(const float* dq_part, const float* dkv_part, int Tl, int N, int H, int D, int C,
+                               const float* coords, int raw_size, float* dq, float* dk, float* dv, float* dcs,
+                               float* d_sqrt_w, void* stream) {
+    return bwd_reduce_impl(false, dq_part, dkv_part, Tl, N, H, D, C, coords, raw_size, dq, dk, dv, dcs, d_sqrt_w, stream);
+}
+
+extern "C" int hept_bwd_reduce16(const void* dq_part16, const void* dkv_part16, int Tl, int N, int H, int D, int C,
+                                 const float* coords, int raw_size, float* dq, float* dk, float* dv, float* dcs,
+                                 float* d_sqrt_w, void* stream) {
+    return bwd_reduce_impl(true, dq_part16, dkv_part16, Tl, N, H, D, C, coords, raw_size, dq, dk, dv, dcs, d_sqrt_w, stream);
 }

@@ -207,6 +207,16 @@ class HEPTAttention(nn.Module):
         return sh.finish(acc, lambda part, n0, cnt: ops.combine_out(part, d, self.out_linear.weight,
                                                                      self.out_linear.bias, n0, cnt))
 
+    # Tiles of the TRAINING path: "fp32" (default: the reference's arithmetic, gradients pinned on its autograd) or
+    # "bf16" (opt-in: the bf16 forward's rows and one bf16 MFMA per product in the backward as well -- about half the
+    # step time, gradients to the accuracy of a bf16 forward).  Set on the instance or the class.
+    train_tiles = "fp32"
+
+    def _train_tiles(self) -> str:
+        if self.train_tiles not in ("fp32", "bf16"):
+            raise ValueError("train_tiles must be 'fp32' or 'bf16'")
+        return "fp32" if self.precision == "fp32_mfma" else self.train_tiles
+
     def _train_fused_ok(self, x, kwargs) -> bool:
         """Whether the training-mode ``Attn`` block may hand its LayerNorm and projections to the fused row builder"""
         return (x.is_cuda and self.dim_per_head == 24 and self.num_heads == 8 and self.sharding is None
@@ -224,16 +234,17 @@ class HEPTAttention(nn.Module):
         acc = HeptPartialSumsFused.apply(x.float(), norm1.weight.float(), norm1.bias.float(), norm1.eps, w_q.weight.float(),
                                          w_k.weight.float(), w_v.weight.float(), kwargs["coords"].float(), sqrt_w,
                                          self.e2lsh.alpha.detach(), kwargs["combined_shifts"], self.block_size,
-                                         self.precision == "fp32_mfma")
+                                         self.precision == "fp32_mfma", self._train_tiles())
         return HeptCombine.apply(acc, self.out_linear.weight, self.out_linear.bias).to(x.dtype)
 
     def _forward_train(self, query, key, value, **kwargs):
         """Differentiable path: HIP forward/backward of the block attention inside autograd (f32 tiles)."""
         from .autograd import HeptPartialSums, RpeScale, ReplicatedGrad, sum_over_ranks
 
-        # the backward kernels use f32 tiles, so training always runs them -- also for a module whose inference
-        # precision is 16-bit (gradients are those of the reference's fp32 arithmetic)
+        # training runs f32 tiles -- also for a module whose inference precision is 16-bit -- so that the gradients are
+        # those of the reference's fp32 arithmetic; `train_tiles = "bf16"` opts into the 16-bit kernels in both directions
         f32_mfma = self.precision == "fp32_mfma"
+        tiles = self._train_tiles()
         n = query.shape[0]
         if n % self.block_size != 0:
             raise ValueError(f"number of points {n} is not a multiple of block_size {self.block_size}")
@@ -261,7 +272,7 @@ class HEPTAttention(nn.Module):
                        phi.view(self.n_hashes, h, n)[t0:t0 + tl].reshape(tl * h, n).contiguous(),
                        cfac.view(self.n_hashes, h)[t0:t0 + tl].reshape(tl * h).contiguous(), raw)
             q2, k2, v2, coords, sqrt_w = (ReplicatedGrad.apply(x, sh.group) for x in (q2, k2, v2, coords, sqrt_w))
-        acc = HeptPartialSums.apply(q2, k2, v2, coords, sqrt_w, alpha, codes, self.block_size, geo, f32_mfma)
+        acc = HeptPartialSums.apply(q2, k2, v2, coords, sqrt_w, alpha, codes, self.block_size, geo, f32_mfma, tiles)
         if sh is not None and sh.world > 1:
             acc = sum_over_ranks(acc, sh.group)
         from .autograd import HeptCombine

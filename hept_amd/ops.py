@@ -271,21 +271,26 @@ def combine_out(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: int
 @_on_device
 def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int, block_size: int,
                    f32_mfma: bool = False, coords: Optional[torch.Tensor] = None, raw_size: Optional[int] = None):
-    """Backward of block_attn + reduce_tables for f32 tiles: gradient rows gacc (N,H,32) -> dq, dk, dv (N, H*D)
+    """Backward of block_attn + reduce_tables for f32 (or bf16) tiles: gradient rows gacc (N,H,32) -> dq, dk, dv (N, H*D)
     and dcs (N, H, C), the gradient of the scaled coordinates shared by q^ and k^.  ``f32_mfma`` selects the
     native f32 MFMA kernel instead of the split-bf16 products.  With ``coords`` (N, C) a fifth result
     d_sqrt_w (H, C) = sum_n dcs * coords is reduced in the same pass; rows at and after ``raw_size`` get zeros."""
     lib = _lib.load()
-    if qhat.dtype != torch.float32:
-        raise TypeError("the backward pass needs f32 tiles (precision='fp32')")
+    if qhat.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("the backward pass needs f32 or bf16 tiles (rows of precision 'fp32' or 'bf16')")
     h, n, _ = qhat.shape
     tl = qpos.shape[0]
     gacc = _f32c(gacc, "grad of the partial sums")
     dev = qhat.device
-    dq_part = torch.empty(tl, n, h, 32, device=dev, dtype=torch.float32)
-    dkv_part = torch.empty(tl, n, h, 64, device=dev, dtype=torch.float32)
+    rows16 = qhat.dtype == torch.bfloat16
+    part_dtype = torch.bfloat16 if rows16 else torch.float32
+    dq_part = torch.empty(tl, n, h, 32, device=dev, dtype=part_dtype)
+    dkv_part = torch.empty(tl, n, h, 64, device=dev, dtype=part_dtype)
     st = _stream(qhat)
-    fn = lib.hept_block_attn_bwd_f32mfma if f32_mfma else lib.hept_block_attn_bwd
+    if rows16:   # the rows of the bf16 forward: one bf16 MFMA per product, bf16 per-table gradient rows (16-bit training)
+        fn = lib.hept_block_attn_bwd_bf16
+    else:
+        fn = lib.hept_block_attn_bwd_f32mfma if f32_mfma else lib.hept_block_attn_bwd
     _lib.check(fn(qhat.data_ptr(), kvhat.data_ptr(), qpos.data_ptr(), kpos.data_ptr(), gacc.data_ptr(), n, h, head_dim,
                   tl, block_size, dq_part.data_ptr(), dkv_part.data_ptr(), st), "hept_block_attn_bwd")
     dq = torch.empty(n, h * head_dim, device=dev, dtype=torch.float32)
@@ -295,7 +300,7 @@ def block_attn_bwd(qhat, kvhat, qpos, kpos, gacc, head_dim: int, coords_dim: int
     if coords is not None:
         coords = _f32c(coords, "coords")
         dsw = torch.empty(h, coords_dim, device=dev, dtype=torch.float32)
-    _lib.check(lib.hept_bwd_reduce(dq_part.data_ptr(), dkv_part.data_ptr(), tl, n, h, head_dim, coords_dim,
+    _lib.check((lib.hept_bwd_reduce16 if rows16 else lib.hept_bwd_reduce)(dq_part.data_ptr(), dkv_part.data_ptr(), tl, n, h, head_dim, coords_dim,
                                    coords.data_ptr() if coords is not None else None,
                                    n if raw_size is None else int(raw_size), dq.data_ptr(), dk.data_ptr(),
                                    dv.data_ptr(), dcs.data_ptr(), dsw.data_ptr() if dsw is not None else None, st),

@@ -339,6 +339,15 @@ int hept_block_attn_bwd(const float* qhat, const float* kvhat, const int32_t* qp
 int hept_block_attn_bwd_f32mfma(const float* qhat, const float* kvhat, const int32_t* qpos, const int32_t* kpos,
                                 const float* gacc, int N, int H, int D, int Tl, int B, float* dq_part,
                                 float* dkv_part, void* stream);
+/* the same on the rows of the bf16 forward (HEPT_PREC_BF16: qhat (H, N, 64 B), kvhat (H, N, 128 B)), one bf16 MFMA per
+ * product: the opt-in 16-bit training mode.  The per-table gradient rows are bf16 as well: dq_part16 (Tl, N, H, 32) and
+ * dkv_part16 (Tl, N, H, 64) of bf16; hept_bwd_reduce16 sums them (in f32) like hept_bwd_reduce. */
+int hept_block_attn_bwd_bf16(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos,
+                             const float* gacc, int N, int H, int D, int Tl, int B, void* dq_part16,
+                             void* dkv_part16, void* stream);
+int hept_bwd_reduce16(const void* dq_part16, const void* dkv_part16, int Tl, int N, int H, int D, int C,
+                      const float* coords, int raw_size, float* dq, float* dk, float* dv, float* dcs,
+                      float* d_sqrt_w, void* stream);
 /* coords (N, C) + d_sqrt_w (H, C) (both may be NULL): also d_sqrt_w[h,c] = sum_n dcs[n,h,c] * coords[n,c], the
  * gradient that flows on into w_rpe.weight.  Rows at and after raw_size (the src variant's zero-filled padding,
  * raw_size = N otherwise) get zero gradients.  With d_sqrt_w the head of dq_part is overwritten (it serves as

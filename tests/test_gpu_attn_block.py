@@ -228,6 +228,37 @@ def test_training_mode_folds_norm1_and_projections_into_the_row_builder(name, gp
         assert err <= (5e-2 if name == "a1_attn_ckpt6k" else 1e-2), (key, err)
 
 
+def test_block_training_with_bf16_tiles(gpu_device):
+    """The fused training path of the block with the operator's opt-in 16-bit tiles (``attn.train_tiles = "bf16"``:
+    ``hept_prep_hash_fused`` writes bf16 rows, ``block_attn_bwd_bf16_kernel`` differentiates them): every parameter
+    that receives a gradient with fp32 tiles receives one, within 0.2 of its scale (bf16-forward accuracy; the hashes
+    come from unrounded values, so the blocks are the same)."""
+    name = "a2_attn_rand"
+    inp, _ = cases.load_case_attn(name)
+    dev = gpu_device
+
+    def run(tiles):
+        blk = Attn(inp["coords"].shape[1], precision="fp32", h_dim=24, num_heads=8, block_size=inp["block_size"],
+                   n_hashes=3, num_w_per_dist=10, n_layers=4)
+        blk.load_state_dict(inp["params"], strict=True)
+        blk = blk.to(dev).train()
+        blk.dropout.p = 0.0
+        blk.attn.train_tiles = tiles
+        x = inp["x"].to(dev).clone().requires_grad_(True)
+        y = blk(x, {"coords": inp["coords"].to(dev), "combined_shifts": inp["combined_shifts"].to(dev)})
+        (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(dev)).sum().backward()
+        return y.detach().cpu(), x.grad.detach().cpu(), {n_: p.grad.detach().cpu() for n_, p in blk.named_parameters()
+                                                         if p.grad is not None}
+
+    y32, dx32, g32 = run("fp32")
+    y16, dx16, g16 = run("bf16")
+    assert set(g16) == set(g32)
+    assert float((y16 - y32).abs().max()) <= 0.1 * float(y32.abs().max())
+    assert float((dx16 - dx32).abs().max()) <= 0.2 * float(dx32.abs().max())
+    for key, ref in g32.items():
+        assert float((g16[key] - ref).abs().max()) <= 0.2 * (float(ref.abs().max()) + 1e-30), key
+
+
 def test_block_train_kernels_match_torch_autograd(gpu_device):
     """csrc/block_train.hip against torch's own autograd of the same ops on the GPU: the weight gradient of a
     Linear(24 -> O) (O = 192 and 24), LayerNorm(24) backward, and ff(norm2(x)) forward + backward.  Reductions over

@@ -280,3 +280,45 @@ def test_gradients_at_tracking_60k(gpu_device):
     assert _close(q.grad.cpu(), want["q"]) and _close(k.grad.cpu(), want["k"]) and _close(v.grad.cpu(), want["v"])
     assert _close(w.grad.cpu(), want["w_rpe_weight"], rel=1e-3)
     assert _close(ow.grad.cpu(), want["out_weight"]) and _close(ob.grad.cpu(), want["out_bias"])
+
+
+def _train_once(inp, tiles, dev):
+    h, e, t = inp["alpha"].shape
+    d = inp["q"].shape[1] // h
+    m = HEPTAttention(e, h_dim=d, num_heads=h, block_size=inp["block_size"], n_hashes=t, num_w_per_dist=10)
+    m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
+                       "e2lsh.alpha": inp["alpha"]}, strict=True)
+    m = m.to(dev).train()
+    m.train_tiles = tiles
+    w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(dev)
+    with torch.no_grad():
+        w_rpe.weight.copy_(inp["w_rpe_weight"])
+    q, k, v = (inp[x].to(dev).requires_grad_(True) for x in ("q", "k", "v"))
+    out = m(q, k, v, w_rpe=w_rpe, coords=inp["coords"].to(dev), combined_shifts=inp["combined_shifts"].to(dev))
+    out.backward(torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev))
+    return [x.detach().cpu() for x in (out, q.grad, k.grad, v.grad, w_rpe.weight.grad, m.out_linear.weight.grad)]
+
+
+@pytest.mark.parametrize("name", ["g1_rand512", "g6_block100", "g4_pileup", "g3_ckpt6k", "g5_track60k"])
+def test_bf16_training_tiles(name, gpu_device):
+    """``HEPTAttention.train_tiles = "bf16"`` (opt-in): the rows and kernels of the bf16 forward, one bf16 MFMA per
+    product in the backward (``block_attn_bwd_bf16_kernel``), bf16 per-table gradient rows summed in f32.  The hashes
+    come from the unrounded values, so the blocks are those of the fp32 path and the gradients are comparable tensor
+    by tensor: within 0.15 of each tensor's scale on every element (measured: <= 0.07, tests/diag_train16.py -- the
+    error level of a bf16 forward), and bit-identical from run to run.  Ragged blocks (B = 100), B = 256 (68 KB of
+    LDS) and the trained-checkpoint case are among the cases."""
+    inp, _ = cases.load_case(name)
+    ref = _train_once(inp, "fp32", gpu_device)
+    got = _train_once(inp, "bf16", gpu_device)
+    for nm, a, b in zip(("out", "dq", "dk", "dv", "dw_rpe", "dW_out"), got, ref):
+        assert bool(torch.isfinite(a).all()), nm
+        assert _close(a, b, rel=0.15), (nm, float((a - b).abs().max() / b.abs().max()))
+    again = _train_once(inp, "bf16", gpu_device)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+
+
+def test_train_tiles_is_validated(gpu_device):
+    inp, _ = cases.load_case("g1_rand512")
+    with pytest.raises(ValueError, match="train_tiles"):
+        _train_once(inp, "fp16", gpu_device)

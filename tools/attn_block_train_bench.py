@@ -33,8 +33,9 @@ def step():
         p.grad = None
 
 
-for fuse in (True, False, True, False):
+for fuse, tiles in ((True, "fp32"), (False, "fp32"), (True, "fp32"), (False, "fp32"), (True, "bf16")):
     blk.fuse_training = fuse
+    blk.attn.train_tiles = tiles   # "bf16": the opt-in 16-bit kernels in both directions
     for _ in range(5):
         step()
     torch.cuda.synchronize()
@@ -42,6 +43,6 @@ for fuse in (True, False, True, False):
     for _ in range(30):
         step()
     torch.cuda.synchronize()
-    print(f"Attn block train step (fwd+bwd, fp32 tiles, dropout 0.1), norm1 + projections "
+    print(f"Attn block train step (fwd+bwd, {tiles} tiles, dropout 0.1), norm1 + projections "
           f"{'folded into the row builder' if fuse else 'composed (torch modules)'}: "
           f"{(time.perf_counter() - t0) / 30 * 1e3:.3f} ms", flush=True)

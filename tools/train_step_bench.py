@@ -1,4 +1,5 @@
-"""fwd + bwd of HEPTAttention (fp32 tiles, autograd path) at tracking-60k: ms per training step."""
+"""fwd + bwd of HEPTAttention (autograd path) at tracking-60k: ms per training step with fp32 tiles (default) and with
+the opt-in bf16 tiles (``train_tiles = "bf16"``), and how far the bf16 gradients are from the fp32 ones."""
 import os
 import sys
 import time
@@ -27,11 +28,29 @@ def step():
     q.grad = k.grad = v.grad = None
 
 
-for _ in range(5):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(30):
-    step()
-torch.cuda.synchronize()
-print(f"train step (fwd+bwd, fp32 tiles): {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms")
+def grads():
+    w_rpe.weight.grad = m.out_linear.weight.grad = None   # (step() lets the parameter gradients accumulate)
+    out = m(q, k, v, **kw)
+    out.backward(gout)
+    res = [q.grad.clone(), k.grad.clone(), v.grad.clone(), w_rpe.weight.grad.clone(), m.out_linear.weight.grad.clone()]
+    q.grad = k.grad = v.grad = w_rpe.weight.grad = m.out_linear.weight.grad = None
+    return out.detach().clone(), res
+
+
+ref_out, ref = None, None
+for tiles in ("fp32", "bf16"):
+    m.train_tiles = tiles
+    out, gr = grads()
+    if tiles == "fp32":
+        ref_out, ref = out, gr
+    else:   # the 16-bit training mode against the fp32 one: max error relative to each tensor's own scale
+        rel = [float((a - b).abs().max() / b.abs().max()) for a, b in zip([out] + gr, [ref_out] + ref)]
+        print("bf16 tiles vs fp32 tiles, max error / tensor scale: out %.2e  dq %.2e  dk %.2e  dv %.2e  dw_rpe %.2e  dW_out %.2e" % tuple(rel))
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        step()
+    torch.cuda.synchronize()
+    print(f"train step (fwd+bwd, {tiles} tiles): {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms")
