@@ -174,6 +174,38 @@ def test_src_module_forward_backward(name, gpu_device):
     assert float((m.out_linear.weight.grad.cpu() - want).abs().max()) <= 5e-3 * float(want.abs().max())
 
 
+def test_src_training_with_bf16_tiles(gpu_device):
+    """The src variant with ``train_tiles = "bf16"``: padding rows (at and after raw_size) are zero-filled by the row
+    builder in 16-bit rows too and receive zero gradients; real rows are within 0.15 of the reference's stored gradient
+    rows' scale."""
+    inp, fx = cases.load_case_src("s1_src1000")
+    dev = gpu_device
+    h, e, t = inp["alpha"].shape
+    m = HEPTAttention(e, variant="src", h_dim=24, num_heads=h, block_size=inp["block_size"], n_hashes=t,
+                      num_w_per_dist=10)
+    m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
+                       "e2lsh.alpha": inp["alpha"], "e2lsh.beta": torch.zeros(1, t)}, strict=True)
+    m = m.to(dev).train()
+    m.train_tiles = "bf16"
+    w_rpe = torch.nn.Linear(inp["w_rpe_weight"].shape[1], inp["w_rpe_weight"].shape[0]).to(dev)
+    with torch.no_grad():
+        w_rpe.weight.copy_(inp["w_rpe_weight"])
+    raw = inp["raw_size"]
+    _, kw = prepare_input_src(torch.zeros(raw, 1, device=dev), inp["coords_raw"].to(dev),
+                              {"block_size": inp["block_size"], "regions": inp["regions"].to(dev)})
+    q, k, v = (inp[x].to(dev).requires_grad_(True) for x in ("q", "k", "v"))
+    out = m(q, k, v, w_rpe=w_rpe, pe=kw["coords"], **kw)
+    ref = torch.from_numpy(fx["out"])
+    assert float((out.detach().cpu()[:raw] - ref[:raw]).abs().max()) <= 0.1 * float(ref.abs().max())
+    out.backward(torch.randn(out.shape, generator=torch.Generator().manual_seed(11)).to(dev))
+    rows = torch.from_numpy(fx["rows"].astype(np.int64))
+    for got, key in ((q.grad, "ref_dq_rows"), (k.grad, "ref_dk_rows"), (v.grad, "ref_dv_rows")):
+        want = torch.from_numpy(fx[key])
+        assert float((got.cpu()[rows] - want).abs().max()) <= 0.15 * float(want.abs().max()), key
+        if raw < got.shape[0]:
+            assert float(got[raw:].abs().max()) == 0.0
+
+
 def test_src_argument_errors(gpu_device):
     inp, _ = cases.load_case_src("s1_src1000")
     g = _gpu(inp, gpu_device)
