@@ -50,7 +50,7 @@ class Attn(nn.Module):
 
     def _fused_ok(self, x) -> bool:
         return (x.is_cuda and not self.training and not torch.is_grad_enabled() and self.dim_per_head == 24
-                and self.num_heads == 8 and self.attn.n_hashes <= 8 and self.attn.sharding is None)
+                and self.num_heads == 8 and self.attn.sharding is None)
 
     # training / grad-enabled calls: LayerNorm + projections + operator as one autograd node (False: compose modules)
     fuse_training = True

@@ -581,21 +581,34 @@ extern "C" int hept_attn_block_forward(const float* x, const float* coords, cons
         return HEPT_ERR_ARG;
     int rc = hept_check_shape(N, H, D, C, T, B);
     if (rc) return rc;
-    if (D != 24 || T > HEPT_MAX_TABLES) return HEPT_ERR_SHAPE;
+    if (D != 24) return HEPT_ERR_SHAPE;
     const Workspace w = carve(workspace, N, H, C, T, precision);
     if (workspace_bytes < w.bytes) return HEPT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     prof_mark(0, st);
-    // (K == 0: params->w_rpe is sqrt_w (H, C); K > 0: the weight itself, scale computed in the kernel -- see run_begin)
-    rc = hept_prep_hash_fused_rpe(x, p->norm1_w, p->norm1_b, p->eps1, p->w_q, p->w_k, p->w_v, coords, p->w_rpe, K,
-                                  p->alpha, codes, N, N, H, D, C, T, 0, T, precision, w.qhat, w.kvhat, w.qproj, w.kproj,
-                                  w.minmax, stream);
-    if (rc) return rc;
     int32_t* qpos = w.pos;
     int32_t* kpos = w.pos + (size_t)T * H * N;
-    prof_mark(1, st);
-    rc = hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, 0, T, w.sort_ws, qpos, kpos, stream);
-    if (rc) return rc;
+    // any number of tables: the row builder and the sort walk chunks of HEPT_MAX_TABLES, as run_begin does (the rows
+    // are rewritten identically by every chunk)
+    for (int c0 = 0; c0 < T; c0 += HEPT_MAX_TABLES) {
+        const int tc = T - c0 < HEPT_MAX_TABLES ? T - c0 : HEPT_MAX_TABLES;
+        // (K == 0: params->w_rpe is sqrt_w (H, C); K > 0: the weight itself, scale computed in the kernel -- see run_begin)
+        rc = hept_prep_hash_fused_rpe(x, p->norm1_w, p->norm1_b, p->eps1, p->w_q, p->w_k, p->w_v, coords, p->w_rpe, K,
+                                      p->alpha, codes, N, N, H, D, C, T, c0, tc, precision, w.qhat, w.kvhat, w.qproj,
+                                      w.kproj, w.minmax, stream);
+        if (rc) return rc;
+        if (c0 == 0) prof_mark(1, st);
+        int32_t* cq = T <= HEPT_MAX_TABLES ? qpos : w.pos_chunk;
+        int32_t* ck = cq + (size_t)tc * H * N;
+        rc = hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, c0, tc, w.sort_ws, cq, ck, stream);
+        if (rc) return rc;
+        if (cq != qpos) {
+            const size_t off = (size_t)c0 * H * N, bytes = (size_t)tc * H * N * 4;
+            if (hipMemcpyAsync(qpos + off, cq, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(kpos + off, ck, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return HEPT_ERR_LAUNCH;
+        }
+    }
     prof_mark(2, st);
     rc = hept_block_attn(w.qhat, w.kvhat, qpos, kpos, N, H, D, T, B, precision, w.part, stream);
     if (rc) return rc;

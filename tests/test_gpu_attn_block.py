@@ -228,6 +228,32 @@ def test_training_mode_folds_norm1_and_projections_into_the_row_builder(name, gp
         assert err <= (5e-2 if name == "a1_attn_ckpt6k" else 1e-2), (key, err)
 
 
+def test_fused_block_with_more_tables_than_one_chunk(gpu_device):
+    """n_hashes = 10 > HEPT_MAX_TABLES: the fused eval block walks the tables in chunks (``hept_attn_block_forward``),
+    like the operator; against the same block composed of torch modules around the operator."""
+    from hept_amd.synthetic import make_inputs
+
+    dev = gpu_device
+    inp = make_inputs([1500, 700], block_size=128, n_hashes=10, seed=3, cluster_size=8)
+    torch.manual_seed(5)
+    blk = Attn(6, precision="fp32", h_dim=24, num_heads=8, block_size=128, n_hashes=10, num_w_per_dist=10).to(dev).eval()
+    with torch.no_grad():
+        blk.attn.e2lsh.alpha.copy_(inp["alpha"].to(dev))
+        blk.w_q.weight.mul_(0.3)
+        blk.w_k.weight.mul_(0.3)
+    x = torch.randn(inp["q"].shape[0], 24, generator=torch.Generator().manual_seed(2)).to(dev)
+    kwargs = {"coords": inp["coords"].to(dev), "combined_shifts": inp["combined_shifts"].to(dev)}
+    with torch.no_grad():
+        assert blk._fused_ok(x)
+        y_fused = blk(x, kwargs)
+        xn = blk.norm1(x)                                     # the reference's composition, example/transformer.py:154-165
+        aggr = blk.attn(blk.w_q(xn), blk.w_k(xn), blk.w_v(xn), pe=kwargs["coords"], w_rpe=blk.w_rpe, **kwargs)
+        x1 = x + aggr
+        y_ref = x1 + blk.ff(blk.norm2(x1))
+    ok = ((y_fused - y_ref).abs() <= 2e-5 + 1e-4 * y_ref.abs()).all(-1).float().mean().item()
+    assert ok >= 0.97, ok   # (the fused projection sums in another order: a few near-tied keys may swap blocks)
+
+
 def test_block_training_with_bf16_tiles(gpu_device):
     """The fused training path of the block with the operator's opt-in 16-bit tiles (``attn.train_tiles = "bf16"``:
     ``hept_prep_hash_fused`` writes bf16 rows, ``block_attn_bwd_bf16_kernel`` differentiates them): every parameter
