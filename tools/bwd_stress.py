@@ -1,4 +1,5 @@
-"""Randomised shapes of the backward: the split-bf16 kernel against the native f32 MFMA kernel (both HIP), block
+"""Randomised shapes of the backward: the split-bf16 kernel (1e-4) and the 16-bit-tile kernel (0.1 of each tensor's
+scale) against the native f32 MFMA kernel (all HIP), block
 sizes that are not multiples of 32, 1..6 tables, every supported (head_dim, coords_dim) pair, one or several clouds.
 python tools/bwd_stress.py [iters]"""
 import os
@@ -42,5 +43,17 @@ for it in range(iters):
     if not worst <= 1e-4:
         bad += 1
         print(f"MISMATCH it={it} D={d} C={c} B={b} T={t} sizes={sizes}: worst rel {worst:.3e}", flush=True)
+    # the 16-bit training tiles (block_attn_bwd_bf16_kernel on the rows of the bf16 row builder) against the same f32
+    # reference: bf16-level agreement on every tensor, finite everywhere
+    ph16 = ops.prep_hash(gd["q"], gd["k"], gd["v"], gd["coords"], sw, gd["alpha"], gd["combined_shifts"], "bf16")
+    got16 = ops.block_attn_bwd(ph16["qhat"], ph16["kvhat"], qpos, kpos, gacc, d, c, b)
+    worst16 = 0.0
+    for a, r in zip(got16, ref):
+        worst16 = max(worst16, float((a - r).abs().max()) / (float(r.abs().max()) + 1e-30))
+        if not bool(torch.isfinite(a).all()):
+            worst16 = float("inf")
+    if not worst16 <= 0.1:
+        bad += 1
+        print(f"MISMATCH (bf16 tiles) it={it} D={d} C={c} B={b} T={t} sizes={sizes}: worst rel {worst16:.3e}", flush=True)
 print(f"{iters} shapes, {bad} mismatches")
 sys.exit(1 if bad else 0)
