@@ -322,3 +322,24 @@ def test_train_tiles_is_validated(gpu_device):
     inp, _ = cases.load_case("g1_rand512")
     with pytest.raises(ValueError, match="train_tiles"):
         _train_once(inp, "fp16", gpu_device)
+
+
+@pytest.mark.parametrize("heads,d,c", [(4, 16, 4), (16, 24, 6), (5, 20, 5)])
+def test_bf16_training_tiles_with_other_head_counts(heads, d, c, gpu_device):
+    """The 16-bit training tiles off the shipped shapes: the generic row builder writes the bf16 rows, the partial rows
+    are f32 for D != 24 (only D = 24 has the packed form) -- module-level gradients against the fp32 tiles."""
+    from hept_amd.synthetic import make_inputs
+
+    inp = make_inputs([700, 420], block_size=64, n_hashes=2, coords_dim=c, h_dim=d, num_heads=heads, seed=31,
+                      cluster_size=8)
+    inp["block_size"] = 64
+    ref = _train_once(inp, "fp32", gpu_device)
+    got = _train_once(inp, "bf16", gpu_device)
+    # These clouds are tight clusters (spread 0.05): k^ - q^ inside a block is comparable to the bf16 spacing of the
+    # rows, and d q^ = sum_j dS_ij (k^_j - q^_i) is the exact gradient of the ROUNDED forward -- up to a quarter of the
+    # tensor's scale away from the fp32 one (measured 0.19-0.24 for dq whatever the shape, tests/diag_train16_shapes.py;
+    # 0.03-0.06 on unclustered data); out, dv and dW_out stay within 2 %.
+    bound = {"out": 0.05, "dq": 0.4, "dk": 0.25, "dv": 0.05, "dw_rpe": 0.35, "dW_out": 0.05}
+    for nm, a, b in zip(("out", "dq", "dk", "dv", "dw_rpe", "dW_out"), got, ref):
+        assert bool(torch.isfinite(a).all()), nm
+        assert _close(a, b, rel=bound[nm]), (nm, float((a - b).abs().max() / b.abs().max()))
