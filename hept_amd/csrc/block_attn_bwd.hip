@@ -605,7 +605,10 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_bwd_bf16_kernel(
             exp_clamped(x, pe);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                ds[r] = x[r] <= 0.f ? pe[r] * y[r] : 0.f;
+                // (no [X <= 0] mask here: X = -|q_r - k_r|^2 / 2 <= 0 in exact arithmetic, a positive X is f32 round-off
+                //  around zero where the exact logit is negative and the gradient does flow; the f32-tile kernels keep
+                //  the mask to follow torch's clamp on the same rounded number.  2 of ~10 VALU instructions per logit.)
+                ds[r] = pe[r] * y[r];
                 if (!FULL && (kt * 32 + hept_acc_row(r, hh) >= B || !own_ok)) ds[r] = 0.f;
             }
 #pragma unroll
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_bwd_bf16_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (!FULL && (qt * 32 + hept_acc_row(r, hh) >= B || !own_ok)) pr[r] = 0.f;
-                ds[r] = x[r] <= 0.f ? pr[r] * y[r] : 0.f;
+                ds[r] = pr[r] * y[r];
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
