@@ -169,8 +169,17 @@ def cpu_baseline(inp, block_size, min_seconds=10.0):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": inp["n_raw"] / med, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+        "cpu_model": model, "host_threads": cores,
         "sample": f"{len(times)} full forwards of the same {WORKLOAD} cloud (fp32, no_grad, median {med*1e3:.0f} ms; "
                   f"best of 8/32/{cores} threads on a {cores}-thread host)",
     }
@@ -278,7 +287,7 @@ def worker(args) -> int:
         group = dist.group.WORLD
 
     from hept_amd import HEPTAttention, ops
-    from hept_amd.synthetic import workload_inputs
+    from hept_amd.synthetic import WORKLOADS, workload_inputs
 
     def fence():
         torch.cuda.synchronize()
@@ -289,13 +298,21 @@ def worker(args) -> int:
     host_inputs = []   # kept to the end: returning ~150 MB of host pages to the OS takes the CPU ~17 ms, which is
                        # 17 ms of idle device right in front of the next timed region if it happens between two
 
-    def build(tables_per_gpu, precision):
-        n_tables = tables_per_gpu * world
-        inp = workload_inputs(WORKLOAD, seed=0, n_hashes=n_tables)
+    def build(tables_per_gpu, precision, workload=WORKLOAD, block_size=None):
+        """Module + resident inputs of one named workload (hept_amd.synthetic.WORKLOADS = the BASELINE.json configs);
+        ``tables_per_gpu`` None: the workload's own n_hashes; ``block_size``: override (the reference's yaml uses 100)"""
+        over = {}
+        if tables_per_gpu is not None:
+            over["n_hashes"] = tables_per_gpu * world
+        if block_size is not None:
+            over["block_size"] = block_size
+        inp = workload_inputs(workload, seed=0, **over)
         host_inputs.append(inp)
         g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
         c = inp["coords"].shape[1]
-        attn = HEPTAttention(D + c, h_dim=D, num_heads=H, block_size=B, n_hashes=n_tables, num_w_per_dist=10,
+        n_tables = inp["alpha"].shape[2]
+        bs = block_size if block_size is not None else WORKLOADS[workload]["block_size"]
+        attn = HEPTAttention(D + c, h_dim=D, num_heads=H, block_size=bs, n_hashes=n_tables, num_w_per_dist=10,
                              precision=precision, process_group=group)
         attn.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
                               "e2lsh.alpha": inp["alpha"]}, strict=True)
@@ -357,15 +374,19 @@ def worker(args) -> int:
             elapsed = float(tt)
         return elapsed, stage_ms["block_attn"] / max(n_rec, 1) * launches, n_rec
 
-    def roofline(n, c, tables, precision, attn_ms, n_rec):
+    def roofline(n, c, tables, precision, attn_ms, n_rec, block_size=B):
         """HBM roofline of the block-attention kernel: algorithmic bytes per launch / mean launch duration.  The f32
         kernel issues bf16 MFMAs (split products) and is bound by its gathers and scatters as well, so both precisions
-        are priced against HBM; ``mfma_busy_frac`` (PMC, profiles/) is the matrix pipe's share of the kernel's cycles."""
+        are priced against HBM; ``mfma_busy_frac`` (PMC, profiles/) is the matrix pipe's share of the kernel's cycles
+        (counters exist for the headline shape only: other block sizes carry traffic = null)."""
         tile_bytes = 4 if precision == "fp32" else 2
         nbytes = algorithmic_bytes(n, H, D, c, tables, tile_bytes)
         ach = nbytes / (attn_ms * 1e-3) / 1e9
-        traffic, busy, source = pmc_record(precision)
-        flops = algorithmic_flops(n, H, D, c, tables, B)
+        if block_size == B:
+            traffic, busy, source = pmc_record(precision)
+        else:
+            traffic, busy, source = None, None, {"kernel_launched": launched_kernel(precision, block_size), "refused": "no PMC pass for this shape"}
+        flops = algorithmic_flops(n, H, D, c, tables, block_size)
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "frac_of_copy": ach / HBM_COPY_GBS, "copy_peak": HBM_COPY_GBS,
                 "kernel": "block_attn_kernel" if precision != "fp32" else "block_attn_split_kernel",
@@ -428,9 +449,23 @@ def worker(args) -> int:
         if rank == 0 and table:
             print("exchange tuning (us/step): " + ", ".join(f"{t}/{g}: {v * 1e6:.1f}" for (t, g), v in sorted(table.items())),
                   file=sys.stderr)
+        return table
 
+    def tune_record(table):
+        """tune()'s table for the JSON line: us per step of every (transport, head groups) candidate that worked on all
+        ranks, and what RCCL alone would have done (the best RCCL candidate) next to the one-sided transport"""
+        if not table:
+            return {}
+        rec = {"tune_us_per_step": {f"{t}/{g}": round(v * 1e6, 1) for (t, g), v in sorted(table.items())}}
+        rccl = [v for (t, _), v in table.items() if t == "rccl"]
+        p2p = [v for (t, _), v in table.items() if t == "p2p"]
+        rec["rccl_only_us_per_step"] = round(min(rccl) * 1e6, 1) if rccl else None
+        rec["one_sided_us_per_step"] = round(min(p2p) * 1e6, 1) if p2p else None
+        return rec
+
+    head_tune = {}
     if multi:
-        settle(attn, step)
+        head_tune = tune_record(settle(attn, step))
 
     # ------------------------------------------------------------------------------------------------- sub-records
     def sub_records():
@@ -455,11 +490,33 @@ def worker(args) -> int:
                                   "steps": sub_steps, "dtype": "f16 q^,k^ rows / bf16 weights, values",
                                   "block_attn_ms": ams}
                 del attn16, step16
+            if world == 1 and not args.force_dist and args.precision == "bf16":
+                # the other BASELINE.json configurations on this GPU, each in both tile precisions: c1 (example-4k),
+                # c2 (tracking-6k), c5 (pileup batch, block 256) and b100 = the headline cloud at the reference's own
+                # block_size 100 (src/configs/tracking/tracking_trans_hept.yaml:12).  Short clouds are latency-bound:
+                # their roofline fraction says how far a 40 us forward is from streaming its bytes.
+                for key, wl, bs in (("c1", "example-4k", None), ("c2", "tracking-6k", None), ("c5", "pileup-8clouds", None),
+                                    ("b100", WORKLOAD, 100)):
+                    rec = {"workload": wl + (f" at block_size={bs}" if bs else "")}
+                    for prec in ("fp32", "bf16"):
+                        inp_s, attn_s, step_s = build(None, prec, wl, bs)
+                        bsz = bs if bs is not None else WORKLOADS[wl]["block_size"]
+                        ns, cs, ts = inp_s["q"].shape[0], inp_s["coords"].shape[1], inp_s["alpha"].shape[2]
+                        el, ams, nrec = measure(step_s, sub_steps, sub_warm)
+                        roof_s = roofline(ns, cs, ts, prec, ams, nrec, bsz)
+                        rec[prec] = {"ms_per_step": el / sub_steps * 1e3, "value": inp_s["n_raw"] / (el / sub_steps),
+                                     "unit": "points/s", "steps": sub_steps, "n_raw": inp_s["n_raw"], "n_padded": ns,
+                                     "block_size": bsz, "n_hashes": ts,
+                                     "roofline": {k: roof_s[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
+                                                                         "kernel_ms", "algorithmic_bytes")}}
+                        del attn_s, step_s
+                    sub[key] = rec
             if tables_per_gpu != 1:
                 # BASELINE config 4: n_hashes = #GPUs, one table per GPU (at N = 1 a single table)
                 _, attn4, step4 = build(1, args.precision)
+                c4_tune = {}
                 if multi:
-                    settle(attn4, step4)
+                    c4_tune = tune_record(settle(attn4, step4))
                 el, ams, nrec = measure(step4, sub_steps, sub_warm, launches_per_step(attn4))
                 if multi:
                     attn4.sharding.check()
@@ -469,6 +526,7 @@ def worker(args) -> int:
                              "steps": sub_steps, "block_attn_ms": ams}
                 if multi:
                     sub["c4"]["exchange"] = exchange_record(attn4, step4)
+                    sub["c4"]["exchange"].update(c4_tune)
                     attn4.sharding.check()
                 del attn4, step4
         return sub
@@ -487,6 +545,7 @@ def worker(args) -> int:
     if multi:
         attn.sharding.check()   # a one-sided wait that timed out inside the region voids the measurement
         exch = exchange_record(attn, step)
+        exch.update(head_tune)
         attn.sharding.check()
 
     if args.stages and rank == 0:

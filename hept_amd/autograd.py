@@ -104,15 +104,17 @@ class HeptPartialSums(torch.autograd.Function):
 
         n_tables = alpha.shape[2]
         qs, ks = [], []
+        rows = None   # the row buffers of the first chunk: later chunks rewrite the same rows into them
         for c0 in range(0, n_tables, MAX_TABLES):
             tc = min(MAX_TABLES, n_tables - c0)
             if geo is None:
-                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, tiles, t0=c0, tl=tc)
+                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, codes, tiles, t0=c0, tl=tc, rows=rows)
                 qp, kp = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"], t0=c0)
             else:
                 eta, phi, cfac, raw_size = geo
-                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, None, tiles, t0=c0, tl=tc, raw_size=raw_size)
+                ph = ops.prep_hash(q, k, v, coords, sqrt_w, alpha, None, tiles, t0=c0, tl=tc, raw_size=raw_size, rows=rows)
                 qp, kp = ops.sort_tables_src(ph["qproj"], ph["kproj"], eta, phi, cfac, ph["minmax"], t0=c0)
+            rows = (ph["qhat"], ph["kvhat"])
             qs.append(qp)
             ks.append(kp)
         qpos, kpos = (qs[0], ks[0]) if len(qs) == 1 else (torch.cat(qs), torch.cat(ks))
@@ -165,9 +167,12 @@ class HeptPartialSumsFused(torch.autograd.Function):
         n, d = x.shape
         n_tables = alpha.shape[2]
         qs, ks = [], []
+        rows = None   # see HeptPartialSums.forward
         for c0 in range(0, n_tables, MAX_TABLES):
             tc = min(MAX_TABLES, n_tables - c0)
-            ph = ops.prep_hash_fused(x, ln_w, ln_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, tiles, t0=c0, tl=tc)
+            ph = ops.prep_hash_fused(x, ln_w, ln_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, tiles, t0=c0, tl=tc,
+                                     rows=rows)
+            rows = (ph["qhat"], ph["kvhat"])
             qp, kp = ops.sort_tables(ph["qproj"], ph["kproj"], codes, ph["minmax"], t0=c0)
             qs.append(qp)
             ks.append(kp)
@@ -185,12 +190,16 @@ class HeptPartialSumsFused(torch.autograd.Function):
         d, c, block_size, eps = ctx.dims
         dq, dk, dv, dcs, dsw = ops.block_attn_bwd(qhat, kvhat, qpos, kpos, gacc.contiguous(), d, c, block_size,
                                                   f32_mfma=ctx.f32_mfma, coords=coords, raw_size=x.shape[0])
-        dxn = dq @ w_q + dk @ w_k + dv @ w_v                       # d of the three Linear(D, H*D): (N,192) x (192,24)
-        # LayerNorm backward + the normalised rows in one kernel; the three weight gradients dq^T.xn ... are 192 x 24
-        # outputs reduced over all points -- ~140 us each in rocBLAS at 60k points, ~15 us here (csrc/block_train.hip)
-        dx, xn_d, dlw, dlb = ops.ln_bwd(x, dxn, ln_w, ln_b, eps)                       # example/transformer.py:155
-        dwq, dwk, dwv = ops.rows_wgrad(dq, xn_d), ops.rows_wgrad(dk, xn_d), ops.rows_wgrad(dv, xn_d)
         need = ctx.needs_input_grad
+        dx = dlw = dlb = dwq = dwk = dwv = None
+        if any(need[i] for i in (0, 1, 2, 4, 5, 6)):   # (a frozen front end: nothing behind dq, dk, dv is computed)
+            dxn = dq @ w_q + dk @ w_k + dv @ w_v                   # d of the three Linear(D, H*D): (N,192) x (192,24)
+            # LayerNorm backward + the normalised rows in one kernel; the three weight gradients dq^T.xn ... are 192 x 24
+            # outputs reduced over all points -- ~140 us each in rocBLAS at 60k points, ~15 us here (csrc/block_train.hip)
+            dx, xn_d, dlw, dlb = ops.ln_bwd(x, dxn, ln_w, ln_b, eps)                   # example/transformer.py:155
+            dwq = ops.rows_wgrad(dq, xn_d) if need[4] else None
+            dwk = ops.rows_wgrad(dk, xn_d) if need[5] else None
+            dwv = ops.rows_wgrad(dv, xn_d) if need[6] else None
         dcoords = (dcs * sqrt_w[None]).sum(dim=1) if need[7] else None
         return (dx if need[0] else None, dlw if need[1] else None, dlb if need[2] else None, None,
                 dwq if need[4] else None, dwk if need[5] else None, dwv if need[6] else None, dcoords,

@@ -942,6 +942,11 @@ int bwd_reduce_impl(bool rows16, const void* dq_part, const void* dkv_part, int 
     if (d_sqrt_w && !coords) return HEPT_ERR_ARG;
     if (Tl < 1 || N < 1 || H < 1 || D < 1 || C < 1 || D + C > 30 || raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
     if (d_sqrt_w && H * C > 64) return HEPT_ERR_SHAPE;
+    // d_sqrt_w: the per-workgroup partial sums reuse dq_part as scratch (ceil(N/256) * 64 floats): refuse a cloud so
+    // small that they would overrun its Tl * N * H * 32 elements (2 bytes each with bf16 gradient rows)
+    if (d_sqrt_w && (size_t)((N + DSW_POINTS - 1) / DSW_POINTS) * 64 * sizeof(float) >
+                        (size_t)Tl * N * H * 32 * (rows16 ? 2 : 4))
+        return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)N * H * 32;
     if (rows16)

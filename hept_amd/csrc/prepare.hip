@@ -322,10 +322,12 @@ extern "C" int hept_prepare_probe(const void* batch, int batch_is_i64, int n_raw
                                   int H, int32_t* cloud_start, int32_t* pad_start, int32_t* host_record, void* stream) {
     if (!batch || !regions || !cloud_start || !pad_start || !host_record) return HEPT_ERR_ARG;
     if (n_raw < 1 || B < 1 || T < 1 || H < 1) return HEPT_ERR_SHAPE;
+    // the record must be pinned, device-mapped host memory (hipHostMalloc / hipHostRegister): a kernel store to ordinary
+    // pageable memory is a GPU fault on a machine without XNACK, not an error code -- refuse it here
     void* dev_rec = nullptr;   // the device's address of the pinned host record
     if (hipHostGetDevicePointer(&dev_rec, host_record, 0) != hipSuccess || !dev_rec) {
         (void)hipGetLastError();
-        dev_rec = host_record;   // unified addressing: pinned host memory is reachable under its own address
+        return HEPT_ERR_ARG;
     }
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, batch, batch_is_i64, n_raw, B, regions,
                        T, H, cloud_start, pad_start, reinterpret_cast<int*>(dev_rec));

@@ -113,12 +113,16 @@ def rpe_scale_bwd(w_rpe_weight: torch.Tensor, d_sqrt_w: torch.Tensor, n_heads: i
 
 @_on_device
 def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int = 0, tl: Optional[int] = None,
-              raw_size: Optional[int] = None) -> Dict[str, torch.Tensor]:
+              raw_size: Optional[int] = None, rows: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """``rows`` = (qhat, kvhat) of an earlier call with the same inputs and precision: the row buffers are reused
+    (callers that walk more than HEPT_MAX_TABLES tables in chunks rebuild identical rows for every chunk)."""
     lib = _lib.load()
     q, k, v, coords, sqrt_w, alpha = (_f32c(x, nm) for x, nm in
                                       ((q, "query"), (k, "key"), (v, "value"), (coords, "coords"),
                                        (sqrt_w, "sqrt_w"), (alpha, "alpha")))
     n, h, d, c, t = _dims(q, coords, alpha)
+    if tuple(sqrt_w.shape) != (h, c):   # the kernel indexes it as (H, C): a mismatch would be an out-of-bounds read
+        raise ValueError(f"sqrt_w must have shape {(h, c)}, got {tuple(sqrt_w.shape)}")
     if codes is not None:
         if codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n):
             raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}")
@@ -130,8 +134,13 @@ def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int =
     tile = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16,
             PREC_F32_MFMA: torch.float32}[prec]
     dev = q.device
-    qhat = torch.empty(h, n, 32, device=dev, dtype=tile)
-    kvhat = torch.empty(h, n, 64, device=dev, dtype=tile)
+    if rows is not None:
+        qhat, kvhat = rows
+        if qhat.dtype != tile or tuple(qhat.shape) != (h, n, 32) or kvhat.dtype != tile or tuple(kvhat.shape) != (h, n, 64):
+            raise ValueError("rows: buffers of another shape or precision")
+    else:
+        qhat = torch.empty(h, n, 32, device=dev, dtype=tile)
+        kvhat = torch.empty(h, n, 64, device=dev, dtype=tile)
     qproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
     kproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
     minmax = torch.empty(tl, h, _lib.PREP_GRID, 4, device=dev, dtype=torch.float32)
@@ -468,7 +477,8 @@ def forward_partial_src(q, k, v, coords, region_indices, regions_h, raw_size: in
 
 @_on_device
 def prep_hash_fused(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha, codes, precision="fp32",
-                    t0: int = 0, tl: Optional[int] = None, raw_size: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                    t0: int = 0, tl: Optional[int] = None, raw_size: Optional[int] = None,
+                    rows: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """``prep_hash`` with LayerNorm and the q/k/v projections fused in: ``x`` is the (N, D) input of the Attn block
     (reference ``example/transformer.py:155-156``); same outputs as :func:`prep_hash`."""
     lib = _lib.load()
@@ -483,6 +493,8 @@ def prep_hash_fused(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha
         raise ValueError(f"w_q/w_k/w_v must have shape {(h * d, d)}")
     if coords.shape != (n, c) or norm_w.numel() != d or norm_b.numel() != d:
         raise ValueError("coords / norm1 parameters do not match x")
+    if tuple(sqrt_w.shape) != (h, c):
+        raise ValueError(f"sqrt_w must have shape {(h, c)}, got {tuple(sqrt_w.shape)}")
     if codes is not None:
         if codes.dtype != torch.int64 or tuple(codes.shape) != (t, h, n):
             raise ValueError(f"combined_shifts must be an int64 tensor of shape {(t, h, n)}")
@@ -493,8 +505,13 @@ def prep_hash_fused(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha
     dt = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16,
             PREC_F32_MFMA: torch.float32}[prec]
     dev = x.device
-    qhat = torch.empty(h, n, 32, device=dev, dtype=dt)
-    kvhat = torch.empty(h, n, 64, device=dev, dtype=dt)
+    if rows is not None:   # see prep_hash
+        qhat, kvhat = rows
+        if qhat.dtype != dt or tuple(qhat.shape) != (h, n, 32) or kvhat.dtype != dt or tuple(kvhat.shape) != (h, n, 64):
+            raise ValueError("rows: buffers of another shape or precision")
+    else:
+        qhat = torch.empty(h, n, 32, device=dev, dtype=dt)
+        kvhat = torch.empty(h, n, 64, device=dev, dtype=dt)
     qproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
     kproj = torch.empty(tl, h, n, device=dev, dtype=torch.float32)
     minmax = torch.empty(tl, h, _lib.PREP_GRID, 4, device=dev, dtype=torch.float32)
@@ -552,6 +569,15 @@ def attn_block_forward(x, coords, codes, params: Dict[str, torch.Tensor], *, num
         raise ValueError(f"number of points {n} is not a multiple of block_size {block_size}")
     if codes.dtype != torch.int64 or not codes.is_cuda or tuple(codes.shape) != (t, h, n):
         raise ValueError(f"combined_shifts must be an int64 GPU tensor of shape {(t, h, n)}")
+    # the row builder indexes these by the sizes above: a mismatched tensor would be an out-of-bounds device read
+    if keep["alpha"].shape[0] != h or tuple(coords.shape) != (n, c):
+        raise ValueError(f"attn.e2lsh.alpha must be ({h}, D + C, n_hashes) and coords ({n}, {c})")
+    want_rpe = (h * d, (c - 1) * w_per_dist) if w_per_dist > 0 else (h, c)
+    if tuple(keep["w_rpe"].shape) != want_rpe:
+        raise ValueError(f"w_rpe.weight must have shape {want_rpe}, got {tuple(keep['w_rpe'].shape)}")
+    for f_ in ("w_q", "w_k", "w_v"):
+        if tuple(keep[f_].shape) != (h * d, d):
+            raise ValueError(f"{names[f_]} must have shape {(h * d, d)}")
     codes = codes.contiguous()
     prec = precision_code(precision)
     _lib.check(lib.hept_check_shape(n, h, d, c, t, block_size), "hept_check_shape")

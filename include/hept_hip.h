@@ -384,7 +384,9 @@ size_t hept_prepare_workspace_bytes(int n_raw, int n_clouds, int max_cloud, int 
  * regions (T, 2, H), leaves cloud_start / pad_start (257 i32 each, device) for hept_prepare_input and writes a record
  * of 8 i32 into pinned host memory: [n_clouds, n_pad, longest cloud, smallest cloud (< 1: a cloud id without points),
  * overflow (more than 255 clouds: not resolved, use another path), f32 bits of the largest region count of axis 0,
- * of axis 1, 0x600DF00D].  The caller synchronises the stream and reads the record. */
+ * of axis 1, 0x600DF00D].  The caller synchronises the stream and reads the record.
+ * HARD PRECONDITION: host_record is pinned, device-mapped host memory (hipHostMalloc / hipHostRegister); ordinary
+ * pageable memory is refused with HEPT_ERR_ARG (a kernel store to it would be a GPU fault, not an error code). */
 int hept_prepare_probe(const void* batch, int batch_is_i64, int n_raw, int B, const float* regions, int T, int H,
                        int32_t* cloud_start, int32_t* pad_start, int32_t* host_record, void* stream);
 int hept_prepare_input(const float* coords, int C, const int32_t* cloud_start, const int32_t* pad_start,

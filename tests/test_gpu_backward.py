@@ -343,3 +343,48 @@ def test_bf16_training_tiles_with_other_head_counts(heads, d, c, gpu_device):
     for nm, a, b in zip(("out", "dq", "dk", "dv", "dw_rpe", "dW_out"), got, ref):
         assert bool(torch.isfinite(a).all()), nm
         assert _close(a, b, rel=bound[nm]), (nm, float((a - b).abs().max() / b.abs().max()))
+
+
+def _widen_bf16_rows(qhat16, kvhat16):
+    """The f32-tile rows that hold EXACTLY the values of 16-bit rows (csrc/prep_hash.hip layouts): bf16 columns widened,
+    the norm -- f32 bits in the last 4 bytes of a q^ / k^ half -- moved to f32 column 31."""
+    def half(rows16):                                   # (H, N, 32) bf16 -> (H, N, 32) f32
+        wide = rows16.float()
+        norm = rows16[..., 30:32].contiguous().view(torch.int32).view(torch.float32)[..., 0]
+        wide[..., 30] = 0.0
+        wide[..., 31] = norm
+        return wide
+    q32 = half(qhat16)
+    kv32 = torch.cat([half(kvhat16[..., :32]), kvhat16[..., 32:].float()], dim=-1)
+    return q32.contiguous(), kv32.contiguous()
+
+
+@pytest.mark.parametrize("name,bound", [("g1_rand512", 2e-2), ("g6_block100", 2e-2), ("g4_pileup", 2e-2)])
+def test_bf16_backward_kernel_row_by_row(name, bound, gpu_device):
+    """``block_attn_bwd_bf16_kernel`` against the f32 (split-bf16) kernel run on the SAME rounded rows: only the
+    roundings of P, dS and the incoming gradient tile to bf16 and the bf16 per-table gradient rows differ, so every ROW
+    of every gradient must agree to bf16 level -- a wrong sign or a dropped term on a minority of rows (the row / column
+    sums that ride in columns 30 / 31, the removed [X <= 0] mask) cannot hide behind the tensor's largest element.
+    Per-row bound: max error of the row <= ``bound`` x (largest element of that row + 1e-2 of the tensor's largest)."""
+    inp, fx = cases.load_case(name)
+    dev = gpu_device
+    g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
+    h = inp["alpha"].shape[0]
+    d, c, b = 24, inp["coords"].shape[1], inp["block_size"]
+    sw = ops.rpe_scale(g["w_rpe_weight"], h, d, 10)
+    ph16 = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw, g["alpha"], g["combined_shifts"], "bf16")
+    qpos, kpos = ops.sort_tables(ph16["qproj"], ph16["kproj"], g["combined_shifts"], ph16["minmax"])
+    n = g["q"].shape[0]
+    gacc = torch.zeros(n, h, 32, device=dev)
+    gacc[..., :d + 1] = torch.randn(n, h, d + 1, generator=torch.Generator().manual_seed(5)).to(dev)
+    got = ops.block_attn_bwd(ph16["qhat"], ph16["kvhat"], qpos, kpos, gacc, d, c, b)
+    q32, kv32 = _widen_bf16_rows(ph16["qhat"], ph16["kvhat"])
+    ref = ops.block_attn_bwd(q32, kv32, qpos, kpos, gacc, d, c, b)
+    worst = {}
+    for nm, a, r in zip(("dq", "dk", "dv", "dcs"), got, ref):
+        a, r = a.reshape(n, -1), r.reshape(n, -1)
+        assert bool(torch.isfinite(a).all()), nm
+        row_scale = r.abs().amax(dim=1) + 1e-2 * r.abs().max()
+        worst[nm] = float(((a - r).abs().amax(dim=1) / row_scale).max())
+    # (dcs = the coordinate columns of d q^ + d k^: the two halves cancel, so its rows carry ~2x the relative error)
+    assert all(w <= bound * (3.0 if nm == "dcs" else 1.0) for nm, w in worst.items()), worst
