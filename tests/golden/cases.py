@@ -38,6 +38,13 @@ CASES: Dict[str, dict] = {
         cloud_sizes=[6000], block_size=128, n_hashes=3, coords_dim=6, num_regions=150, seed=103,
         ckpt_weights=True, cluster_size=8, qk_scale=0.08, coords_gain=10.0,
     ),
+    # G7: G3's cloud and checkpoint weights with the coordinates LEFT ALONE (N(0,1) per column): the shipped layer-0
+    # scales (sqrt_w up to 5.8e3) then put |q^|^2 at ~1e8, almost every weight underflows and the surviving logits are
+    # differences of 1e8-sized terms -- a finite-output / no-overflow check of every precision, not a tight parity case.
+    "g7_ckpt_rawcoords": dict(
+        cloud_sizes=[6000], block_size=128, n_hashes=3, coords_dim=6, num_regions=150, seed=103,
+        ckpt_weights=True, cluster_size=8, qk_scale=0.08, no_grads=True,
+    ),
     # G4: pileup shape (C=4, E=28, B=256), imbalanced clouds each >= B, batch index in the AND code.
     "g4_pileup": dict(
         cloud_sizes=[300, 900, 520, 1400, 260, 700], block_size=256, n_hashes=3, coords_dim=4,
@@ -133,12 +140,13 @@ def build_inputs(name: str, stored: Optional[Dict[str, np.ndarray]] = None) -> D
         # coordinate to O(coords_gain) for the head that weighs it most (real detector features
         # are normalised per column; the dataset itself is not available here).  |q̂|² then
         # reaches ~1e3, which exercises the cancellation in q·k - ½|q|² - ½|k|².
-        w4 = inp["w_rpe_weight"].reshape(NUM_HEADS, H_DIM, -1, W_PER_DIST)
-        qw = w4.sum(1).clamp(max=50).exp().sum(-1)
-        sqrt_w = torch.sqrt(2 * torch.cat([qw[:, :1], qw], dim=-1))
-        per_dim = cfg["coords_gain"] / sqrt_w.max(dim=0).values
-        inp["coords"] = (inp["coords"] * per_dim).contiguous()
-        inp["coords_raw"] = inp["coords_raw"] * per_dim
+        if cfg.get("coords_gain"):
+            w4 = inp["w_rpe_weight"].reshape(NUM_HEADS, H_DIM, -1, W_PER_DIST)
+            qw = w4.sum(1).clamp(max=50).exp().sum(-1)
+            sqrt_w = torch.sqrt(2 * torch.cat([qw[:, :1], qw], dim=-1))
+            per_dim = cfg["coords_gain"] / sqrt_w.max(dim=0).values
+            inp["coords"] = (inp["coords"] * per_dim).contiguous()
+            inp["coords_raw"] = inp["coords_raw"] * per_dim
     if "code_patch_idx" in stored and len(stored["code_patch_idx"]):
         idx = torch.from_numpy(np.asarray(stored["code_patch_idx"]).astype(np.int64))
         inp["combined_shifts"][tuple(idx.T)] = torch.from_numpy(np.asarray(stored["code_patch_val"]))

@@ -464,3 +464,38 @@ def test_full_size_with_the_references_own_block_size(gpu_device):
         s16 = _staged(g, inp, prec, qpos=st["qpos"], kpos=st["kpos"])["out"].cpu()
         assert _rows_scaled_ok(s16, orc["out"], REL16[prec]) >= 0.96       # as test_tracking_60k_full_size
         assert _rows_scaled_ok(s16, orc["out"], REL16_ALL_ROWS_FULL[prec]) == 1.0
+
+
+# G7: the shipped checkpoint's layer-0 weights on UN-RESCALED N(0,1) coordinates.  sqrt_w reaches
+# 5.8e3, |q^|^2 ~ 1e8: almost every weight underflows, denominators sit at the 1e-20 floor for many rows, and a
+# surviving logit is the difference of 1e8-sized fp32 terms -- the REFERENCE's own output is rounding noise there (an
+# error of +-6 in the logit), so no implementation can be held to it element by element.  What is asserted:
+# every precision stays finite; fp32 with the reference's permutations reproduces the reference where it is
+# well defined -- rows whose reference denominators are all 0 (+1e-20) in every table come out exactly as the
+# reference's (bias only), and the well-conditioned majority of rows agree at the G3 tolerance.
+G7_MIN_ROWS_AT_G3_TOL = 0.7   # measured 0.80 (printed below); see DESIGN.md section 4
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "mixed16"])
+def test_unrescaled_checkpoint_coordinates_stay_finite(precision, gpu_device):
+    inp, fx = cases.load_case("g7_ckpt_rawcoords")
+    g = _gpu(inp, gpu_device)
+    out = _forward(g, inp, precision)
+    assert bool(torch.isfinite(out).all())
+    qp = torch.from_numpy(fx["q_positions"].astype(np.int32)).to(gpu_device)
+    kp = torch.from_numpy(fx["k_positions"].astype(np.int32)).to(gpu_device)
+    st = _staged(g, inp, precision, qp, kp)
+    got, ref = st["out"].cpu(), torch.from_numpy(fx["out"])
+    assert bool(torch.isfinite(got).all())
+    # the output is a convex combination of value rows pushed through out_linear: bounded by the values themselves
+    bound = float(inp["v"].abs().max()) * float(inp["out_weight"].abs().sum(dim=1).max()) + float(inp["out_bias"].abs().max())
+    assert float(got.abs().max()) <= bound * 1.001
+    frac = _rows_ok(got, ref, atol=ATOL["g3_ckpt6k"], rtol=1e-4)
+    print(f"g7 {precision}: rows within the G3 tolerance of the reference: {frac:.4f}; "
+          f"median |err| {float((got - ref).abs().median()):.3e}, max |err| {float((got - ref).abs().max()):.3e}, "
+          f"|ref| mean {float(ref.abs().mean()):.3f}")
+    if precision == "fp32":
+        # rows the reference leaves at 0 / 1e-20 in every table and head: bias only, bit for bit
+        dead = torch.from_numpy(fx["out"] == inp["out_bias"].numpy()[None, :]).all(dim=1)
+        assert torch.equal(got[dead], ref[dead])
+        assert frac >= G7_MIN_ROWS_AT_G3_TOL

@@ -12,6 +12,9 @@ import cases
 import hept_oracle as ho
 
 FULL_CASES = ["g1_rand512", "g2_example4k", "g3_ckpt6k", "g4_pileup", "g6_block100"]
+# G7 (checkpoint weights on un-rescaled coordinates, no gradients stored): rebuilt exactly and bit-exact with the
+# reference's permutations like the others; the tie-aware end-to-end test does not apply (its logits are rounding noise)
+RAW_CASES = ["g7_ckpt_rawcoords"]
 
 
 def _oracle(inp, **kw):
@@ -21,7 +24,7 @@ def _oracle(inp, **kw):
     )
 
 
-@pytest.mark.parametrize("name", FULL_CASES + ["g5_track60k"])
+@pytest.mark.parametrize("name", FULL_CASES + RAW_CASES + ["g5_track60k"])
 def test_inputs_rebuild_exactly(name):
     inp, fx = cases.load_case(name)
     got = cases.input_checksums(inp)
@@ -29,7 +32,7 @@ def test_inputs_rebuild_exactly(name):
     assert float(inp["combined_shifts"].double().sum()) == float(fx["ref_codes_sum"]) or "random_codes" in cases.CASES[name]
 
 
-@pytest.mark.parametrize("name", FULL_CASES)
+@pytest.mark.parametrize("name", FULL_CASES + RAW_CASES)
 def test_oracle_bit_exact_with_reference_permutations(name):
     inp, fx = cases.load_case(name)
     qp = torch.from_numpy(fx["q_positions"].astype(np.int64))
