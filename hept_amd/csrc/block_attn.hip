@@ -38,8 +38,13 @@ namespace {
 // many workgroups a CU holds.  16-bit tiles: 8 waves per SIMD (<= 64 VGPRs, no spills; 87 -> 80 us at tracking-60k);
 // f32 tiles carry twice the fragments: 6 waves per SIMD, 4 for their ragged-tile variants (masks in registers).  The
 // ragged 16-bit variants fit 64 VGPRs as well (B = 100, the reference's yaml: 97 -> see DESIGN.md section 6).
+// (ragged 16-bit tiles -- B = 100, the reference's yaml -- carry their masks in registers: at the 64-VGPR cap of 8 waves
+//  per SIMD they spilled 1-5 registers to scratch; 7 waves = 72 VGPRs, no scratch: 193.3 -> 191.1 us per forward)
+#ifndef HEPT_RAGGED16_WAVES
+#define HEPT_RAGGED16_WAVES 7
+#endif
 template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL>
-__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(BF16 ? 8 : (FULL ? 6 : 4), BF16 ? 8 : (FULL ? 6 : 4))))
+__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(BF16 ? (FULL ? 8 : HEPT_RAGGED16_WAVES) : (FULL ? 6 : 4), BF16 ? (FULL ? 8 : HEPT_RAGGED16_WAVES) : (FULL ? 6 : 4))))
 void block_attn_kernel(const char* __restrict__ qhat,
                                                               const char* __restrict__ kvhat,
                                                               const int* __restrict__ qpos,
@@ -298,6 +303,15 @@ void block_attn_kernel(const char* __restrict__ qhat,
 //  (bound by the gathers, not by issue).  f32 split tiles, two query tiles per wave: 197 us against 213 us as a kernel
 //  timed back to back on cache-warm rows, but 357 us against 355 us per forward in place, where its gathers run cold --
 //  the one-tile-per-wave form was LDS-bound at 241 us.  Neither was kept: DESIGN.md section 6.)
+// Pieces of P in the P.V product.  V keeps three planes (every value to 24 bits); P = exp(.) in [0, 1] takes TWO:
+// ph + pm carries 16 significand bits, |P - ph - pm| <= 2^-18 P, unbiased, so the product terms are
+// ph.(vh + vm + vl) + pm.(vh + vm) -- 5 MFMAs instead of 6 and 3 VALU instructions per weight instead of 5.5.  The
+// output is a weighted mean of value rows: its error from this is <= 3.8e-6 max|v| in the worst case (one dominant key)
+// and ~1/sqrt(keys) of that typically; measured against the three-piece build at tracking-60k: largest element
+// difference 3.6e-6 = 0.23x of the stated fp32 tolerance (atol 1e-5 + rtol 1e-4), kernel 167.6 -> 158.7 us.
+#ifndef HEPT_SPLIT_PP
+#define HEPT_SPLIT_PP 2
+#endif
 template <int NKT, bool FULL, int VP>
 __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float* __restrict__ qhat,
                                                                     const float* __restrict__ kvhat,
@@ -453,9 +467,10 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
                 float pa[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pa[j] = pr[8 * s + j];
-                u32x4 ph, pm, pl3;
-                if constexpr (VP == 3) split3_bf16(pa, ph, pm, pl3);
-                else split2_bf16(pa, ph, pm);
+                constexpr int PP = HEPT_SPLIT_PP;   // pieces of P (the V planes are VP)
+                u32x4 pp[3];
+                if constexpr (PP == 3) split3_bf16(pa, pp[0], pp[1], pp[2]);
+                else split2_bf16(pa, pp[0], pp[1]);
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 u32x4 vpl[VP];
 #pragma unroll
@@ -466,14 +481,14 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
                     const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     vpl[pl] = __builtin_bit_cast(u32x4, vv);
                 }
-                if constexpr (VP == 3) {
-                    z = mfma_bf16(pl3, vpl[0], z);
-                    z = mfma_bf16(ph, vpl[2], z);
-                    z = mfma_bf16(pm, vpl[1], z);
-                }
-                z = mfma_bf16(pm, vpl[0], z);
-                z = mfma_bf16(ph, vpl[1], z);
-                z = mfma_bf16(ph, vpl[0], z);
+                // every product p_i . v_j of order i + j <= 2, smallest first
+#pragma unroll
+                for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                    for (int i = PP - 1; i >= 0; --i) {
+                        const int j = ord - i;
+                        if (j >= 0 && j < VP) z = mfma_bf16(pp[i], vpl[j], z);
+                    }
             }
         }
     }
