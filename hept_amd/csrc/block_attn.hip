@@ -309,6 +309,15 @@ void block_attn_kernel(const char* __restrict__ qhat,
 // output is a weighted mean of value rows: its error from this is <= 3.8e-6 max|v| in the worst case (one dominant key)
 // and ~1/sqrt(keys) of that typically; measured against the three-piece build at tracking-60k: largest element
 // difference 3.6e-6 = 0.23x of the stated fp32 tolerance (atol 1e-5 + rtol 1e-4), kernel 167.6 -> 158.7 us.
+// Keys staged per chunk.  Every chunk costs two workgroup barriers, and between them a wave alternates a staging stretch
+// (VALU: the splits) and a compute stretch (MFMA + the P splits); at B = 256 (8 waves, 2 workgroups per CU) the two
+// waves a workgroup keeps on a SIMD move in lockstep, so half of the SIMD's chances to run one wave's MFMAs beside
+// another's VALU are gone -- longer stretches (128 keys: 2 chunks instead of 4) give the other workgroup's waves more
+// room to fall out of step.  The planes are then 48 KB per workgroup, which 2 workgroups per CU can afford.
+#ifndef HEPT_SPLIT_CK8
+#define HEPT_SPLIT_CK8 128
+#endif
+constexpr int split_ck(int nkt) { return nkt == 8 ? HEPT_SPLIT_CK8 : (nkt >= 2 ? 64 : 32); }
 #ifndef HEPT_SPLIT_PP
 #define HEPT_SPLIT_PP 2
 #endif
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     constexpr int NT = 64 * NKT;
     constexpr int KEYS = 32 * NKT;
     constexpr int PROW = 64;                    // bytes of one 32-column bf16 plane row
-    constexpr int CK = NKT >= 2 ? 64 : 32;      // keys staged at a time: 24 KB of planes whatever the block size
+    constexpr int CK = split_ck(NKT);           // keys staged at a time: 24 KB of planes (48 KB at B = 256)
     constexpr int NCH = (KEYS + CK - 1) / CK;   // chunks
     constexpr int IPT = (CK * 8 + NT - 1) / NT; // 8-column items per thread and chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -425,34 +434,39 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
         // Q^.K^ of BOTH tiles of the chunk first: the second tile's MFMA chain has no dependence on the first tile's exp /
         // split VALU work, so the two can share the SIMD (one wave's instruction stream is in order: a P tile computed
         // right behind its own logits leaves the matrix pipe idle for the whole exp / split stretch)
-        f32x16 xs[CK / 32];
+        constexpr int TPC = CK / 32, GRP = TPC < 2 ? TPC : 2;   // tiles per chunk; tiles whose logits are formed together
 #pragma unroll
-        for (int kl = 0; kl < CK / 32; ++kl) {
-            const int kt = ch * (CK / 32) + kl;
+        for (int g0 = 0; g0 < TPC; g0 += GRP) {
+        f32x16 xs[GRP];
+#pragma unroll
+        for (int kg = 0; kg < GRP; ++kg) {
+            const int kl = g0 + kg;
+            const int kt = ch * TPC + kl;
             if (kt >= NKT) break;
             if (!FULL && kt * 32 >= B) break;  // uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xs[kl][r] = 0.f;
+            for (int r = 0; r < 16; ++r) xs[kg][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int off = kl * 32 * PROW + krow[s];
                 const u32x4 kh = *reinterpret_cast<const u32x4*>(k_s + off);
                 const u32x4 km = *reinterpret_cast<const u32x4*>(k_s + CK * PROW + off);
                 const u32x4 kl3 = *reinterpret_cast<const u32x4*>(k_s + 2 * CK * PROW + off);
-                xs[kl] = mfma_bf16(kl3, qh[s], xs[kl]);
-                xs[kl] = mfma_bf16(kh, ql[s], xs[kl]);
-                xs[kl] = mfma_bf16(km, qm[s], xs[kl]);
-                xs[kl] = mfma_bf16(km, qh[s], xs[kl]);
-                xs[kl] = mfma_bf16(kh, qm[s], xs[kl]);
-                xs[kl] = mfma_bf16(kh, qh[s], xs[kl]);
+                xs[kg] = mfma_bf16(kl3, qh[s], xs[kg]);
+                xs[kg] = mfma_bf16(kh, ql[s], xs[kg]);
+                xs[kg] = mfma_bf16(km, qm[s], xs[kg]);
+                xs[kg] = mfma_bf16(km, qh[s], xs[kg]);
+                xs[kg] = mfma_bf16(kh, qm[s], xs[kg]);
+                xs[kg] = mfma_bf16(kh, qh[s], xs[kg]);
             }
         }
 #pragma unroll
-        for (int kl = 0; kl < CK / 32; ++kl) {
-            const int kt = ch * (CK / 32) + kl;
+        for (int kg = 0; kg < GRP; ++kg) {
+            const int kl = g0 + kg;
+            const int kt = ch * TPC + kl;
             if (kt >= NKT) break;
             if (!FULL && kt * 32 >= B) break;  // uniform
-            const f32x16 x = xs[kl];
+            const f32x16 x = xs[kg];
 
             float pr[16];
             exp_clamped(x, pr);
@@ -491,6 +505,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
                     }
             }
         }
+        }   // tile groups of the chunk
     }
 
     // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
@@ -520,7 +535,7 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
                       const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
 #define HEPT_SPLIT_CASE(K)                                                                                       \
     case K: {                                                                                                    \
-        constexpr size_t lds = (size_t)(3 + VP) * (K >= 2 ? 64 : 32) * 64;                                       \
+        constexpr size_t lds = (size_t)(3 + VP) * split_ck(K) * 64;                                              \
         if (lds > 65536) {                                                                                       \
             static LdsRaised raised;                                                                             \
             if (hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_split_kernel<K, FULL, VP>), lds))   \
