@@ -112,12 +112,19 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     // W is (D, H*D) row-major: read it coalesced and transpose while writing LDS (a transposed gather from global
     // cost 6.6 us per launch).  Slab of head h: [d][c] at pitch WT_PITCH, only the D x D entries that are read are
     // written (lanes >= D read column D-1: their MFMA output columns are never stored); the pad head of an odd H is 0.
-    for (int i = tid; i < D * HD; i += CMB_THREADS) {
-        const int c = i / HD, h = (i % HD) / D, d = i % D;
-        wt_s[(h * 28 + d) * WT_PITCH + c] = W[i];
+    // Packed rows (16-bit tiles): the weight column of a lane comes straight from W -- 24 consecutive floats of row
+    // `lc`, six 16-B loads per head pair that hit L1 / L2 (W is 18 KB) -- so the launch has no staging prologue and no
+    // barrier in front of its first tile: 27.3 -> 25.6 us at tracking-60k.  f32 rows keep the LDS slab: their waves
+    // already carry 21 row loads per head pair, and six more cost 4.5 us (54.7 against 50.2).
+    constexpr bool WDIRECT = P16 && DT == 24;
+    if constexpr (!WDIRECT) {
+        for (int i = tid; i < D * HD; i += CMB_THREADS) {
+            const int c = i / HD, h = (i % HD) / D, d = i % D;
+            wt_s[(h * 28 + d) * WT_PITCH + c] = W[i];
+        }
+        if (HP > H)
+            for (int i = tid; i < 28 * WT_PITCH; i += CMB_THREADS) wt_s[H * 28 * WT_PITCH + i] = 0.f;
     }
-    if (HP > H)
-        for (int i = tid; i < 28 * WT_PITCH; i += CMB_THREADS) wt_s[H * 28 * WT_PITCH + i] = 0.f;
     const int lc = li < D ? li : D - 1;
     const float bia = (li < D && bias) ? bias[li] : 0.f;
     float* ffn_s = wt_s + HP * 28 * WT_PITCH;                     // [w1 | w2 | b1 | b2 | ln_w | ln_b]
@@ -196,7 +203,19 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             }
             // this head's weight column, requested before the rows are unpacked (LDS latency hides under the VALU work)
             float wv[28];
-            {
+            if constexpr (WDIRECT) {
+                const float* wrow = W + (size_t)lc * HD + (size_t)(hp + hh < H ? hp + hh : 0) * D;
+#pragma unroll
+                for (int u4 = 0; u4 < 7; ++u4)
+                    if (4 * u4 < D) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + 4 * u4);
+                        wv[4 * u4] = w4[0]; wv[4 * u4 + 1] = w4[1]; wv[4 * u4 + 2] = w4[2]; wv[4 * u4 + 3] = w4[3];
+                    }
+                if (hp + hh >= H) {   // the pad head of an odd H
+#pragma unroll
+                    for (int u = 0; u < 28; ++u) wv[u] = 0.f;
+                }
+            } else {
                 const float* wrow = wt_s + (size_t)(hp + hh) * 28 * WT_PITCH + lc;
 #pragma unroll
                 for (int u = 0; u < 28; ++u)
