@@ -96,14 +96,26 @@ constexpr int FFN_D = 24, FFN_PITCH = 25, FFN_WFLOATS = 2 * FFN_D * FFN_D + 4 * 
 // gathered output in EVERY rank's exchange buffer: the 32 x D tile passes through LDS so that each lane stores 16-B
 // pieces of contiguous rows (a 4-byte scatter per accumulator register would put 4-byte writes on the xGMI links);
 // the last workgroup raises this rank's output flag everywhere.
-template <bool P16, bool FFN = false, int DT = 0, bool SPLIT = false, bool PUSH = false>
+// STG (packed rows, D = 24, plain (Tl, N, H, row) layout, even H): the rows reach the lanes THROUGH LDS.  A lane that
+// loads "its" row touches 64 different lines per wave instruction, 16 B of each (the texture addresser works through them
+// one by one, and the L1 has to hold every line until its fourth piece is asked for); here a wave instruction is a
+// direct-to-LDS load (global_load_lds_dwordx4) of 8 points x 128 B -- the two rows of a head pair, whole lines -- into a
+// wave-private image [table][point][8 pieces], no registers, and lane (point, half) then reads its 4 pieces with
+// ds_read_b128 (pieces XOR-permuted by the point on the SOURCE side, so that 16 lanes hit 16 bank groups).  The next
+// head pair's loads are issued as soon as the current rows are in registers: the prefetch lives in LDS (12 KB per
+// wave), not in a second register set.
+constexpr int STG_TABLE_BYTES = 32 * 8 * 16;             // one table, one head pair, 32 points
+constexpr int STG_WAVE_BYTES = 3 * STG_TABLE_BYTES;      // up to three tables in flight
+template <bool P16, bool FFN = false, int DT = 0, bool SPLIT = false, bool PUSH = false, bool STG = false>
 __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
                                                                   int H, int D_rt, int n0, int n_count,
                                                                   const float* __restrict__ W,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out, int HG, size_t gstride,
-                                                                  FfnIn ffn = FfnIn{}, P2pDev px = P2pDev{}) {
+                                                                  FfnIn ffn = FfnIn{}, P2pDev px = P2pDev{},
+                                                                  int stg_off = 0) {
     static_assert(!PUSH || (DT == 24 && !FFN), "the pushing epilogue is built for D = 24 rows");
+    static_assert(!STG || (P16 && DT == 24 && !PUSH), "staged rows: packed rows of the plain layout");
     constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
     extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H (even-padded)][28 (d)][32 (c, zero padded)]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
@@ -156,10 +168,44 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     };
     const int tile_first = SPLIT ? blockIdx.x : blockIdx.x * CMB_WAVES + w;
     RawRow<P16> cur[3], nxt[3];  // up to 3 tables in flight; more tables are loaded in place below
-    if (tile_first < n_tiles && hp0 < HP) {
+    // STG: this wave's LDS image and the two halves of the hand-over (see the comment above the kernel)
+    char* const stg = reinterpret_cast<char*>(wt_s) + stg_off + w * STG_WAVE_BYTES;
+    auto stg_request = [&](int tile, int hp) {   // rows of head pair (hp, hp + 1), tables 0 .. tpre - 1: global -> LDS
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-            if (t < tpre) cur[t].load(row_at(tile_first, hp0) + (size_t)t * tstride);
+            if (t < tpre) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int slot = j * 64 + lane, pt = slot >> 3, sub = (slot & 7) ^ ((pt >> 1) & 7);
+                    const int i2 = tile * 32 + pt;
+                    const int n = n0 + (i2 < n_count ? i2 : n_count - 1);
+                    const char* g = reinterpret_cast<const char*>(part + (size_t)t * tstride) +
+                                    ((size_t)n * H + hp) * 64 + sub * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(stg + t * STG_TABLE_BYTES + j * 1024),
+                                                     16, 0, 0);
+                }
+            }
+    };
+    auto stg_take = [&]() {   // LDS -> this lane's rows (cur[t]); afterwards the image may be overwritten
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < tpre) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cur[t].q[q] = *reinterpret_cast<const u32x4*>(stg + t * STG_TABLE_BYTES +
+                                                                   (li * 8 + ((hh * 4 + q) ^ ((li >> 1) & 7))) * 16);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if (tile_first < n_tiles && hp0 < HP) {
+        if constexpr (STG) stg_request(tile_first, hp0);
+        else {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (t < tpre) cur[t].load(row_at(tile_first, hp0) + (size_t)t * tstride);
+        }
     }
     if constexpr (FFN) {
         for (int i = tid; i < FFN_D * FFN_D; i += CMB_THREADS) {
@@ -195,7 +241,11 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             // 21 x 16 B per head pair and lane: holding two sets put the kernel at 256 VGPRs + 120 AGPRs, ONE wave per
             // SIMD and therefore two rounds of workgroups; there the current set is summed first and the next set is
             // loaded into the same registers, still ahead of the 24 MFMAs (see below)
-            if constexpr (P16) {
+            if constexpr (STG) {
+                stg_take();
+                if (more) stg_request(tile, hp + hstep);
+                else if (wrap) stg_request(tile_next, hp0);
+            } else if constexpr (P16) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
                     if ((more || wrap) && t < tpre)
@@ -243,7 +293,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
 #pragma unroll
             for (int u = 0; u < 28; ++u)
                 if (u < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[u] * inv, wv[u], acc, 0, 0, 0);
-            if constexpr (P16) {
+            if constexpr (P16 && !STG) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) cur[t] = nxt[t];
             }
@@ -757,36 +807,57 @@ extern "C" int hept_reduce_heads(const float* part, int part_precision, int Tl, 
 #endif
 constexpr int CMB_SPLIT_BELOW = HEPT_CMB_SPLIT_BELOW;  // tiles; 1024 tiles = one wave per SIMD on 256 CUs
 
-template <bool P16, bool FFN, int DT, bool PUSH = false>
-int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int D, int n0, int n_count, const float* W,
-                   const float* b, float* out, const FfnIn& ffn, int HG = 0, size_t gstride = 0,
-                   const P2pDev& px = P2pDev{}) {
-    if (HG <= 0) HG = H;
+// HEPT_NO_STAGED_COMBINE=1: packed rows are loaded lane by lane as in round 3 (A/B measurements; read once)
+inline bool staged_combine_off() {
+    static const bool off = [] { const char* e = getenv("HEPT_NO_STAGED_COMBINE"); return e && *e && *e != '0'; }();
+    return off;
+}
+
+template <bool P16, bool FFN, int DT, bool PUSH, bool STG>
+int combine_launch_impl(hipStream_t st, const float* part, int Tl, int N, int H, int D, int n0, int n_count,
+                        const float* W, const float* b, float* out, const FfnIn& ffn, int HG, size_t gstride,
+                        const P2pDev& px) {
     const int n_tiles = (n_count + 31) / 32;
     const bool split = n_tiles < CMB_SPLIT_BELOW;
-    const size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * WT_PITCH +
-                                        (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0) +
-                                        (split ? (CMB_WAVES - 1) * 16 * 64 : 0) +
-                                        (PUSH ? (split ? 1 : CMB_WAVES) * 32 * 24 : 0));
-    if (lds > 65536) {   // many heads: the weight slab alone is 3.6 KiB per head
+    size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * WT_PITCH +
+                                  (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0) +
+                                  (split ? (CMB_WAVES - 1) * 16 * 64 : 0) +
+                                  (PUSH ? (split ? 1 : CMB_WAVES) * 32 * 24 : 0));
+    lds = (lds + 15) & ~(size_t)15;
+    const int stg_off = (int)lds;
+    if (STG) lds += (size_t)CMB_WAVES * STG_WAVE_BYTES;
+    if (lds > 65536) {   // many heads (the weight slab alone is 3.6 KiB per head), or the staged rows' images
         static LdsRaised raised_split, raised_flat;
         if (hept_raise_lds(split ? raised_split : raised_flat,
-                           split ? reinterpret_cast<const void*>(&combine_out_kernel<P16, FFN, DT, true, PUSH>)
-                                 : reinterpret_cast<const void*>(&combine_out_kernel<P16, FFN, DT, false, PUSH>), lds))
+                           split ? reinterpret_cast<const void*>(&combine_out_kernel<P16, FFN, DT, true, PUSH, STG>)
+                                 : reinterpret_cast<const void*>(&combine_out_kernel<P16, FFN, DT, false, PUSH, STG>), lds))
             return HEPT_ERR_LAUNCH;
     }
     if (split) {
-        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true, PUSH>), dim3(n_tiles < HEPT_CMB_SPLIT_GRID ? n_tiles : HEPT_CMB_SPLIT_GRID), dim3(CMB_THREADS), lds, st, part,
-                           Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px);
+        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true, PUSH, STG>), dim3(n_tiles < HEPT_CMB_SPLIT_GRID ? n_tiles : HEPT_CMB_SPLIT_GRID), dim3(CMB_THREADS), lds, st, part,
+                           Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px, stg_off);
     } else {
         const int wgs = (n_tiles + CMB_WAVES - 1) / CMB_WAVES;
 #ifndef HEPT_CMB_MAX_WGS
 #define HEPT_CMB_MAX_WGS 2048
 #endif
-        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, false, PUSH>), dim3(wgs < HEPT_CMB_MAX_WGS ? wgs : HEPT_CMB_MAX_WGS), dim3(CMB_THREADS),
-                           lds, st, part, Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px);
+        hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, false, PUSH, STG>), dim3(wgs < HEPT_CMB_MAX_WGS ? wgs : HEPT_CMB_MAX_WGS), dim3(CMB_THREADS),
+                           lds, st, part, Tl, N, H, D, n0, n_count, W, b, out, HG, gstride, ffn, px, stg_off);
     }
     return hept_launch_status();
+}
+
+template <bool P16, bool FFN, int DT, bool PUSH = false>
+int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int D, int n0, int n_count, const float* W,
+                   const float* b, float* out, const FfnIn& ffn, int HG = 0, size_t gstride = 0,
+                   const P2pDev& px = P2pDev{}) {
+    if (HG <= 0) HG = H;
+    // staged rows: packed rows of the plain layout (no head groups), even head count
+    if constexpr (P16 && DT == 24 && !PUSH) {
+        if (HG == H && H % 2 == 0 && !staged_combine_off())
+            return combine_launch_impl<P16, FFN, DT, PUSH, true>(st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn, HG, gstride, px);
+    }
+    return combine_launch_impl<P16, FFN, DT, PUSH, false>(st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn, HG, gstride, px);
 }
 
 extern "C" int hept_combine_groups(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
