@@ -104,8 +104,14 @@ constexpr int FFN_D = 24, FFN_PITCH = 25, FFN_WFLOATS = 2 * FFN_D * FFN_D + 4 * 
 // ds_read_b128 (pieces XOR-permuted by the point on the SOURCE side, so that 16 lanes hit 16 bank groups).  The next
 // head pair's loads are issued as soon as the current rows are in registers: the prefetch lives in LDS (12 KB per
 // wave), not in a second register set.
-constexpr int STG_TABLE_BYTES = 32 * 8 * 16;             // one table, one head pair, 32 points
+constexpr int STG_TABLE_BYTES = 32 * 8 * 16;             // packed rows: one table, one head pair, 32 points
 constexpr int STG_WAVE_BYTES = 3 * STG_TABLE_BYTES;      // up to three tables in flight
+// f32 rows (128 B): the image of ONE (table, head pair) unit is 32 points x 256 B = 8 KB, so the tables of a head pair
+// go through a two-deep ring of such images one after the other: unit u + 2 is requested as soon as unit u's rows are
+// in registers, the wait in front of unit u leaves the 8 loads of unit u + 1 in flight (s_waitcnt vmcnt(8)), and the
+// weight column comes straight from W (no slab: 64 KB of images per workgroup, two workgroups per CU).
+constexpr int STG32_UNIT_BYTES = 32 * 16 * 16;
+constexpr int STG32_WAVE_BYTES = 2 * STG32_UNIT_BYTES;
 template <bool P16, bool FFN = false, int DT = 0, bool SPLIT = false, bool PUSH = false, bool STG = false>
 __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* __restrict__ part, int Tl, int N,
                                                                   int H, int D_rt, int n0, int n_count,
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                                                                   FfnIn ffn = FfnIn{}, P2pDev px = P2pDev{},
                                                                   int stg_off = 0) {
     static_assert(!PUSH || (DT == 24 && !FFN), "the pushing epilogue is built for D = 24 rows");
-    static_assert(!STG || (P16 && DT == 24 && !PUSH), "staged rows: packed rows of the plain layout");
+    static_assert(!STG || (DT == 24 && !PUSH), "staged rows: D = 24 rows of the plain layout");
     constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
     extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H (even-padded)][28 (d)][32 (c, zero padded)]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     // `lc`, six 16-B loads per head pair that hit L1 / L2 (W is 18 KB) -- so the launch has no staging prologue and no
     // barrier in front of its first tile: 27.3 -> 25.6 us at tracking-60k.  f32 rows keep the LDS slab: their waves
     // already carry 21 row loads per head pair, and six more cost 4.5 us (54.7 against 50.2).
-    constexpr bool WDIRECT = P16 && DT == 24;
+    constexpr bool WDIRECT = (P16 || STG) && DT == 24;
     if constexpr (!WDIRECT) {
         for (int i = tid; i < D * HD; i += CMB_THREADS) {
             const int c = i / HD, h = (i % HD) / D, d = i % D;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     }
     const int lc = li < D ? li : D - 1;
     const float bia = (li < D && bias) ? bias[li] : 0.f;
-    float* ffn_s = wt_s + HP * 28 * WT_PITCH;                     // [w1 | w2 | b1 | b2 | ln_w | ln_b]
+    float* ffn_s = wt_s + (WDIRECT ? 0 : HP * 28 * WT_PITCH);     // [w1 | w2 | b1 | b2 | ln_w | ln_b] (no slab with WDIRECT)
     float* stage_s = ffn_s + FFN_WFLOATS + w * 32 * FFN_PITCH;  // this wave's 32 x D tile
     float* stage_s_end = ffn_s + (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0);
     if constexpr (PUSH) {
@@ -169,7 +175,33 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     const int tile_first = SPLIT ? blockIdx.x : blockIdx.x * CMB_WAVES + w;
     RawRow<P16> cur[3], nxt[3];  // up to 3 tables in flight; more tables are loaded in place below
     // STG: this wave's LDS image and the two halves of the hand-over (see the comment above the kernel)
-    char* const stg = reinterpret_cast<char*>(wt_s) + stg_off + w * STG_WAVE_BYTES;
+    char* const stg = reinterpret_cast<char*>(wt_s) + stg_off + w * (P16 ? STG_WAVE_BYTES : STG32_WAVE_BYTES);
+    // ---- f32 rows: the unit ring (see STG32_UNIT_BYTES)
+    struct Unit { int tile, hp, t; bool ok; };
+    const int tile_step = SPLIT ? (int)gridDim.x : (int)gridDim.x * CMB_WAVES;
+    auto unit_next = [&](Unit u) {
+        if (!u.ok) return u;
+        if (u.t + 1 < Tl) { ++u.t; return u; }
+        u.t = 0;
+        if (u.hp + hstep < HP) { u.hp += hstep; return u; }
+        u.hp = hp0;
+        u.tile += tile_step;
+        u.ok = u.tile < n_tiles;
+        return u;
+    };
+    auto unit_request = [&](const Unit& u, int slot_buf) {   // 8 direct-to-LDS loads: 32 points x (2 rows x 8 pieces)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int slot = j * 64 + lane, pt = slot >> 4, sub = (slot & 15) ^ (pt & 15);
+            const int i2 = u.tile * 32 + pt;
+            const int n = n0 + (i2 < n_count ? i2 : n_count - 1);
+            const char* g = reinterpret_cast<const char*>(part + (size_t)u.t * tstride) + ((size_t)n * H + u.hp) * 128 + sub * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(stg + slot_buf * STG32_UNIT_BYTES + j * 1024),
+                                             16, 0, 0);
+        }
+    };
+    int ring = 0;
     auto stg_request = [&](int tile, int hp) {   // rows of head pair (hp, hp + 1), tables 0 .. tpre - 1: global -> LDS
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -200,7 +232,11 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     if (tile_first < n_tiles && hp0 < HP) {
-        if constexpr (STG) stg_request(tile_first, hp0);
+        if constexpr (STG && !P16) {
+            const Unit u0{tile_first, hp0, 0, true}, u1 = unit_next(u0);
+            unit_request(u0, 0);
+            if (u1.ok) unit_request(u1, 1);
+        } else if constexpr (STG) stg_request(tile_first, hp0);
         else {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             // 21 x 16 B per head pair and lane: holding two sets put the kernel at 256 VGPRs + 120 AGPRs, ONE wave per
             // SIMD and therefore two rounds of workgroups; there the current set is summed first and the next set is
             // loaded into the same registers, still ahead of the 24 MFMAs (see below)
-            if constexpr (STG) {
+            if constexpr (STG && P16) {
                 stg_take();
                 if (more) stg_request(tile, hp + hstep);
                 else if (wrap) stg_request(tile_next, hp0);
@@ -275,6 +311,23 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
 #pragma unroll
             for (int u = 0; u < 28; ++u) s[u] = 0.f;
             float den = 0.f;
+            if constexpr (STG && !P16) {
+                for (int t = 0; t < Tl; ++t) {   // the tables of this head pair, one ring slot each
+                    const Unit ua{tile, hp, t, true}, ub = unit_next(ua), uc = unit_next(ub);
+                    // unit ua's loads were issued before ub's eight: leave those in flight (nothing else is younger
+                    // than them but loads that may as well be waited for)
+                    if (ub.ok) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 7; ++q)
+                        cur[0].q[q] = *reinterpret_cast<const u32x4*>(stg + ring * STG32_UNIT_BYTES +
+                                                                       (li * 16 + ((hh * 8 + q) ^ (li & 15))) * 16);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (uc.ok) unit_request(uc, ring);
+                    den += cur[0].add_to(s, D);
+                    ring ^= 1;
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 if (t < tpre) den += cur[t].add_to(s, D);
@@ -283,7 +336,8 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                 extra.load(row_of(hp) + (size_t)t * tstride);
                 den += extra.add_to(s, D);
             }
-            if constexpr (!P16) {
+            }
+            if constexpr (!P16 && !STG) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
                     if ((more || wrap) && t < tpre)
@@ -819,13 +873,14 @@ int combine_launch_impl(hipStream_t st, const float* part, int Tl, int N, int H,
                         const P2pDev& px) {
     const int n_tiles = (n_count + 31) / 32;
     const bool split = n_tiles < CMB_SPLIT_BELOW;
-    size_t lds = sizeof(float) * ((size_t)((H + 1) & ~1) * 28 * WT_PITCH +
+    constexpr bool WDIRECT = (P16 || STG) && DT == 24;   // as in the kernel: no weight slab in LDS
+    size_t lds = sizeof(float) * ((WDIRECT ? (size_t)0 : (size_t)((H + 1) & ~1) * 28 * WT_PITCH) +
                                   (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0) +
                                   (split ? (CMB_WAVES - 1) * 16 * 64 : 0) +
                                   (PUSH ? (split ? 1 : CMB_WAVES) * 32 * 24 : 0));
     lds = (lds + 15) & ~(size_t)15;
     const int stg_off = (int)lds;
-    if (STG) lds += (size_t)CMB_WAVES * STG_WAVE_BYTES;
+    if (STG) lds += (size_t)CMB_WAVES * (P16 ? STG_WAVE_BYTES : STG32_WAVE_BYTES);
     if (lds > 65536) {   // many heads (the weight slab alone is 3.6 KiB per head), or the staged rows' images
         static LdsRaised raised_split, raised_flat;
         if (hept_raise_lds(split ? raised_split : raised_flat,
@@ -853,7 +908,7 @@ int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int 
                    const P2pDev& px = P2pDev{}) {
     if (HG <= 0) HG = H;
     // staged rows: packed rows of the plain layout (no head groups), even head count
-    if constexpr (P16 && DT == 24 && !PUSH) {
+    if constexpr (DT == 24 && !PUSH) {
         if (HG == H && H % 2 == 0 && !staged_combine_off())
             return combine_launch_impl<P16, FFN, DT, PUSH, true>(st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn, HG, gstride, px);
     }
