@@ -36,6 +36,14 @@ def test_bench_line(precision, bound, dtype, gpu_device):
         assert f["roofline"]["bound"] == "hbm" and f["roofline"]["kernel"] == "block_attn_split_kernel"
         assert d["c4"]["ms_per_step"] < d["ms_per_step"] and "n_hashes=1" in d["c4"]["workload"]
         assert 0.5 < d["mixed16"]["ms_per_step"] / d["ms_per_step"] < 1.5      # the every-row-tight 16-bit mode
+        # every other BASELINE configuration (round 4): c1, c2, c5 and the reference's own block size, both precisions
+        for key, n_raw, bs in (("c1", 4096, 64), ("c2", 6000, 128), ("c5", 60000, 256), ("b100", 60000, 100)):
+            for prec in ("fp32", "bf16"):
+                rec = d[key][prec]
+                assert rec["n_raw"] == n_raw and rec["block_size"] == bs and rec["ms_per_step"] > 0
+                assert abs(rec["value"] - n_raw / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-6
+                assert rec["roofline"]["bound"] == "hbm" and 0.0 < rec["roofline"]["frac"] < 1.0
+            assert d[key]["fp32"]["ms_per_step"] > 0.8 * d[key]["bf16"]["ms_per_step"]
     assert d["config"]["rccl_ranks"] == 0
     assert KEYS <= set(d) and ROOF <= set(d["roofline"])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 2 and d["higher_is_better"] is True
