@@ -936,19 +936,44 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
             small_tile_s[atomicAdd(&bin_s[bin_of((unsigned int)(mine[u] >> 32))], 1u)] = mine[u];
     __syncthreads();
     int* out = pos_out + (size_t)seg * N_stride;
-    for (int i = tid; i < N; i += SMALL_THREADS) {
-        const unsigned long long p = small_tile_s[i];
-        const unsigned int d = bin_of((unsigned int)(p >> 32));
-        const int g0 = (int)cur_s[d], g1 = (int)cur_s[d + 1];
-        int smaller = 0;
-        for (int j = g0; j < g1; j += 4) {
+    // rank inside the id group.  The launch is one workgroup per segment, so its length is this thread's chain: the
+    // SMALL_ITEMS positions of a thread are independent -- their tile reads, group bounds and first group rounds are
+    // issued side by side (a loop over them was SMALL_ITEMS dependent chains of four LDS round trips each)
+    unsigned long long pv[SMALL_ITEMS];
+    int g0v[SMALL_ITEMS], g1v[SMALL_ITEMS], smv[SMALL_ITEMS];
+#pragma unroll
+    for (int u = 0; u < SMALL_ITEMS; ++u) {
+        const int i = u * SMALL_THREADS + tid;
+        pv[u] = small_tile_s[i < N ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < SMALL_ITEMS; ++u) {
+        const unsigned int d = bin_of((unsigned int)(pv[u] >> 32));
+        g0v[u] = (int)cur_s[d];
+        g1v[u] = (int)cur_s[d + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < SMALL_ITEMS; ++u) {   // first round of every group: up to 4 members
+        unsigned long long q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = small_tile_s[min(g0v[u] + e, g1v[u] - 1)];
+        int sm = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm += (g0v[u] + e < g1v[u]) && (q[e] < pv[u]);
+        smv[u] = sm;
+    }
+#pragma unroll
+    for (int u = 0; u < SMALL_ITEMS; ++u) {
+        const int i = u * SMALL_THREADS + tid;
+        int smaller = smv[u];
+        for (int j = g0v[u] + 4; j < g1v[u]; j += 4) {   // larger groups: further rounds
             unsigned long long q[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = small_tile_s[min(j + u, g1 - 1)];
+            for (int e = 0; e < 4; ++e) q[e] = small_tile_s[min(j + e, g1v[u] - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) smaller += (j + u < g1) && (q[u] < p);
+            for (int e = 0; e < 4; ++e) smaller += (j + e < g1v[u]) && (q[e] < pv[u]);
         }
-        out[g0 + smaller] = (int)(unsigned int)p;
+        if (i < N) out[g0v[u] + smaller] = (int)(unsigned int)pv[u];
     }
 }
 
