@@ -106,7 +106,12 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
     // (segments longer than the one-workgroup sort) that launch -- a latency-bound chain that leaves the memory system
     // idle -- carries it as rider workgroups, and the row builder runs its q and k roles only (sort_tables.hip: RowsJob)
     const int raw_size = geo.eta ? geo.raw_size : N;
-    const bool ride = Tl <= HEPT_MAX_TABLES && hept_sort_carries_rows(N, H, D) && !row_riders_off();
+    // ... unless the launch is too short to hide them: with ONE local table (BASELINE config 4: one table per GPU) and
+    // 16-bit rows the bucket sort is ~12 us of its own work against ~20 us of riders -- the row builder keeps its v
+    // role there (tracking-60k, T = 1: 111.0 -> 104.7 us per forward; two tables and more, and f32 rows at any count,
+    // are faster with riders: profiles/r04_experiments.txt)
+    const bool f32_rows = precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA;
+    const bool ride = Tl <= HEPT_MAX_TABLES && (Tl >= 2 || f32_rows) && hept_sort_carries_rows(N, H, D) && !row_riders_off();
     const HeptRowsJob job{v, w.kvhat, N, raw_size, H, D, precision};
     const HeptRowsJob* rows = ride ? &job : nullptr;
     for (int c0 = 0; c0 < Tl; c0 += HEPT_MAX_TABLES) {   // chunks of tables (the rows are rewritten identically)

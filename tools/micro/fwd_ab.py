@@ -1,7 +1,7 @@
 """us per HEPTAttention.forward (whole operator, in place: the gather kernels run cold, as in bench.py) + the stage
 times, for A/B builds of one kernel.  The first call for a (workload, precision) saves the output; later calls print
 the largest difference to it (absolute, and relative to atol 1e-5 + rtol 1e-4: the fp32 every-element bound).
-python tools/micro/fwd_ab.py [precision] [label] [workload] [block size]"""
+python tools/micro/fwd_ab.py [precision] [label] [workload] [block size | -] [n_hashes]"""
 import os
 import sys
 
@@ -15,8 +15,10 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 label = sys.argv[2] if len(sys.argv) > 2 else "default"
 wl = sys.argv[3] if len(sys.argv) > 3 else "tracking-60k"
 kw = {}
-if len(sys.argv) > 4:
+if len(sys.argv) > 4 and sys.argv[4] not in ("-", ""):
     kw["block_size"] = int(sys.argv[4])
+if len(sys.argv) > 5:
+    kw["n_hashes"] = int(sys.argv[5])
 dev = torch.device("cuda:0")
 inp = workload_inputs(wl, seed=0, **kw)
 bs = kw.get("block_size", WORKLOADS[wl]["block_size"])
@@ -41,7 +43,7 @@ def step():
 out = step()
 torch.cuda.synchronize()
 base = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out",
-                    f"fwd_ab_base_{wl}_{bs}_{prec}.pt")
+                    f"fwd_ab_base_{wl}_{bs}_{inp['alpha'].shape[2]}_{prec}.pt")
 diff = ""
 if os.path.exists(base):
     ref = torch.load(base).to(dev)
@@ -69,4 +71,4 @@ torch.cuda.synchronize()
 ms, cnt = ops.profile_read()
 ops.profile_enable(0, 0)
 st = " ".join(f"{k.replace('_tables','').replace('block_','')}={v / cnt * 1e3:.1f}" for k, v in ms.items() if v > 0)
-print(f"{label} {wl} B={bs} {prec}: {best:.1f} us per forward [{st}]{diff}", flush=True)
+print(f"{label} {wl} B={bs} T={inp['alpha'].shape[2]} {prec}: {best:.1f} us per forward [{st}]{diff}", flush=True)
