@@ -116,17 +116,22 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
     const HeptRowsJob* rows = ride ? &job : nullptr;
     for (int c0 = 0; c0 < Tl; c0 += HEPT_MAX_TABLES) {   // chunks of tables (the rows are rewritten identically)
         const int tc = Tl - c0 < HEPT_MAX_TABLES ? Tl - c0 : HEPT_MAX_TABLES;
+        // (the row builder also clears the sort's bucket counters on its way: no fill launch in front of the sort)
+        void* zptr = nullptr;
+        size_t zbytes = 0;
+        hept_sort_zero_block(w.sort_ws, N, H, tc, &zptr, &zbytes);
         rc = hept_prep_hash_rpe(q, k, v, coords, w_rpe, K, alpha, codes, N, raw_size, H, D, C, T,
-                                t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream, ride ? 2 : 3);
+                                t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream, ride ? 2 : 3,
+                                zptr, zbytes);
         if (rc) return rc;
         if (c0 == 0) prof_mark(1, st);
         // the sort writes one (2, tc, H, N) array: straight into w.pos when the call is a single chunk
         int32_t* cq = Tl <= HEPT_MAX_TABLES ? qpos : w.pos_chunk;
         int32_t* ck = cq + (size_t)tc * H * N;
         rc = geo.eta ? hept_sort_tables_src_rows(w.qproj, w.kproj, geo.eta, geo.phi, geo.cfac, w.minmax, N, H, T, t0 + c0,
-                                                 tc, w.sort_ws, cq, ck, rows, stream)
+                                                 tc, w.sort_ws, cq, ck, rows, stream, zbytes != 0)
                      : hept_sort_tables_rows(w.qproj, w.kproj, codes, w.minmax, N, H, T, t0 + c0, tc, w.sort_ws, cq, ck,
-                                             rows, stream);
+                                             rows, stream, zbytes != 0);
         if (rc) return rc;
         if (cq != qpos) {
             const size_t off = (size_t)c0 * H * N, bytes = (size_t)tc * H * N * 4;
@@ -598,14 +603,18 @@ extern "C" int hept_attn_block_forward(const float* x, const float* coords, cons
     for (int c0 = 0; c0 < T; c0 += HEPT_MAX_TABLES) {
         const int tc = T - c0 < HEPT_MAX_TABLES ? T - c0 : HEPT_MAX_TABLES;
         // (K == 0: params->w_rpe is sqrt_w (H, C); K > 0: the weight itself, scale computed in the kernel -- see run_begin)
+        void* zptr = nullptr;
+        size_t zbytes = 0;
+        hept_sort_zero_block(w.sort_ws, N, H, tc, &zptr, &zbytes);   // (see run_begin)
         rc = hept_prep_hash_fused_rpe(x, p->norm1_w, p->norm1_b, p->eps1, p->w_q, p->w_k, p->w_v, coords, p->w_rpe, K,
                                       p->alpha, codes, N, N, H, D, C, T, c0, tc, precision, w.qhat, w.kvhat, w.qproj,
-                                      w.kproj, w.minmax, stream);
+                                      w.kproj, w.minmax, stream, zptr, zbytes);
         if (rc) return rc;
         if (c0 == 0) prof_mark(1, st);
         int32_t* cq = T <= HEPT_MAX_TABLES ? qpos : w.pos_chunk;
         int32_t* ck = cq + (size_t)tc * H * N;
-        rc = hept_sort_tables(w.qproj, w.kproj, codes, w.minmax, N, H, T, c0, tc, w.sort_ws, cq, ck, stream);
+        rc = hept_sort_tables_rows(w.qproj, w.kproj, codes, w.minmax, N, H, T, c0, tc, w.sort_ws, cq, ck, nullptr, stream,
+                                   zbytes != 0);
         if (rc) return rc;
         if (cq != qpos) {
             const size_t off = (size_t)c0 * H * N, bytes = (size_t)tc * H * N * 4;

@@ -160,12 +160,13 @@ __device__ __forceinline__ unsigned int hept_wave_max(unsigned int x) {
 int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                        const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
                        int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
-                       void* stream, int roles = 3);   // roles == 2: q and k rows + hashes only (the v rows: HeptRowsJob)
+                       void* stream, int roles = 3,   // roles == 2: q and k rows + hashes only (the v rows: HeptRowsJob)
+                       void* zero_ptr = nullptr, size_t zero_bytes = 0);   // scratch the launch clears on its way (hept_sort_zero_block)
 int hept_prep_hash_fused_rpe(const float* x, const float* norm_w, const float* norm_b, float eps, const float* w_q,
                              const float* w_k, const float* w_v, const float* coords, const float* sqrt_w, int K,
                              const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T,
                              int t0, int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj,
-                             float* minmax, void* stream);
+                             float* minmax, void* stream, void* zero_ptr = nullptr, size_t zero_bytes = 0);
 // The v half of the kvhat rows written by workgroups that ride in the bucket-sort launch (sort_tables.hip) instead of by
 // the row builder's third role: hept_prep_hash_rpe with roles == 2 leaves them out, hept_sort_tables_rows /
 // hept_sort_tables_src_rows with a job description write them.  hept_sort_carries_rows: the sort of N-key segments has
@@ -176,12 +177,15 @@ struct HeptRowsJob {
     int N, raw_size, H, D, precision;
 };
 bool hept_sort_carries_rows(int N, int H, int D);
+// zeroed: the block hept_sort_zero_block names has been zeroed on this stream by the caller (the row builder of the same
+// forward does it: hept_prep_hash_rpe's `zero` argument); otherwise the sort pays a fill launch for it
 int hept_sort_tables_rows(const float* qproj, const float* kproj, const int64_t* codes, const float* minmax, int N, int H,
                           int T, int t0, int Tl, void* sort_ws, int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows,
-                          void* stream);
+                          void* stream, bool zeroed = false);
 int hept_sort_tables_src_rows(const float* qproj, const float* kproj, const float* eta_idx, const float* phi_idx,
                               const float* cfac, float* minmax, int N, int H, int T, int t0, int Tl, void* sort_ws,
-                              int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows, void* stream);
+                              int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows, void* stream, bool zeroed = false);
+void hept_sort_zero_block(void* sort_ws, int N, int H, int Tl, void** ptr, size_t* bytes);
 // hept_segmented_argsort for a caller that knows finite bounds of its keys (prepare.hip: packed code keys): the
 // per-segment range pass (a fill and a kernel) is skipped; any bounds give the exact stable sort
 int hept_segmented_argsort_bounded(const float* keys, int S, int L, float lo, float hi, void* ws, int32_t* pos,

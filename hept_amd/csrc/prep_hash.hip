@@ -125,6 +125,18 @@ __global__ __launch_bounds__(1024) void rpe_scale_bwd_kernel(const float* __rest
     }
 }
 
+// A block of scratch the NEXT kernel of the forward needs zeroed (the bucket counters of the sort, sort_tables.hip:
+// RegionArgs): the launch's workgroups clear it on their way in, a few stores each, instead of a fill launch.
+struct ZeroJob {
+    unsigned int* ptr;
+    unsigned int words;
+};
+__device__ __forceinline__ void zero_block(const ZeroJob& z) {
+    const unsigned int n_threads = gridDim.x * gridDim.y * blockDim.x;
+    for (unsigned int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < z.words; i += n_threads)
+        z.ptr[i] = 0u;
+}
+
 // Streaming transform, one lane per (point, head) row, three wave ROLES selected by blockIdx.y:
 //   role 0 (q): q row + coords -> q^ row, q hashes, hash min/max, largest AND code
 //   role 1 (k): k row + coords -> k^ half of the kvhat row, k hashes, hash min/max
@@ -407,7 +419,17 @@ static_assert(PREP_WGS_PER_ROLE <= PREP_SLOTS_PER_ROLE && HEPT_PREP_WGS2 <= PREP
 inline int prep_wgs(int N, int roles = 3) {
     const int tiles = (N + PREP_POINTS - 1) / PREP_POINTS, per_wg = PREP_THREADS / HEPT_WAVE;
     const int want = (tiles + per_wg - 1) / per_wg, cap = roles == 2 ? HEPT_PREP_WGS2 : PREP_WGS_PER_ROLE;
-    return want < cap ? (want < 1 ? 1 : want) : cap;
+    if (want <= cap) return want < 1 ? 1 : want;
+    // The launch is one round of workgroups and ends with its slowest wave: with `cap` workgroups some waves take one
+    // tile more than others (tracking-60k: 7504 tiles on 2048 waves = 1360 waves with 4 tiles, 688 with 3).  Take the
+    // number of trips that cap implies and the FEWEST workgroups that still make it: every wave gets the same number of
+    // tiles (469 workgroups x 4 waves x 4 tiles) and the round has fewer waves to share the CUs with.
+    // (measured with two roles -- 2 x 469 instead of 2 x 512 workgroups: row builder 45.9-46.9 -> 44.0-45.3 us; three
+    //  roles at 3 x 313 instead of 3 x 341 are a round of fewer, longer waves and lose ~1 us: they keep the cap)
+    static const bool even = [] { const char* e = getenv("HEPT_PREP_UNEVEN"); return !(e && *e && *e != '0'); }();
+    if (!even || roles != 2) return cap;
+    const int trips = (tiles + cap * per_wg - 1) / (cap * per_wg);
+    return (tiles + trips * per_wg - 1) / (trips * per_wg);
 }
 
 // (fp16 q^/k^ rows, 4 table slots: left alone the allocation takes 135 VGPRs = 3 waves per SIMD where the bf16 build
@@ -419,9 +441,11 @@ void prep_hash_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, int K, const float* __restrict__ alpha,
     const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
-    void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
+    void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax,
+    ZeroJob zero) {
     constexpr int H = 8, E = D + C;
     static_assert(D % 4 == 0 && E <= 30 && D <= 28, "row packing needs D%4==0, E<=30");
+    zero_block(zero);
     __shared__ __attribute__((aligned(16))) float alpha_s[H * alpha_pitch(E, TMAX)];
     __shared__ float sw_s[H * C];
     __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * TMAX * H * 4];
@@ -460,8 +484,10 @@ void prep_fused_kernel(
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, int K, const float* __restrict__ alpha,
     const int64_t* __restrict__ codes, int N, int raw_size, int T, int t0, int Tl, void* __restrict__ qhat_,
-    void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax) {
+    void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj, float* __restrict__ minmax,
+    ZeroJob zero) {
     constexpr int D = 24, H = 8, E = D + C;
+    zero_block(zero);
     __shared__ __attribute__((aligned(16))) float alpha_s[H * alpha_pitch(E, TMAX)];
     __shared__ float sw_s[H * C];
     // wave buffers: the output image only (264 slots for 16-bit rows, 520 for f32 rows); red_s reuses them after the loop
@@ -502,12 +528,12 @@ template <int C>
 int launch_prep_fused(const float* x, const float* ln_w, const float* ln_b, float eps, const float* wq, const float* wk,
                       const float* wv, const float* coords, const float* sqrt_w, int K, const float* alpha,
                       const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision, void* qhat,
-                      void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st) {
+                      void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st, ZeroJob zero) {
     const dim3 grid(prep_wgs(N), 3);
     // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
 #define HEPT_FUSED_LAUNCH(TILE, TMAX)                                                                                  \
     hipLaunchKernelGGL((prep_fused_kernel<C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, x, ln_w, ln_b, eps, wq, wk, \
-                       wv, coords, sqrt_w, K, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
+                       wv, coords, sqrt_w, K, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax, zero)
 #define HEPT_FUSED_TILE(TILE)                                                                                          \
     do {                                                                                                               \
         if (Tl <= 4) HEPT_FUSED_LAUNCH(TILE, 4);                                                                       \
@@ -524,13 +550,13 @@ int launch_prep_fused(const float* x, const float* ln_w, const float* ln_b, floa
 template <int D, int C>
 int launch_prep(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                 const float* alpha, const int64_t* codes, int N, int raw_size, int T, int t0, int Tl, int precision,
-                void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st, int roles) {
+                void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax, hipStream_t st, int roles, ZeroJob zero) {
     // q- and k-role workgroups each write one of the HEPT_PREP_GRID partial slots the sort kernel reduces
     const dim3 grid(prep_wgs(N, roles), roles);
     // table slots of the kernel (accumulators, alpha slab): 4 for the usual 1-4 tables per call, else HEPT_MAX_TABLES
 #define HEPT_PREP_LAUNCH(TILE, TMAX)                                                                                 \
     hipLaunchKernelGGL((prep_hash_kernel<D, C, TILE, TMAX>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w, \
-                       K, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax)
+                       K, alpha, codes, N, raw_size, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax, zero)
 #define HEPT_PREP_TILE(TILE)                                                                                         \
     do {                                                                                                             \
         if (Tl <= 4) HEPT_PREP_LAUNCH(TILE, 4);                                                                      \
@@ -565,10 +591,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
     const float* __restrict__ coords, const float* __restrict__ sqrt_w, int K, const float* __restrict__ alpha,
     const int64_t* __restrict__ codes, int N, int raw_size, int H, int D, int C, int T, int t0, int Tl,
     void* __restrict__ qhat_, void* __restrict__ kvhat_, float* __restrict__ qproj, float* __restrict__ kproj,
-    float* __restrict__ minmax) {
+    float* __restrict__ minmax, ZeroJob zero) {
     constexpr bool BF16 = TILE != HEPT_PREC_F32;
     constexpr bool F16QK = TILE == HEPT_PREC_MIXED16;
     constexpr int QROW = BF16 ? 64 : 128;
+    zero_block(zero);
     __shared__ float alpha_s[16 * 30 * HEPT_MAX_TABLES];              // [h][e][t]
     __shared__ unsigned int red_s[HEPT_MAX_TABLES * 16 * 3];          // ordered-uint min / max / code max per (t, h)
     __shared__ float sw_s[16 * 29];                                   // sqrt_w (H, C)
@@ -686,17 +713,17 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_generic_kernel(
 int launch_prep_generic(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                         const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
                         int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
-                        hipStream_t st, int roles) {
+                        hipStream_t st, int roles, ZeroJob zero) {
     const dim3 grid(HEPT_PREP_GRID / 2, roles);   // q- and k-role workgroups each own one partial slot
     if (precision == HEPT_PREC_BF16)
         hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_BF16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
-                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax, zero);
     else if (precision == HEPT_PREC_MIXED16)
         hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_MIXED16>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
-                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax, zero);
     else
         hipLaunchKernelGGL((prep_generic_kernel<HEPT_PREC_F32>), grid, dim3(PREP_THREADS), 0, st, q, k, v, coords, sqrt_w,
-                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax);
+                           K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, qhat, kvhat, qproj, kproj, minmax, zero);
     return hept_launch_status();
 }
 
@@ -723,8 +750,10 @@ extern "C" int hept_rpe_scale_bwd(const float* w_rpe, const float* d_sqrt_w, int
 int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const float* coords, const float* sqrt_w, int K,
                        const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T, int t0,
                        int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj, float* minmax,
-                       void* stream, int roles) {
+                       void* stream, int roles, void* zero_ptr, size_t zero_bytes) {
     if (roles != 2 && roles != 3) return HEPT_ERR_ARG;
+    if (zero_bytes % 4 != 0 || (zero_bytes && !zero_ptr) || zero_bytes > 0xFFFFFFFFull) return HEPT_ERR_ARG;
+    const ZeroJob zero{reinterpret_cast<unsigned int*>(zero_ptr), (unsigned int)(zero_bytes / 4)};
     if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
     if (K < 0 || (K > 0 && (C < 2 || H * (C - 1) * K > 1024))) return HEPT_ERR_SHAPE;
     if (!q || !k || !v || !coords || !sqrt_w || !alpha || !qhat || !kvhat || !qproj || !kproj || !minmax)
@@ -738,7 +767,7 @@ int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const flo
 #define HEPT_PREP_CASE(DD, CC)                                                                             \
     if (H == 8 && D == DD && C == CC)                                                                      \
         return launch_prep<DD, CC>(q, k, v, coords, sqrt_w, K, alpha, codes, N, raw_size, T, t0, Tl, precision, \
-                                   qhat, kvhat, qproj, kproj, minmax, st, roles);
+                                   qhat, kvhat, qproj, kproj, minmax, st, roles, zero);
     HEPT_PREP_CASE(24, 6)
     HEPT_PREP_CASE(24, 4)
     HEPT_PREP_CASE(24, 2)
@@ -747,7 +776,7 @@ int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const flo
     HEPT_PREP_CASE(8, 4)
 #undef HEPT_PREP_CASE
     return launch_prep_generic(q, k, v, coords, sqrt_w, K, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, precision, qhat,
-                               kvhat, qproj, kproj, minmax, st, roles);
+                               kvhat, qproj, kproj, minmax, st, roles, zero);
 }
 
 extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, const float* coords,
@@ -755,7 +784,7 @@ extern "C" int hept_prep_hash(const float* q, const float* k, const float* v, co
                               int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat, void* kvhat,
                               float* qproj, float* kproj, float* minmax, void* stream) {
     return hept_prep_hash_rpe(q, k, v, coords, sqrt_w, 0, alpha, codes, N, raw_size, H, D, C, T, t0, Tl, precision, qhat,
-                              kvhat, qproj, kproj, minmax, stream, 3);
+                              kvhat, qproj, kproj, minmax, stream, 3, nullptr, 0);
 }
 
 // internal (common.h): K as in hept_prep_hash_rpe
@@ -763,8 +792,10 @@ int hept_prep_hash_fused_rpe(const float* x, const float* norm_w, const float* n
                              const float* w_k, const float* w_v, const float* coords, const float* sqrt_w, int K,
                              const float* alpha, const int64_t* codes, int N, int raw_size, int H, int D, int C, int T,
                              int t0, int Tl, int precision, void* qhat, void* kvhat, float* qproj, float* kproj,
-                             float* minmax, void* stream) {
+                             float* minmax, void* stream, void* zero_ptr, size_t zero_bytes) {
     if (raw_size < 0 || raw_size > N) return HEPT_ERR_SHAPE;
+    if (zero_bytes % 4 != 0 || (zero_bytes && !zero_ptr) || zero_bytes > 0xFFFFFFFFull) return HEPT_ERR_ARG;
+    const ZeroJob zero{reinterpret_cast<unsigned int*>(zero_ptr), (unsigned int)(zero_bytes / 4)};
     if (K < 0 || (K > 0 && (C < 2 || H * (C - 1) * K > 1024))) return HEPT_ERR_SHAPE;
     if (!x || !norm_w || !norm_b || !w_q || !w_k || !w_v || !coords || !sqrt_w || !alpha || !qhat || !kvhat ||
         !qproj || !kproj || !minmax)
@@ -777,7 +808,7 @@ int hept_prep_hash_fused_rpe(const float* x, const float* norm_w, const float* n
 #define HEPT_FUSED_CASE(CC)                                                                                         \
     if (C == CC)                                                                                                    \
         return launch_prep_fused<CC>(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, K, alpha, codes, N, raw_size, \
-                                     T, t0, Tl, precision, qhat, kvhat, qproj, kproj, minmax, st);
+                                     T, t0, Tl, precision, qhat, kvhat, qproj, kproj, minmax, st, zero);
     HEPT_FUSED_CASE(6)
     HEPT_FUSED_CASE(4)
     HEPT_FUSED_CASE(2)
@@ -791,5 +822,5 @@ extern "C" int hept_prep_hash_fused(const float* x, const float* norm_w, const f
                                     int H, int D, int C, int T, int t0, int Tl, int precision, void* qhat,
                                     void* kvhat, float* qproj, float* kproj, float* minmax, void* stream) {
     return hept_prep_hash_fused_rpe(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, 0, alpha, codes, N, raw_size, H,
-                                    D, C, T, t0, Tl, precision, qhat, kvhat, qproj, kproj, minmax, stream);
+                                    D, C, T, t0, Tl, precision, qhat, kvhat, qproj, kproj, minmax, stream, nullptr, 0);
 }

@@ -78,6 +78,32 @@ struct SegParams {
     float kmin, scale;
 };
 
+// REGION layout (segments of SMALL_CAP < N <= REGION_MAX_N keys; round 5): every (segment, bucket) owns a fixed region
+// of `capb` pair slots, region[seg][bucket][0 .. capb), at a pitch that is an odd number of 256-B units (the regions'
+// first lines must not all fall on the same memory channels).  KA reserves the slots of a chunk's run with ONE atomic
+// per (chunk, bucket) on cnt[seg][bucket] -- the return value is where the run starts inside the region -- so KB reads
+// one contiguous array instead of n_chunks runs behind a dependent table lookup, and the first final position of a
+// bucket is the sum of the counts in front of it.  Arrival order inside a region is arbitrary: KB sorts unique
+// (key, index) pairs, the result does not depend on it.  Pairs that do not fit (skewed keys, ties) go to the segment's
+// overflow pool through a bump cursor; a bucket with more than capb pairs collects them from there (slow, exact).
+// The counters (cnt[segs][NTOP], then cursor[segs]) must be zero when KA starts: the row builder of the same forward
+// zeroes them (hept_sort_zero_block), stand-alone callers pay a fill.
+struct RegionArgs {
+    unsigned int* cnt;               // [segs][NTOP] pairs per bucket, then [segs] overflow-pool cursors
+    unsigned long long* region;      // [segs][NTOP][pitch]
+    unsigned long long* pool;        // [segs][N] overflow pairs of the segment, any order
+    unsigned long long* gathered;    // [segs][N] KB: the pairs of an overflowing bucket, collected (at the bucket's positions)
+    unsigned int capb, pitch;        // slots per region; pitch in pairs
+    int segs;
+};
+constexpr int REGION_MAX_N = 131072;   // = NTOP * BKT_CAP_SMALL / 2: the range of the small-tile bucket kernel
+constexpr unsigned int region_cap(int N) {   // >= 8x the average bucket, a power of two, >= 2048
+    unsigned int c = 2048;
+    while ((size_t)c * 32 < (size_t)N) c <<= 1;
+    return c;
+}
+constexpr unsigned int region_pitch(unsigned int capb) { return capb + 32; }   // + 256 B: an odd multiple of 256 B
+
 // EMBED (segments of at most 2^20 keys): the pair carries the low id bits next to the point index,
 //     pair = key << 32 | low id << 20 | index,
 // so that KB reads a pair's group with a shift instead of recomputing the float id map (KB is bound by VALU issue:
@@ -110,21 +136,26 @@ constexpr int SCT_WAVES = SCT / HEPT_WAVE;
 constexpr int TAB = RADIX + 1;   // digit offset table of a chunk
 static_assert(SCT >= RADIX && SCT % RADIX == 0 && SORT_CHUNK % SCT == 0 && SCT_ITEMS % 4 == 0, "digit ownership / items per thread");
 static_assert(HEPT_PREP_GRID % SCT == 0, "range partials per thread");
-template <int MODE, bool EMBED>
+template <int MODE, bool EMBED, bool REGION>
 __global__ __launch_bounds__(SCT) void chunk_sort_kernel(
     const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
     const float* __restrict__ eta_idx, const float* __restrict__ phi_idx, const float* __restrict__ cfac,
     const float* __restrict__ minmax, const unsigned int* __restrict__ range_bits, float range_lo, float range_hi, int N,
     int H, int t0, int Tl, int n_chunks, const int* __restrict__ seg_len, SegParams* __restrict__ seg_params,
-    unsigned long long* __restrict__ pairs, unsigned int* __restrict__ tab) {
+    unsigned long long* __restrict__ pairs, unsigned int* __restrict__ tab, RegionArgs rg) {
     __shared__ unsigned long long stage_s[SORT_CHUNK];   // the chunk, digit-sorted (32 KiB)
     __shared__ unsigned int cnt_s[RADIX];                // keys of the chunk per digit
     __shared__ unsigned int start_s[TAB];                // first local position of a digit
     __shared__ unsigned int wsum_s[RADIX / HEPT_WAVE];
     __shared__ float red_s[3][SCT_WAVES];
+    // REGION: digit of every staged position; slot of local position lp inside its bucket's region = lp + delta[digit]
+    __shared__ unsigned char dig_s[REGION ? SORT_CHUNK : 4];
+    __shared__ int delta_s[REGION ? RADIX : 1];
+    __shared__ unsigned int over_s[REGION ? RADIX + 2 : 1];   // overflow: pairs of a digit beyond the region; [RADIX]: any, [RADIX+1]: pool base
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool digit = tid < RADIX;                      // this thread owns digit `tid`
     const int seg = blockIdx.y, chunk = blockIdx.x;
+    if (REGION && tid == 0) over_s[RADIX] = 0;
     const size_t seg_off = (size_t)seg * N;        // N = segment stride; len = keys that take part (ragged argsort)
     const int len = seg_len ? seg_len[seg] : N;
     const int base = chunk * SORT_CHUNK;
@@ -260,35 +291,101 @@ __global__ __launch_bounds__(SCT) void chunk_sort_kernel(
     __syncthreads();
     // digit `tid`: exclusive prefix over the digits -> first local position of the digit
     const unsigned int total = digit ? cnt_s[tid] : 0u;
+    // REGION: reserve the run's slots in the bucket's region (the round trip of the atomic runs beside the prefix and the
+    // staging below; its result is needed for the write-out only)
+    unsigned int gbase = 0;
+    if constexpr (REGION) {
+        if (digit && total) gbase = atomicAdd(rg.cnt + (size_t)seg * NTOP + tid, total);
+    }
     const unsigned int incl = hept_wave_scan_add(total);
     if (digit && lane == 63) wsum_s[w] = incl;
     __syncthreads();
     const int n_valid = max(0, min(SORT_CHUNK, len - base));
-    unsigned int* my_tab = tab + ((size_t)seg * n_chunks + chunk) * TAB;
+    unsigned int first = incl - total;
     if (digit) {
-        unsigned int first = incl - total;
 #pragma unroll
         for (int ww = 0; ww < RADIX / HEPT_WAVE; ++ww)
             if (ww < w) first += wsum_s[ww];
         start_s[tid] = first;
-        my_tab[tid] = first;
-        if (tid == RADIX - 1) my_tab[RADIX] = (unsigned int)n_valid;
+        if constexpr (!REGION) {
+            unsigned int* my_tab = tab + ((size_t)seg * n_chunks + chunk) * TAB;
+            my_tab[tid] = first;
+            if (tid == RADIX - 1) my_tab[RADIX] = (unsigned int)n_valid;
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SCT_ITEMS; ++r) {
         const int n = base + ((r >> 2) * SCT + tid) * 4 + (r & 3);
-        if (n < len)
-            stage_s[start_s[dig[r]] + rank[r]] = ((unsigned long long)key[r] << 32) |
-                                                 (EMBED ? ((unsigned int)lowid[r] << EMBED_SHIFT) | (unsigned int)n : (unsigned int)n);
+        if (n < len) {
+            const unsigned int lp = start_s[dig[r]] + rank[r];
+            stage_s[lp] = ((unsigned long long)key[r] << 32) |
+                          (EMBED ? ((unsigned int)lowid[r] << EMBED_SHIFT) | (unsigned int)n : (unsigned int)n);
+            if constexpr (REGION) dig_s[lp] = dig[r];
+        }
+    }
+    if constexpr (REGION) {
+        if (digit) {
+            delta_s[tid] = (int)gbase - (int)first;
+            const unsigned int end = gbase + total;
+            const unsigned int ov = end > rg.capb ? end - (gbase > rg.capb ? gbase : rg.capb) : 0u;
+            over_s[tid] = ov;
+            if (ov) over_s[RADIX] = 1u;
+        }
     }
     __syncthreads();
-    // write out: the chunk's run, linear
-    unsigned long long* out = pairs + seg_off + base;
+    if constexpr (REGION) {
+        // write out: every run goes to its bucket's region (consecutive lanes: consecutive slots of a run)
+        unsigned long long* reg = rg.region + (size_t)seg * NTOP * rg.pitch;
+        if (over_s[RADIX] == 0u) {   // uniform: the common case, every run fits
 #pragma unroll
-    for (int r = 0; r < SCT_ITEMS; ++r) {
-        const int lp = r * SCT + tid;
-        if (lp < n_valid) out[lp] = stage_s[lp];
+            for (int r = 0; r < SCT_ITEMS; ++r) {
+                const int lp = r * SCT + tid;
+                if (lp < n_valid) {
+                    const unsigned int d = dig_s[lp];
+                    reg[(size_t)d * rg.pitch + (unsigned int)(lp + delta_s[d])] = stage_s[lp];
+                }
+            }
+        } else {
+            // some run crosses the end of its region: those pairs go to the segment's overflow pool, packed by an
+            // exclusive prefix over the digits' overflow counts behind one bump of the pool cursor
+            const unsigned int ov = digit ? over_s[tid] : 0u;
+            const unsigned int oincl = hept_wave_scan_add(ov);
+            if (digit && lane == 63) wsum_s[w] = oincl;
+            __syncthreads();
+            if (digit) {
+                unsigned int ofirst = oincl - ov;
+#pragma unroll
+                for (int ww = 0; ww < RADIX / HEPT_WAVE; ++ww)
+                    if (ww < w) ofirst += wsum_s[ww];
+                over_s[tid] = ofirst;
+                if (tid == RADIX - 1) over_s[RADIX + 1] = atomicAdd(rg.cnt + (size_t)rg.segs * NTOP + seg, ofirst + ov);
+            }
+            __syncthreads();
+            unsigned long long* pool = rg.pool + seg_off + over_s[RADIX + 1];
+#pragma unroll
+            for (int r = 0; r < SCT_ITEMS; ++r) {
+                const int lp = r * SCT + tid;
+                if (lp < n_valid) {
+                    const unsigned int d = dig_s[lp];
+                    const unsigned int slot = (unsigned int)(lp + delta_s[d]);
+                    if (slot < rg.capb) {
+                        reg[(size_t)d * rg.pitch + slot] = stage_s[lp];
+                    } else {
+                        const unsigned int gb = (unsigned int)(delta_s[d] + (int)start_s[d]);   // the run's first slot
+                        pool[over_s[d] + (slot - (gb > rg.capb ? gb : rg.capb))] = stage_s[lp];
+                    }
+                }
+            }
+        }
+    } else {
+        // write out: the chunk's run, linear
+        unsigned long long* out = pairs + seg_off + base;
+#pragma unroll
+        for (int r = 0; r < SCT_ITEMS; ++r) {
+            const int lp = r * SCT + tid;
+            if (lp < n_valid) out[lp] = stage_s[lp];
+        }
     }
 }
 
@@ -412,30 +509,92 @@ static_assert(LOBINS % BKT_THREADS == 0, "every thread owns the same number of b
 // MAXR = chunks whose run offsets fit the kernel's LDS table (64: every wave builds the table by itself with one
 // shuffle scan, no barrier; the large-tile kernel takes up to 1024 chunks = 4 M keys per segment through a serial
 // scan); longer segments walk the global table for every lookup -- slow, never wrong
-template <int CAP, bool EMBED, int MAXR>
-__global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned long long* __restrict__ pairs,
-                                                                  unsigned long long* __restrict__ scratch,
-                                                                  const SegParams* __restrict__ seg_params,
-                                                                  const unsigned int* __restrict__ tab, int N,
-                                                                  int n_chunks, int* __restrict__ pos_out,
-                                                                  RowsJob rows) {
-    static_assert(CAP >= LOBINS, "the tile also holds the splitters of the streaming path");
-    if ((int)blockIdx.y < rows.vy) {   // uniform: a rider workgroup (the first rows of the grid: dispatched first)
-        const unsigned int wg = blockIdx.y * gridDim.x + blockIdx.x, n_wgs = (unsigned int)rows.vy * gridDim.x;
-        if (rows.H == 8) rows_rider<8>(rows, wg, n_wgs);
-        else rows_rider<0>(rows, wg, n_wgs);
-        return;
-    }
-#ifdef HEPT_RIDERS_ONLY   // measurement builds: what the riders cost by themselves
-    if (rows.vy > 0) return;
-#endif
-    __shared__ unsigned long long tile_s[CAP];
-    __shared__ unsigned int cur_s[LOBINS + 1];  // [0] stays 0; bin d lives at [d + 1]
-    __shared__ unsigned int wsum_s[BKT_WAVES];
-    __shared__ unsigned int roff_s[MAXR + 1];   // pairs of the bucket in runs 0 .. c-1
-    __shared__ unsigned int rbase_s[MAXR + 1];  // first pair of run c, as an index into the segment's pairs; [MAXR]: start
+// The common bucket of the REGION layout (nb <= LEAN_SLOTS * threads pairs, all of them in registers, low id bits embedded):
+// the same three steps as the general code below -- histogram of the low id bits, exclusive prefix, scatter into the
+// tile -- but every thread ranks ITS OWN pairs straight from its registers: the scatter's atomic told it the group, the
+// bins array (now one past the last slot of every group) the group's bounds; a group of one or two pairs (92 % of the
+// pairs at tracking-60k) is ranked by two tile reads and two compares, without a loop.  No validity masks, no
+// run lookups, no second pass: ~45 % of the general path's instructions (the kernel is bound by instruction issue).
+constexpr int LEAN_SLOTS = 4;
+// pr[u] = pair u * threads + tid of the bucket for every u with u * threads < nb (anything where that position is >= nb)
+__device__ __forceinline__ void bucket_lean(const unsigned long long (&pr)[LEAN_SLOTS], int nb, int start,
+                                            unsigned long long* __restrict__ tile_s, unsigned int* __restrict__ cur_s,
+                                            unsigned int* __restrict__ wsum_s, int* __restrict__ out) {
+    static_assert(BKT_BINS_PER_THREAD == 4, "bins per thread: one 16-B LDS access");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int seg = (int)blockIdx.y - rows.vy, bucket = blockIdx.x;
+    unsigned int* bin_s = cur_s + 1;
+    unsigned int d[LEAN_SLOTS];
+#pragma unroll
+    for (int u = 0; u < LEAN_SLOTS; ++u) {
+        if (u * BKT_THREADS >= nb) break;   // uniform
+        d[u] = ((unsigned int)pr[u] >> EMBED_SHIFT) & (unsigned int)(LOBINS - 1);
+        if (u * BKT_THREADS + tid < nb) atomicAdd(&bin_s[d[u]], 1u);
+    }
+    __syncthreads();
+    {   // exclusive prefix over the bins: thread owns bins 4 tid .. 4 tid + 3
+        const u32x4 c = *reinterpret_cast<const u32x4*>(bin_s + 4 * tid);
+        const unsigned int tot = c[0] + c[1] + c[2] + c[3];
+        const unsigned int incl = hept_wave_scan_add(tot);
+        if (lane == 63) wsum_s[w] = incl;
+        __syncthreads();
+        unsigned int run = incl - tot;
+#pragma unroll
+        for (int ww = 0; ww < BKT_WAVES; ++ww)
+            if (ww < w) run += wsum_s[ww];
+        u32x4 e;
+        e[0] = run; e[1] = run + c[0]; e[2] = e[1] + c[1]; e[3] = e[2] + c[2];
+        *reinterpret_cast<u32x4*>(bin_s + 4 * tid) = e;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < LEAN_SLOTS; ++u) {
+        if (u * BKT_THREADS >= nb) break;   // uniform
+        if (u * BKT_THREADS + tid < nb) tile_s[atomicAdd(&bin_s[d[u]], 1u)] = pr[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < LEAN_SLOTS; ++u) {
+        if (u * BKT_THREADS >= nb) break;   // uniform
+        if (u * BKT_THREADS + tid < nb) {
+            const unsigned long long p = pr[u];
+            const int g0 = (int)cur_s[d[u]], g1 = (int)cur_s[d[u] + 1];   // the group: [end of the group before, own end)
+            const unsigned long long a = tile_s[g0], b = tile_s[g1 - 1];   // first and last member (the same pair: alone)
+            int smaller = (int)(a < p) + (int)(b < p);
+            for (int j = g0 + 1; j < g1 - 1; ++j) smaller += (int)(tile_s[j] < p);   // groups of three and more
+            out[start + g0 + smaller] = (int)((unsigned int)p & EMBED_INDEX_MASK);
+        }
+    }
+}
+
+// REGION (see RegionArgs): the bucket's pairs are ONE contiguous array, region[seg][bucket][0 .. nb), nb = cnt[seg][bucket],
+// and its first final position is the sum of the counts in front of it -- no run table, no lookup, and nothing the pair
+// loads depend on: the first two register slots are requested before the counts have arrived (a region is at least
+// 2 * threads slots long; what lies behind nb is ignored).  A bucket of more than capb pairs first collects its pairs
+// (the region + its share of the segment's overflow pool) into `gathered` and carries on from there.
+// the LDS of one bucket (owned by the kernel that calls bucket_body)
+struct BucketLds {
+    unsigned long long* tile;   // [CAP]
+    unsigned int* binarr;       // [LOBINS + 4] at a 16-B boundary: cur = binarr + 3 (cur[0] stays 0), bin d lives at cur[d + 1]
+    unsigned int* wsum;         // [BKT_WAVES]
+    unsigned int* roff;         // [MAXR + 1] pairs of the bucket in runs 0 .. c-1
+    unsigned int* rbase;        // [MAXR + 1] first pair of run c, as an index into the segment's pairs; [MAXR]: start
+    unsigned int* front;        // [BKT_WAVES + 1] REGION: per-wave sums of the counts in front; [BKT_WAVES]: gather cursor
+};
+template <int CAP, bool EMBED, int MAXR, bool REGION, bool LEAN>
+__device__ __forceinline__ void bucket_body(const unsigned long long* __restrict__ pairs,
+                                            unsigned long long* __restrict__ scratch,
+                                            const SegParams* __restrict__ seg_params,
+                                            const unsigned int* __restrict__ tab, int N, int n_chunks,
+                                            int* __restrict__ pos_out, const RegionArgs& rga, const int seg, const int bucket,
+                                            const BucketLds& lds) {
+    static_assert(CAP >= LOBINS, "the tile also holds the splitters of the streaming path");
+    unsigned long long* tile_s = lds.tile;
+    unsigned int* cur_s = lds.binarr + 3;
+    unsigned int* wsum_s = lds.wsum;
+    unsigned int* roff_s = lds.roff;
+    unsigned int* rbase_s = lds.rbase;
+    unsigned int* front_s = lds.front;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned long long* seg_pairs = pairs + (size_t)seg * N;
     const unsigned int* btab = tab + (size_t)seg * n_chunks * TAB + bucket;   // + c * TAB: [first, end) of run c
     unsigned int* bin_s = cur_s + 1;
@@ -446,8 +605,31 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     };
     zero_bins();
     // ---- the bucket's runs: offsets, first final position, size
-    const bool table_in_lds = n_chunks <= MAXR;
+    const bool table_in_lds = REGION || n_chunks <= MAXR;
     int start = 0, nb = 0, longest = 1 << 30;
+    constexpr int SPEC = 2;                       // REGION: register slots requested before nb is known
+    unsigned long long spec[SPEC] = {};
+    const unsigned long long* src = nullptr;      // REGION: the bucket's pairs, contiguous
+    if constexpr (REGION) {
+        static_assert(NTOP % BKT_THREADS == 0, "every thread sums the same number of bucket counts");
+        constexpr int CPT = NTOP / BKT_THREADS;
+        const unsigned int* cseg = rga.cnt + (size_t)seg * NTOP;
+        const unsigned long long* reg = rga.region + ((size_t)seg * NTOP + bucket) * rga.pitch;
+#pragma unroll
+        for (int u = 0; u < SPEC; ++u) spec[u] = reg[u * BKT_THREADS + tid];
+        unsigned int in_front = 0;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int b = tid * CPT + u;
+            const unsigned int c = cseg[b];
+            in_front += b < bucket ? c : 0u;
+        }
+        nb = (int)cseg[bucket];
+        in_front = hept_wave_sum(in_front);
+        if (lane == 0) front_s[w] = in_front;
+        if (tid == 0) front_s[BKT_WAVES] = 0;
+        src = reg;
+    } else
     if (n_chunks <= HEPT_WAVE) {
         // every wave builds the table by itself (same values, written twice): no barrier before the lookups
         unsigned int a0 = 0, a1 = 0;
@@ -499,9 +681,46 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
     //  from them -- loop bounds, the path taken, the output base -- lives in vector registers and every branch on them
     //  becomes predicated code: 122 VGPRs instead of ~60)
     nb = __builtin_amdgcn_readfirstlane(nb);
+    if (nb <= 0) return;   // uniform
+    bool collected = false;   // REGION: the bucket overflowed its region and was collected into `gathered`
+    if constexpr (REGION) {
+        __syncthreads();   // the waves' sums of the counts in front (and the bins are zero in every wave's view)
+#pragma unroll
+        for (int ww = 0; ww < BKT_WAVES; ++ww) start += (int)front_s[ww];
+#ifndef HEPT_BKT_NO_LEAN
+        if constexpr (EMBED && LEAN) {
+            if (nb <= LEAN_SLOTS * BKT_THREADS) {   // uniform: the common bucket
+                unsigned long long pr[LEAN_SLOTS];
+#pragma unroll
+                for (int u = 0; u < LEAN_SLOTS; ++u) {
+                    if (u >= SPEC && u * BKT_THREADS >= nb) break;   // uniform
+                    pr[u] = u < SPEC ? spec[u < SPEC ? u : 0] : (u * BKT_THREADS + tid < nb ? src[u * BKT_THREADS + tid] : 0ull);
+                }
+                bucket_lean(pr, nb, __builtin_amdgcn_readfirstlane(start), tile_s, cur_s, wsum_s, pos_out + (size_t)seg * N);
+                return;
+            }
+        }
+#endif
+        if (nb > (int)rga.capb) {   // uniform, uncommon: region + this bucket's share of the overflow pool -> gathered
+            start = __builtin_amdgcn_readfirstlane(start);
+            unsigned long long* gdst = rga.gathered + (size_t)seg * N + start;
+            for (int i = tid; i < (int)rga.capb; i += BKT_THREADS) gdst[i] = src[i];
+            const SegParams sp = seg_params[seg];
+            const int n_pool = (int)rga.cnt[(size_t)rga.segs * NTOP + seg];
+            const unsigned long long* pool = rga.pool + (size_t)seg * N;
+            for (int j = tid; j < n_pool; j += BKT_THREADS) {
+                const unsigned long long p = pool[j];
+                if ((int)(bucket_id((unsigned int)(p >> 32), sp.kmin, sp.scale) >> TOP_SHIFT) == bucket)
+                    gdst[rga.capb + atomicAdd(&front_s[BKT_WAVES], 1u)] = p;
+            }
+            __threadfence_block();
+            __syncthreads();
+            src = gdst;
+            collected = true;
+        }
+    }
     start = __builtin_amdgcn_readfirstlane(start);
     longest = __builtin_amdgcn_readfirstlane(longest);
-    if (nb <= 0) return;   // uniform
     // position in run order -> (run, first pair of the run, pairs in front of the run)
     struct Where { int c; unsigned int before, base, len; };
     auto locate = [&](unsigned int idx) -> Where {
@@ -531,6 +750,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         return wv;
     };
     auto pair_at = [&](unsigned int idx) -> unsigned long long {
+        if constexpr (REGION) return src[idx];
         const Where wv = locate(idx);
         return seg_pairs[(size_t)wv.base + (idx - wv.before)];
     };
@@ -548,7 +768,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
 #ifdef HEPT_BKT_NO_BY_RUN
     const bool by_run = false;
 #else
-    const bool by_run = n_chunks <= HEPT_WAVE && n_chunks <= BKT_THREADS && longest <= (ITEMS << lpr_log);   // uniform
+    const bool by_run = !REGION && n_chunks <= HEPT_WAVE && n_chunks <= BKT_THREADS && longest <= (ITEMS << lpr_log);   // uniform
 #endif
     unsigned long long mine[ITEMS];
     unsigned long long vmask = 0;   // bit u: slot u holds a pair (ITEMS <= 64)
@@ -576,7 +796,8 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         for (int u = 0; u < ITEMS; ++u) {
             if (ITEMS <= 16 && u >= n_slots) break;   // (longer register tiles: the early exit would keep the loop from unrolling)
             const int i = u * BKT_THREADS + tid;
-            mine[u] = i < n_reg ? pair_at((unsigned int)i) : 0ull;
+            if (REGION && u < SPEC) mine[u] = i < n_reg ? (collected ? src[i] : spec[u]) : 0ull;
+            else mine[u] = i < n_reg ? pair_at((unsigned int)i) : 0ull;
             vmask |= i < n_reg ? 1ull << u : 0ull;
         }
     }
@@ -620,7 +841,7 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         }
         __syncthreads();
     };
-    __syncthreads();   // the bins are zero in every wave's view
+    if constexpr (!REGION) __syncthreads();   // the bins are zero in every wave's view (REGION: the barrier of the front sums)
     int n_low = nb;  // pairs in the lower half of the id bins (two-pass buckets)
     if (in_lds) {
 #pragma unroll
@@ -719,6 +940,33 @@ __global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned
         __syncthreads();
         rank_all(g, 0, nb);
     }
+}
+
+template <int CAP, bool EMBED, int MAXR, bool REGION>
+__global__ __launch_bounds__(BKT_THREADS) void bucket_sort_kernel(const unsigned long long* __restrict__ pairs,
+                                                                  unsigned long long* __restrict__ scratch,
+                                                                  const SegParams* __restrict__ seg_params,
+                                                                  const unsigned int* __restrict__ tab, int N,
+                                                                  int n_chunks, int* __restrict__ pos_out,
+                                                                  RowsJob rows, RegionArgs rga) {
+    if ((int)blockIdx.y < rows.vy) {   // uniform: a rider workgroup (the first rows of the grid: dispatched first)
+        const unsigned int wg = blockIdx.y * gridDim.x + blockIdx.x, n_wgs = (unsigned int)rows.vy * gridDim.x;
+        if (rows.H == 8) rows_rider<8>(rows, wg, n_wgs);
+        else rows_rider<0>(rows, wg, n_wgs);
+        return;
+    }
+#ifdef HEPT_RIDERS_ONLY   // measurement builds: what the riders cost by themselves
+    if (rows.vy > 0) return;
+#endif
+    __shared__ unsigned long long tile_s[CAP];
+    __shared__ __attribute__((aligned(16))) unsigned int binarr_s[LOBINS + 4];
+    __shared__ unsigned int wsum_s[BKT_WAVES];
+    __shared__ unsigned int roff_s[REGION ? 1 : MAXR + 1];
+    __shared__ unsigned int rbase_s[REGION ? 1 : MAXR + 1];
+    __shared__ unsigned int front_s[REGION ? BKT_WAVES + 1 : 1];
+    const BucketLds lds{tile_s, binarr_s, wsum_s, roff_s, rbase_s, front_s};
+    bucket_body<CAP, EMBED, MAXR, REGION, true>(pairs, scratch, seg_params, tab, N, n_chunks, pos_out, rga,
+                                                (int)blockIdx.y - rows.vy, (int)blockIdx.x, lds);
 }
 
 // src variant: per (table, head) upper bound of the shift in units of span: max_n (phi * cfac + eta), written into
@@ -990,57 +1238,89 @@ int launch_small_sort(int segs, hipStream_t st, const float* qproj, const float*
 
 // the two passes shared by hept_sort_tables and hept_segmented_argsort
 struct SortBuffers {
-    unsigned long long *pa, *pb;   // pairs (chunk runs), scratch of the streaming path
+    unsigned long long *pa, *pb;   // pairs (chunk runs; REGION: the overflow pools), scratch of the streaming path
     unsigned int* tab;             // [segs][n_chunks][257] digit offsets of every chunk's run
     unsigned int* range;           // [segs][2] ordered-uint finite min / ~max of raw keys (hept_segmented_argsort)
     SegParams* params;
+    RegionArgs rg;                 // REGION layout (rg.region == nullptr: segments outside its range)
+    size_t zero_bytes;             // bytes at rg.cnt that must be zero when KA starts
+    size_t bytes;
 };
+inline bool region_sort_off() {   // HEPT_SORT_LINEAR=1: the round-3 layout (chunk runs + run tables) for A/B runs; read once
+    static const bool off = [] { const char* e = getenv("HEPT_SORT_LINEAR"); return e && *e && *e != '0'; }();
+    return off;
+}
+inline bool region_range(int N) { return N > SMALL_CAP && N <= REGION_MAX_N; }
 SortBuffers carve_sort(void* sort_ws, int segs, int N) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     char* ws = reinterpret_cast<char*>(sort_ws);
-    SortBuffers b;
-    b.pa = reinterpret_cast<unsigned long long*>(ws);
-    ws += al((size_t)segs * N * 8);
-    b.pb = reinterpret_cast<unsigned long long*>(ws);
-    ws += al((size_t)segs * N * 8);
-    b.tab = reinterpret_cast<unsigned int*>(ws);
-    ws += al((size_t)segs * n_chunks * TAB * 4);
-    b.range = reinterpret_cast<unsigned int*>(ws);
-    ws += al((size_t)segs * 8);
-    b.params = reinterpret_cast<SegParams*>(ws);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* r = ws ? ws + off : nullptr;
+        off += al(bytes);
+        return r;
+    };
+    SortBuffers b{};
+    b.pa = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
+    b.pb = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
+    b.tab = reinterpret_cast<unsigned int*>(take((size_t)segs * n_chunks * TAB * 4));
+    b.range = reinterpret_cast<unsigned int*>(take((size_t)segs * 8));
+    b.params = reinterpret_cast<SegParams*>(take((size_t)segs * sizeof(SegParams)));
+    if (region_range(N)) {
+        b.rg.capb = region_cap(N);
+        b.rg.pitch = region_pitch(b.rg.capb);
+        b.rg.segs = segs;
+        b.zero_bytes = ((size_t)segs * NTOP + segs) * 4;
+        b.rg.cnt = reinterpret_cast<unsigned int*>(take(b.zero_bytes));
+        b.rg.gathered = reinterpret_cast<unsigned long long*>(take((size_t)segs * N * 8));
+        b.rg.region = reinterpret_cast<unsigned long long*>(take((size_t)segs * NTOP * b.rg.pitch * 8));
+        b.rg.pool = b.pa;
+    }
+    b.bytes = off;
     return b;
 }
 constexpr int BKT_CAP_SMALL = HEPT_BKT_CAP;  // LDS tile: the average bucket is N/NTOP
 constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segments (average bucket up to ~3000 pairs)
+static_assert(REGION_MAX_N == NTOP * (BKT_CAP_SMALL / 2), "the REGION layout serves exactly the small-tile bucket kernel");
+// `zeroed`: the caller has already zeroed b.zero_bytes at b.rg.cnt on this stream (the row builder of the same forward)
 template <int MODE, bool EMBED>
-void run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj,
-                     const float* kproj, const int64_t* codes, const float* eta, const float* phi, const float* cfac,
-                     const float* minmax, int H, int t0, int Tl, const int* seg_len, const float* bounds,
-                     const RowsJob& rows) {
+int run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj,
+                    const float* kproj, const int64_t* codes, const float* eta, const float* phi, const float* cfac,
+                    const float* minmax, int H, int t0, int Tl, const int* seg_len, const float* bounds,
+                    const RowsJob& rows, bool zeroed) {
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
-    hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes, eta,
-                       phi, cfac, minmax, bounds ? nullptr : b.range, bounds ? bounds[0] : 0.f, bounds ? bounds[1] : 0.f, N,
-                       H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab);
     const dim3 grid4(NTOP, segs + rows.vy);   // rider rows first
+    if (b.rg.region && !region_sort_off()) {
+        if (!zeroed && hipMemsetAsync(b.rg.cnt, 0, b.zero_bytes, st) != hipSuccess) return HEPT_ERR_LAUNCH;
+        hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED, true>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes,
+                           eta, phi, cfac, minmax, bounds ? nullptr : b.range, bounds ? bounds[0] : 0.f,
+                           bounds ? bounds[1] : 0.f, N, H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab, b.rg);
+        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED, 64, true>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb,
+                               b.params, b.tab, N, n_chunks, pos, rows, b.rg);
+        return HEPT_OK;
+    }
+    hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED, false>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes, eta,
+                       phi, cfac, minmax, bounds ? nullptr : b.range, bounds ? bounds[0] : 0.f, bounds ? bounds[1] : 0.f, N,
+                       H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab, RegionArgs{});
     if ((size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2))
-        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED, 64>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
-                           b.tab, N, n_chunks, pos, rows);
+        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED, 64, false>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
+                           b.tab, N, n_chunks, pos, rows, RegionArgs{});
     else
-        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_LARGE, EMBED, 1024>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb,
-                           b.params, b.tab, N, n_chunks, pos, rows);
+        hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_LARGE, EMBED, 1024, false>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb,
+                           b.params, b.tab, N, n_chunks, pos, rows, RegionArgs{});
+    return HEPT_OK;
 }
 template <int MODE>
-void run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj, const float* kproj,
-                const int64_t* codes, const float* eta, const float* phi, const float* cfac, const float* minmax, int H,
-                int t0, int Tl, const int* seg_len = nullptr, const float* bounds = nullptr,
-                const RowsJob& rows = RowsJob{}) {
+int run_passes(const SortBuffers& b, int segs, int N, int* pos, hipStream_t st, const float* qproj, const float* kproj,
+               const int64_t* codes, const float* eta, const float* phi, const float* cfac, const float* minmax, int H,
+               int t0, int Tl, const int* seg_len = nullptr, const float* bounds = nullptr,
+               const RowsJob& rows = RowsJob{}, bool zeroed = false) {
     if (N <= (1 << EMBED_SHIFT))
-        run_passes_impl<MODE, true>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len,
-                                    bounds, rows);
-    else
-        run_passes_impl<MODE, false>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len,
-                                     bounds, rows);
+        return run_passes_impl<MODE, true>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len,
+                                           bounds, rows, zeroed);
+    return run_passes_impl<MODE, false>(b, segs, N, pos, st, qproj, kproj, codes, eta, phi, cfac, minmax, H, t0, Tl, seg_len,
+                                        bounds, rows, zeroed);
 }
 
 // the job of the rider workgroups, from the description a caller in another translation unit hands over
@@ -1063,13 +1343,21 @@ RowsJob rows_job(const HeptRowsJob* r) {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static size_t sort_bytes(size_t segs, size_t N) {
-    const size_t n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
-    return 2 * align256(segs * N * 8) + align256(segs * n_chunks * TAB * 4) + align256(segs * 8) +
-           align256(segs * sizeof(SegParams));
-}
+static size_t sort_bytes(size_t segs, size_t N) { return carve_sort(nullptr, (int)segs, (int)N).bytes; }
 
 extern "C" size_t hept_sort_workspace_bytes(int N, int H, int Tl) { return sort_bytes((size_t)2 * Tl * H, N); }
+
+// internal (common.h): the block of `sort_ws` (for hept_sort_tables*_rows of 2*Tl*H segments of N keys) that has to be zero
+// when the sort starts -- *bytes == 0: none.  A caller whose preceding kernel zeroes it passes zeroed = true.
+void hept_sort_zero_block(void* sort_ws, int N, int H, int Tl, void** ptr, size_t* bytes) {
+    *ptr = nullptr;
+    *bytes = 0;
+    if (!sort_ws || N <= SMALL_CAP || region_sort_off()) return;
+    const SortBuffers b = carve_sort(sort_ws, 2 * Tl * H, N);
+    if (!b.rg.region) return;
+    *ptr = b.rg.cnt;
+    *bytes = b.zero_bytes;
+}
 
 // internal (common.h): the sort of N-key segments is the KA / KB pair, whose KB launch can carry the v rows
 // (segments of the small-tile bucket kernel only: the large-tile one runs two waves per SIMD at 218 VGPRs, and riders
@@ -1087,7 +1375,7 @@ extern "C" int hept_sort_tables(const float* qproj, const float* kproj, const in
 // internal (common.h): hept_sort_tables whose bucket-sort launch also writes the v rows described by `rows` (or null)
 int hept_sort_tables_rows(const float* qproj, const float* kproj, const int64_t* codes, const float* minmax, int N, int H,
                           int T, int t0, int Tl, void* sort_ws, int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows,
-                          void* stream) {
+                          void* stream, bool zeroed) {
     if (!qproj || !kproj || !codes || !minmax || !sort_ws || !qpos || !kpos) return HEPT_ERR_ARG;
     if (rows && (!rows->v || !rows->kvhat || rows->N != N || !hept_sort_carries_rows(N, rows->H, rows->D))) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
@@ -1097,9 +1385,9 @@ int hept_sort_tables_rows(const float* qproj, const float* kproj, const int64_t*
     if (N <= SMALL_CAP)
         return launch_small_sort<0>(segs, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, N, H, t0, Tl, qpos);
     const SortBuffers b = carve_sort(sort_ws, segs, N);
-    run_passes<0>(b, segs, N, qpos, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, H, t0, Tl, nullptr, nullptr,
-                  rows_job(rows));
-    return hept_launch_status();
+    const int rc = run_passes<0>(b, segs, N, qpos, st, qproj, kproj, codes, nullptr, nullptr, nullptr, minmax, H, t0, Tl,
+                                 nullptr, nullptr, rows_job(rows), zeroed);
+    return rc ? rc : hept_launch_status();
 }
 
 extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, const float* eta_idx,
@@ -1111,7 +1399,7 @@ extern "C" int hept_sort_tables_src(const float* qproj, const float* kproj, cons
 
 int hept_sort_tables_src_rows(const float* qproj, const float* kproj, const float* eta_idx, const float* phi_idx,
                               const float* cfac, float* minmax, int N, int H, int T, int t0, int Tl, void* sort_ws,
-                              int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows, void* stream) {
+                              int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows, void* stream, bool zeroed) {
     if (!qproj || !kproj || !eta_idx || !phi_idx || !cfac || !minmax || !sort_ws || !qpos || !kpos)
         return HEPT_ERR_ARG;
     if (rows && (!rows->v || !rows->kvhat || rows->N != N || !hept_sort_carries_rows(N, rows->H, rows->D))) return HEPT_ERR_ARG;
@@ -1124,9 +1412,9 @@ int hept_sort_tables_src_rows(const float* qproj, const float* kproj, const floa
     const SortBuffers b = carve_sort(sort_ws, segs, N);
     hipLaunchKernelGGL(src_bound_kernel, dim3(Tl * H), dim3(SORT_THREADS), 0, st, eta_idx, phi_idx, cfac, N, H, t0,
                        minmax);
-    run_passes<1>(b, segs, N, qpos, st, qproj, kproj, nullptr, eta_idx, phi_idx, cfac, minmax, H, t0, Tl, nullptr, nullptr,
-                  rows_job(rows));
-    return hept_launch_status();
+    const int rc = run_passes<1>(b, segs, N, qpos, st, qproj, kproj, nullptr, eta_idx, phi_idx, cfac, minmax, H, t0, Tl,
+                                 nullptr, nullptr, rows_job(rows), zeroed);
+    return rc ? rc : hept_launch_status();
 }
 
 extern "C" size_t hept_argsort_workspace_bytes(int S, int L) { return sort_bytes((size_t)S, (size_t)L); }
@@ -1146,8 +1434,9 @@ int segmented_argsort_impl(const float* keys, int S, int L, const int* seg_len, 
         if (hipMemsetAsync(b.range, 0xFF, (size_t)S * 8, st) != hipSuccess) return HEPT_ERR_LAUNCH;
         hipLaunchKernelGGL(raw_range_kernel, dim3(n_chunks, S), dim3(SORT_THREADS), 0, st, keys, L, seg_len, b.range);
     }
-    run_passes<2>(b, S, L, pos, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 1, seg_len, bounds);
-    return hept_launch_status();
+    const int rc = run_passes<2>(b, S, L, pos, st, keys, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 1, seg_len,
+                                 bounds);
+    return rc ? rc : hept_launch_status();
 }
 }  // namespace
 
