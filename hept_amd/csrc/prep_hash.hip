@@ -23,6 +23,9 @@ constexpr int PREP_THREADS = 256;
 // 8 chunks + one pad slot per head
 constexpr int PREP_WAVE_SLOTS = 64 * 8 + 8;
 constexpr int PREP_POINTS = 8;   // points per wave iteration; lane = (point = lane >> 3, head = lane & 7)
+#ifndef HEPT_PREP_CODE_SAMPLE
+#define HEPT_PREP_CODE_SAMPLE 8   // the q role looks at the AND codes of one tile in this many (see prep_role)
+#endif
 // LDS pitch (floats) of one head's alpha slab [e][TMAX] (TMAX = 4 or 8 table slots, template parameter): = 4 (mod 32), so that the 8 heads of a wave read
 // 8 disjoint bank groups (a plain E * 8 pitch put them on two groups: 4-way conflicts, 60 % of the LDS cycles)
 constexpr int alpha_pitch(int E, int TMAX) { return ((E * TMAX + 27) / 32) * 32 + 4; }
@@ -257,8 +260,11 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
             float cs[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) cs[c] = (live && !is_pad) ? coords[(size_t)n * C + c] : 0.f;
-            if (ROLE == 0 && codes) {
-                // largest AND code of this (table, head): bounds the sort-key range for sort_tables
+            if (ROLE == 0 && codes && (__builtin_amdgcn_readfirstlane(tile_i) % HEPT_PREP_CODE_SAMPLE) == 0) {   // (wave-uniform)
+                // largest AND code of this (table, head), from every HEPT_PREP_CODE_SAMPLE-th tile: it only sets the
+                // scale of the sort's bucket ids (keys beyond the bound share the last id: the sort is exact for ANY
+                // value here), so a sample's maximum serves as well as the true one -- and the row builder reads 1.4 MB
+                // of int64 codes instead of 11.5 MB at tracking-60k.  Deterministic (tiles, not random numbers).
 #pragma unroll
                 for (int t = 0; t < TMAX; ++t)
                     if (t < Tl && live) cm[t] = fmaxf(cm[t], __ll2float_ru(codes[((size_t)(t0 + t) * H + h) * N + n]));

@@ -1044,8 +1044,21 @@ constexpr int SMALL_ITEMS = SMALL_CAP / SMALL_THREADS;
 constexpr int SMALL_BINS = 4096;
 constexpr size_t SMALL_LDS = (size_t)SMALL_CAP * 8 + (SMALL_BINS + 1) * 4;
 
+// Round 5 -- Q workgroups per segment, split by id range (SMALL_SPLIT = 4): one workgroup per segment kept 48 of the 256
+// CUs busy for 13.7 us at tracking-6k, and most of that is the per-thread chain of LDS round trips of the scatter and
+// rank phases over six keys per thread.  Workgroup q of a segment forms ALL keys (the loads are the cheap part) but keeps
+// only those whose id falls into its quarter of the id range: it counts the keys below its range (their number is where
+// its own positions start), histograms / prefixes / scatters / ranks its own ~N/Q keys -- a quarter of the bins per
+// thread, a third of the rank slots.  Any split of a monotone id range gives the exact sort; a skewed one (all keys in one
+// quarter) degrades to the one-workgroup time.
+#ifndef HEPT_SMALL_SPLIT
+#define HEPT_SMALL_SPLIT 4
+#endif
+constexpr int SMALL_SPLIT = HEPT_SMALL_SPLIT;
+static_assert(SMALL_SPLIT >= 1 && SMALL_BINS % SMALL_SPLIT == 0 && (SMALL_BINS / SMALL_SPLIT) % SMALL_THREADS == 0,
+              "every thread owns the same number of a workgroup's bins");
 // MODE 0: key = proj + float(code) * span;  MODE 1: src variant (get_geo_shift);  MODE 2: raw keys (S segments of L)
-template <int MODE>
+template <int MODE, int Q>
 __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
     const float* __restrict__ qproj, const float* __restrict__ kproj, const int64_t* __restrict__ codes,
     const float* __restrict__ eta_idx, const float* __restrict__ phi_idx, const float* __restrict__ cfac,
@@ -1054,11 +1067,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned long long small_tile_s[];  // [SMALL_CAP] pairs, then bins
     __shared__ float red_s[3][SMALL_WAVES];
     __shared__ unsigned int wsum_s[SMALL_WAVES];
+    __shared__ unsigned int below_s[SMALL_WAVES];
     unsigned int* cur_s = reinterpret_cast<unsigned int*>(small_tile_s + SMALL_CAP);  // [0] stays 0; bin d at [d + 1]
     unsigned int* bin_s = cur_s + 1;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, seg = blockIdx.x;
+    constexpr int BQ = SMALL_BINS / Q;   // bins of this workgroup: ids [part * BQ, (part + 1) * BQ)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, seg = blockIdx.x / Q, part = blockIdx.x % Q;
     const int N = seg_len ? seg_len[seg] : N_stride;  // keys that take part (ragged argsort); N_stride = segment pitch
-    for (int i = tid; i < SMALL_BINS + 1; i += SMALL_THREADS) cur_s[i] = 0;
+    for (int i = tid; i < BQ + 1; i += SMALL_THREADS) cur_s[i] = 0;
 
     // MODE 0: the hashes and codes of this thread's keys are requested first -- they do not depend on the key range,
     // and the launch is one workgroup per segment: its length is this chain of dependent loads
@@ -1130,12 +1145,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
 
     // ---- keys -> pairs in registers, histogram of the id
     unsigned long long mine[SMALL_ITEMS];
+    unsigned int below = 0;   // keys of this thread whose id lies below the workgroup's range
     float cf = 0.f;
     if (MODE == 1) { const int th = seg % (Tl * H); cf = cfac[(size_t)(t0 + th / H) * H + th % H]; }
 #pragma unroll
     for (int u = 0; u < SMALL_ITEMS; ++u) {
         const int n = u * SMALL_THREADS + tid;
-        mine[u] = ~0ull;
+        mine[u] = ~0ull;   // (not a pair of this workgroup)
         if (n < N) {
             float key;
             if (MODE == 0) {
@@ -1156,13 +1172,23 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
                 key = proj[n];
             }
             const unsigned int ub = ordered_bits(key);
-            mine[u] = ((unsigned long long)ub << 32) | (unsigned int)n;
-            atomicAdd(&bin_s[bin_of(ub)], 1u);
+            const unsigned int b = bin_of(ub);
+            if (Q == 1 || b / BQ == (unsigned int)part) {
+                mine[u] = ((unsigned long long)ub << 32) | (unsigned int)n;
+                atomicAdd(&bin_s[b - part * BQ], 1u);
+            } else {
+                below += b < (unsigned int)(part * BQ) ? 1u : 0u;
+            }
         }
     }
+    if (Q > 1) {
+        below = hept_wave_sum(below);
+        if (lane == 0) below_s[w] = below;
+    }
     __syncthreads();
-    {   // exclusive prefix over the bins: thread owns 4 consecutive bins
-        constexpr int BPT = SMALL_BINS / SMALL_THREADS;
+    unsigned int n_mine;   // pairs of this workgroup
+    {   // exclusive prefix over the bins: thread owns BPT consecutive bins
+        constexpr int BPT = BQ / SMALL_THREADS;
         unsigned int c[BPT], tot = 0;
 #pragma unroll
         for (int u = 0; u < BPT; ++u) { c[u] = bin_s[BPT * tid + u]; tot += c[u]; }
@@ -1170,7 +1196,15 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
         if (lane == 63) wsum_s[w] = incl;
         __syncthreads();
         unsigned int run = incl - tot;
-        for (int ww = 0; ww < w; ++ww) run += wsum_s[ww];
+        n_mine = 0;
+        below = 0;
+#pragma unroll
+        for (int ww = 0; ww < SMALL_WAVES; ++ww) {
+            const unsigned int ws = wsum_s[ww];
+            run += ww < w ? ws : 0u;
+            n_mine += ws;
+            if (Q > 1) below += below_s[ww];
+        }
 #pragma unroll
         for (int u = 0; u < BPT; ++u) {
             bin_s[BPT * tid + u] = run;
@@ -1180,10 +1214,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SMALL_ITEMS; ++u)
-        if (u * SMALL_THREADS + tid < N)
-            small_tile_s[atomicAdd(&bin_s[bin_of((unsigned int)(mine[u] >> 32))], 1u)] = mine[u];
+        if (mine[u] != ~0ull)
+            small_tile_s[atomicAdd(&bin_s[bin_of((unsigned int)(mine[u] >> 32)) - part * BQ], 1u)] = mine[u];
     __syncthreads();
-    int* out = pos_out + (size_t)seg * N_stride;
+    n_mine = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_mine);
+    const int n_slots = ((int)n_mine + SMALL_THREADS - 1) / SMALL_THREADS;   // rank slots in use (uniform): ~N / (Q * threads)
+    int* out = pos_out + (size_t)seg * N_stride + below;
     // rank inside the id group.  The launch is one workgroup per segment, so its length is this thread's chain: the
     // SMALL_ITEMS positions of a thread are independent -- their tile reads, group bounds and first group rounds are
     // issued side by side (a loop over them was SMALL_ITEMS dependent chains of four LDS round trips each)
@@ -1191,17 +1227,20 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
     int g0v[SMALL_ITEMS], g1v[SMALL_ITEMS], smv[SMALL_ITEMS];
 #pragma unroll
     for (int u = 0; u < SMALL_ITEMS; ++u) {
+        if (u >= n_slots) break;
         const int i = u * SMALL_THREADS + tid;
-        pv[u] = small_tile_s[i < N ? i : 0];
+        pv[u] = small_tile_s[i < (int)n_mine ? i : 0];
     }
 #pragma unroll
     for (int u = 0; u < SMALL_ITEMS; ++u) {
-        const unsigned int d = bin_of((unsigned int)(pv[u] >> 32));
+        if (u >= n_slots) break;
+        const unsigned int d = bin_of((unsigned int)(pv[u] >> 32)) - part * BQ;
         g0v[u] = (int)cur_s[d];
         g1v[u] = (int)cur_s[d + 1];
     }
 #pragma unroll
     for (int u = 0; u < SMALL_ITEMS; ++u) {   // first round of every group: up to 4 members
+        if (u >= n_slots) break;
         unsigned long long q[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) q[e] = small_tile_s[min(g0v[u] + e, g1v[u] - 1)];
@@ -1212,6 +1251,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
     }
 #pragma unroll
     for (int u = 0; u < SMALL_ITEMS; ++u) {
+        if (u >= n_slots) break;
         const int i = u * SMALL_THREADS + tid;
         int smaller = smv[u];
         for (int j = g0v[u] + 4; j < g1v[u]; j += 4) {   // larger groups: further rounds
@@ -1221,7 +1261,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_sort_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) smaller += (j + e < g1v[u]) && (q[e] < pv[u]);
         }
-        if (i < N) out[g0v[u] + smaller] = (int)(unsigned int)pv[u];
+        if (i < (int)n_mine) out[g0v[u] + smaller] = (int)(unsigned int)pv[u];
     }
 }
 
@@ -1229,9 +1269,19 @@ template <int MODE>
 int launch_small_sort(int segs, hipStream_t st, const float* qproj, const float* kproj, const int64_t* codes,
                       const float* eta, const float* phi, const float* cfac, const float* minmax, int N, int H, int t0,
                       int Tl, int* pos, const int* seg_len = nullptr) {
-    static LdsRaised raised;
-    if (hept_raise_lds(raised, reinterpret_cast<const void*>(small_sort_kernel<MODE>), SMALL_LDS)) return HEPT_ERR_LAUNCH;
-    hipLaunchKernelGGL(small_sort_kernel<MODE>, dim3(segs), dim3(SMALL_THREADS), SMALL_LDS, st, qproj, kproj, codes, eta,
+    // one workgroup per segment when the launch already fills the chip, or when the segments are too short to be worth
+    // splitting (HEPT_SMALL_NO_SPLIT=1: always; A/B runs)
+    static const bool no_split = [] { const char* e = getenv("HEPT_SMALL_NO_SPLIT"); return e && *e && *e != '0'; }();
+    if (SMALL_SPLIT > 1 && !no_split && segs <= 128 && N > SMALL_THREADS) {
+        static LdsRaised raised;
+        if (hept_raise_lds(raised, reinterpret_cast<const void*>(small_sort_kernel<MODE, SMALL_SPLIT>), SMALL_LDS)) return HEPT_ERR_LAUNCH;
+        hipLaunchKernelGGL((small_sort_kernel<MODE, SMALL_SPLIT>), dim3(segs * SMALL_SPLIT), dim3(SMALL_THREADS), SMALL_LDS, st,
+                           qproj, kproj, codes, eta, phi, cfac, minmax, N, H, t0, Tl, pos, seg_len);
+        return hept_launch_status();
+    }
+    static LdsRaised raised1;
+    if (hept_raise_lds(raised1, reinterpret_cast<const void*>(small_sort_kernel<MODE, 1>), SMALL_LDS)) return HEPT_ERR_LAUNCH;
+    hipLaunchKernelGGL((small_sort_kernel<MODE, 1>), dim3(segs), dim3(SMALL_THREADS), SMALL_LDS, st, qproj, kproj, codes, eta,
                        phi, cfac, minmax, N, H, t0, Tl, pos, seg_len);
     return hept_launch_status();
 }

@@ -79,7 +79,8 @@ int hept_rpe_scale(const float* w_rpe, int H, int D, int C, int K, float* sqrt_w
 /* replaces prep_qk (example/hept.py:25-27), the head-major rearranges (:57-59), E2LSH.forward
  * (example/hept_utils.py:45-47) and the min/max of lsh_mapping (:66-70).
  * minmax: (Tl, H, HEPT_PREP_GRID, 4) f32 per-workgroup partials [hash min, hash max, largest AND
- * code, 0]; reduced by hept_sort_tables (the code maximum bounds the sort-key range). */
+ * code seen, 0]; reduced by hept_sort_tables.  The code maximum only scales the sort's bucket ids (the
+ * sort is exact for any value), so the tuned kernels take it from a fixed sample of the points. */
 /* raw_size < N selects the padding rule of the reference's src variant (src/models/attention/hept.py:89-96):
  * rows >= raw_size are zero rows that hash to +inf (raw_size == N: no such rows).  codes may be NULL (src
  * variant: the key range then comes from hept_sort_tables_src). */

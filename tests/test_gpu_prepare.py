@@ -152,6 +152,26 @@ def test_segmented_argsort_ragged(gpu_device):
             assert torch.equal(pos[s, :n], torch.sort(keys[s, :n], stable=True).indices), (s_, l_, s, n)
 
 
+@pytest.mark.parametrize("n", [9000, 60032, 131072])
+def test_segmented_argsort_region_overflow_pool(gpu_device, n):
+    """Round 5 layout: every (segment, bucket) owns a region of fixed capacity (2 048 pairs up to 65 536 keys); runs
+    that do not fit go to the segment's overflow pool and the bucket collects them from there.  Three hot buckets per
+    segment far above the capacity (pairs of SEVERAL buckets interleave in the pool, several chunks overflow into it),
+    one of them a pile of equal keys, next to ordinary buckets; plus a segment that is one pile."""
+    g = torch.Generator().manual_seed(17)
+    keys = torch.rand(4, n, generator=g)
+    hot = n // 5
+    for s_ in range(3):
+        perm = torch.randperm(n, generator=g)
+        keys[s_, perm[:hot]] = 0.25 + torch.rand(hot, generator=g) / 300            # one bucket, spread
+        keys[s_, perm[hot:2 * hot]] = 0.5 + torch.rand(hot, generator=g) / 2000      # one bucket, its lower part
+        keys[s_, perm[2 * hot:3 * hot]] = 0.75                                       # one id group
+        keys[s_, 0], keys[s_, 1] = 0.0, 1.0
+    keys[3] = -2.5
+    pos = ops.segmented_argsort(keys.to(gpu_device)).long().cpu()
+    assert torch.equal(pos, torch.sort(keys, dim=-1, stable=True).indices)
+
+
 @pytest.mark.parametrize("spread", ["whole_bucket", "lower_half", "one_bin"])
 def test_segmented_argsort_oversize_bucket_paths(gpu_device, spread):
     """60 000 uniform keys + 1 500 extra keys inside one of the 256 top-level buckets: the bucket holds ~1 730 pairs,
