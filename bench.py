@@ -139,6 +139,37 @@ def algorithmic_flops(n, h, d, c, t, b):
     return 2 * t * h * n * b * (2 * d + c)
 
 
+SMALL_SORT_MAX = 6144      # csrc/sort_tables.hip SMALL_CAP: clouds up to this size sort in one launch
+RIDERS_MAX = 131072        # ... and up to this size the bucket-sort launch can carry the v rows (hept_sort_carries_rows)
+
+
+def step_kernels(n, h, d, c, t, precision):
+    """Algorithmic bytes of every launch of one hept_forward: what each kernel has to read and
+    write once, whatever the caches do.  Returns [(stage key, kernel name, bytes)] in launch order; stage keys are those of
+    ops.profile_read()."""
+    s = 4 if precision == "fp32" else 2
+    row = 32 * s                                              # one q^ / k^ / v row
+    keys = 2 * t * h * n                                      # sort keys: q and k segments
+    v_rows = n * h * d * 4 + n * h * row                      # v in, v halves of the kvhat rows out
+    riders = (t >= 2 or precision == "fp32") and SMALL_SORT_MAX < n <= RIDERS_MAX   # csrc/capi.hip run_begin
+    prep = 2 * n * h * d * 4 + 2 * n * c * 4 + t * h * n * 8 // 8 + 2 * n * h * row + keys * 4
+    packed = precision != "fp32" and d == 24
+    combine = t * n * h * (64 if packed else 128) + n * d * 4
+    attn = algorithmic_bytes(n, h, d, c, t, s)
+    attn_name = "block_attn_split_kernel" if precision == "fp32" else "block_attn_kernel"
+    if n <= SMALL_SORT_MAX:
+        return [("prep_hash", "prep_hash_kernel (q, k, v roles)", prep + v_rows),
+                ("sort_tables", "small_sort_kernel", keys * 4 + t * h * n * 8 + keys * 4),
+                ("block_attn", attn_name, attn), ("combine", "combine_out_kernel", combine)]
+    chunk = keys * 4 + t * h * n * 8 + keys * 8               # hashes, int64 codes (once per (table, head)), pairs out
+    bucket = keys * 8 + keys * 4                               # pairs in, positions out
+    return [("prep_hash", "prep_hash_kernel (q, k roles)" if riders else "prep_hash_kernel (q, k, v roles)",
+             prep + (0 if riders else v_rows)),
+            ("chunk_sort", "chunk_sort_kernel", chunk),
+            ("bucket_sort", "bucket_sort_kernel + v-row riders" if riders else "bucket_sort_kernel", bucket + (v_rows if riders else 0)),
+            ("block_attn", attn_name, attn), ("combine", "combine_out_kernel", combine)]
+
+
 def cpu_baseline(inp, block_size, min_seconds=10.0):
     """The oracle (CPU restatement of the reference, fp32, all host threads) timed on this box: kind 'port'."""
     import torch
@@ -224,28 +255,40 @@ def launched_kernel(precision, block_size=128, head_dim=24):
     return f"block_attn_kernel<{nkt},true,{p16},{'true' if precision == 'mixed16' else 'false'},{full}>"
 
 
-def pmc_record(precision):
-    """Per-launch PMC figures of the block-attention kernel from profiles/attn_traffic.json (tools/pmc.sh passes): HBM
-    traffic in bytes and the fraction of the kernel's cycles the matrix pipe was busy -- counters cannot be collected
-    inside an un-profiled run, so they are copied, but ONLY when the record belongs to this build: same digest of the
-    kernel sources and the same template instance as the one this run launches.  Returns (traffic, busy, source)."""
+def pmc_record(precision, block_size=128, head_dim=24):
+    """Per-launch PMC figures of the block-attention kernel from profiles/attn_traffic.json (tools/pmc.sh /
+    tools/pmc_shapes.sh passes): HBM traffic in bytes, the fraction of the kernel's cycles the matrix pipe was busy and
+    the fraction the vector ALUs were issuing -- counters cannot be collected inside an un-profiled run, so they are
+    copied, but ONLY when the record belongs to this build: same digest of the kernel sources and the same template
+    instance as the one this run launches.  Returns (record dict or None, source)."""
     tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
-    src = {"file": "profiles/attn_traffic.json", "kernel_launched": launched_kernel(precision)}
+    key = launched_kernel(precision, block_size, head_dim)
+    src = {"file": "profiles/attn_traffic.json", "kernel_launched": key}
     try:
         rec = json.load(open(tpath))
     except Exception as exc:  # noqa: BLE001
         src["refused"] = f"unreadable: {exc!r}"
-        return None, None, src
-    kernel = rec.get(precision + "_kernel")
-    src.update(kernel_measured=kernel, git_head=rec.get("git_head"), source_sha256=rec.get("source_sha256"),
-               command=rec.get("command"))
+        return None, src
+    src.update(git_head=rec.get("git_head"), source_sha256=rec.get("source_sha256"))
     if rec.get("source_sha256") != attn_source_sha256():
-        src["refused"] = "the record's source digest is not this tree's (re-run tools/pmc.sh + tools/make_traffic.py)"
-        return None, None, src
-    if not isinstance(kernel, str) or src["kernel_launched"] not in kernel.replace(" ", ""):
-        src["refused"] = "the record was taken from another kernel template than the one this run launches"
-        return None, None, src
-    return rec.get(precision), rec.get(precision + "_mfma_busy_frac"), src
+        src["refused"] = "the record's source digest is not this tree's (re-run tools/pmc.sh, tools/pmc_shapes.sh + tools/make_traffic.py)"
+        return None, src
+    ent = (rec.get("by_kernel") or {}).get(key)
+    if not ent:
+        src["refused"] = "no PMC pass for this kernel template"
+        return None, src
+    src.update(kernel_measured=ent.get("kernel"), command=ent.get("command"))
+    return ent, src
+
+
+def bound_from_counters(ent, kernel_ms):
+    """Which resource the kernel sits closest to, from its counters and this run's duration: HBM (traffic over the
+    measured copy rate) against instruction issue (vector ALU + matrix pipe shares of the kernel's cycles -- the two
+    share a wave's issue slot).  The roofline contract knows two bounds: issue-bound is reported as "mfma"."""
+    hbm = ent["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_COPY_GBS
+    issue = (ent.get("valu_issue_frac") or 0.0) + (ent.get("mfma_busy_frac") or 0.0)
+    return ("hbm" if hbm >= issue else "mfma"), {"hbm_frac_of_copy_on_traffic": hbm, "valu_issue_frac": ent.get("valu_issue_frac"),
+                                                  "mfma_busy_frac": ent.get("mfma_busy_frac"), "issue_frac": issue}
 
 
 def worker(args) -> int:
@@ -376,23 +419,68 @@ def worker(args) -> int:
 
     def roofline(n, c, tables, precision, attn_ms, n_rec, block_size=B):
         """HBM roofline of the block-attention kernel: algorithmic bytes per launch / mean launch duration.  The f32
-        kernel issues bf16 MFMAs (split products) and is bound by its gathers and scatters as well, so both precisions
-        are priced against HBM; ``mfma_busy_frac`` (PMC, profiles/) is the matrix pipe's share of the kernel's cycles
-        (counters exist for the headline shape only: other block sizes carry traffic = null)."""
+        kernel issues bf16 MFMAs (split products); ``bound`` is read off the kernel's counters (profiles/attn_traffic.json,
+        one PMC record per kernel template: HBM traffic against vector + matrix issue) when a record of this build
+        exists, and is "hbm" with ``traffic`` null otherwise."""
         tile_bytes = 4 if precision == "fp32" else 2
         nbytes = algorithmic_bytes(n, H, D, c, tables, tile_bytes)
         ach = nbytes / (attn_ms * 1e-3) / 1e9
-        if block_size == B:
-            traffic, busy, source = pmc_record(precision)
-        else:
-            traffic, busy, source = None, None, {"kernel_launched": launched_kernel(precision, block_size), "refused": "no PMC pass for this shape"}
+        ent, source = pmc_record(precision, block_size)
+        bound, evidence = ("hbm", None) if ent is None else bound_from_counters(ent, attn_ms)
         flops = algorithmic_flops(n, H, D, c, tables, block_size)
-        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "frac_of_copy": ach / HBM_COPY_GBS, "copy_peak": HBM_COPY_GBS,
+        return {"bound": bound, "bound_evidence": evidence, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "frac_of_copy": ach / HBM_COPY_GBS, "copy_peak": HBM_COPY_GBS,
                 "kernel": "block_attn_kernel" if precision != "fp32" else "block_attn_split_kernel",
-                "kernel_ms": attn_ms, "event_samples": n_rec, "algorithmic_bytes": nbytes, "traffic": traffic,
-                "traffic_source": source, "mfma_busy_frac": busy,
+                "kernel_ms": attn_ms, "event_samples": n_rec, "algorithmic_bytes": nbytes,
+                "traffic": ent["traffic"] if ent else None, "traffic_source": source,
+                "mfma_busy_frac": ent.get("mfma_busy_frac") if ent else None,
                 "algorithmic_tflops": flops / (attn_ms * 1e-3) / 1e12, "mfma_bf16_peak_tflops": MFMA_BF16_PEAK_TF}
+
+    _pair_cost = []
+
+    def event_pair_ms():
+        """what an event pair around NOTHING reads on this stream (median of 20): the bracket's own cost is inside every
+        event-timed stage (the rocprofv3 kernel trace in profiles/ shows the kernels shorter by about this much)"""
+        if not _pair_cost:
+            gaps = []
+            for _ in range(20):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                e1.record()
+                torch.cuda.synchronize()
+                gaps.append(e0.elapsed_time(e1))
+            _pair_cost.append(sorted(gaps)[len(gaps) // 2])
+        return _pair_cost[0]
+
+    def whole_step(step, n, c, tables, precision, ms_per_step, steps=60):
+        """Every launch of the step, not only the dominant one: an extra, untimed pass with all stages bracketed by HIP
+        events (hept_profile mode 2), the bracket's own cost taken off each stage, against the launch's algorithmic
+        bytes -- and the whole step's bytes over the TIMED step time (``step_roofline``)."""
+        ops.profile_enable(2, steps + 2)
+        fence()
+        for _ in range(steps):
+            step()
+        fence()
+        ms, cnt = ops.profile_read()
+        ops.profile_enable(1, (max(args.steps, sub_cap) + 2) * (8 if multi else 1), stride=NO_SAMPLES)
+        if not cnt:
+            return {}
+        per = {k: v / cnt for k, v in ms.items()}
+        per["bucket_sort"] = per["sort_tables"] - per["chunk_sort"]
+        pair = event_pair_ms()
+        kernels, total = [], 0
+        for key, name, nbytes in step_kernels(n, H, D, c, tables, precision):
+            # (a chain of stages shares its events: every stage is bounded by two of them but each event bounds two stages,
+            #  so a stage carries about half of what a lone pair costs -- with this the five launches add up to the timed,
+            #  un-bracketed step within 1 %)
+            k_ms = max(per[key] - pair / 2, 1e-6)
+            gbs = nbytes / (k_ms * 1e-3) / 1e9
+            kernels.append({"name": name, "ms": k_ms, "algorithmic_bytes": nbytes, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+            total += nbytes
+        gbs = total / (ms_per_step * 1e-3) / 1e9
+        return {"kernels": kernels, "kernels_note": f"HIP-event stage times of {cnt} extra untimed steps minus half of a lone event pair's {pair * 1e3:.1f} us",
+                "step_roofline": {"bound": "hbm", "algorithmic_bytes": total, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": gbs / HBM_PEAK_GBS, "frac_of_copy": gbs / HBM_COPY_GBS}}
 
     def exchange_record(attn, step, steps=30):
         """What ran between the GPUs, said by the objects that ran it: the transport and head groups after the ladder
@@ -480,7 +568,11 @@ def worker(args) -> int:
                 _, attn32, step32 = build(tables_per_gpu, "fp32")
                 el, ams, nrec = measure(step32, sub_steps, sub_warm)
                 sub["fp32"] = {"ms_per_step": el / sub_steps * 1e3, "value": n_raw / (el / sub_steps), "unit": "points/s",
-                               "steps": sub_steps, "dtype": "f32", "roofline": roofline(n, C, tables_per_gpu, "fp32", ams, nrec)}
+                               "steps": sub_steps,
+                               "dtype": "f32 rows and accumulation; tile products as split-bf16 MFMAs (q^.k^: 6 terms, P.V: P in two bf16 "
+                                        "pieces = 16 significand bits); precision='fp32_mfma' is the exact f32 mode",
+                               "roofline": roofline(n, C, tables_per_gpu, "fp32", ams, nrec)}
+                sub["fp32"].update(whole_step(step32, n, C, tables_per_gpu, "fp32", el / sub_steps * 1e3))
                 del attn32, step32
                 # mixed16 (fp16 q^/k^ rows, bf16 weights and values): the 16-bit mode whose EVERY row stays within
                 # 2.5e-2 of the fp32 reference's row scale (bf16: 1e-1 on trained weights), at the same speed
@@ -495,8 +587,10 @@ def worker(args) -> int:
                 # c2 (tracking-6k), c5 (pileup batch, block 256) and b100 = the headline cloud at the reference's own
                 # block_size 100 (src/configs/tracking/tracking_trans_hept.yaml:12).  Short clouds are latency-bound:
                 # their roofline fraction says how far a 40 us forward is from streaming its bytes.
-                for key, wl, bs in (("c1", "example-4k", None), ("c2", "tracking-6k", None), ("c5", "pileup-8clouds", None),
-                                    ("b100", WORKLOAD, 100)):
+                # c2x10: ten tracking-6k clouds in ONE call through the batch index of the AND code -- the way the
+                # reference runs small clouds (example/transformer.py:35-63), at the per-point rate of the 60k cloud
+                for key, wl, bs in (("c1", "example-4k", None), ("c2", "tracking-6k", None), ("c2x10", "tracking-6k-x10", None),
+                                    ("c5", "pileup-8clouds", None), ("b100", WORKLOAD, 100)):
                     rec = {"workload": wl + (f" at block_size={bs}" if bs else "")}
                     for prec in ("fp32", "bf16"):
                         inp_s, attn_s, step_s = build(None, prec, wl, bs)
@@ -504,15 +598,20 @@ def worker(args) -> int:
                         ns, cs, ts = inp_s["q"].shape[0], inp_s["coords"].shape[1], inp_s["alpha"].shape[2]
                         # short clouds are bound by the host's launch rate (33 us of issue per forward), and a 10 ms
                         # region is at the mercy of one scheduling hiccup of a shared host: median of three regions
-                        runs = sorted((measure(step_s, sub_steps, sub_warm) for _ in range(3 if ns < 20000 else 1)),
-                                      key=lambda r: r[0])
+                        # (three regions for the long clouds as well: one hiccup -- an allocator call of the module built
+                        #  before, a scheduling pause of the host -- doubled a 40 ms region in one run of round 5)
+                        runs = sorted((measure(step_s, sub_steps, sub_warm) for _ in range(3)), key=lambda r: r[0])
                         el, ams, nrec = runs[len(runs) // 2]
                         roof_s = roofline(ns, cs, ts, prec, ams, nrec, bsz)
                         rec[prec] = {"ms_per_step": el / sub_steps * 1e3, "value": inp_s["n_raw"] / (el / sub_steps),
                                      "unit": "points/s", "steps": sub_steps, "n_raw": inp_s["n_raw"], "n_padded": ns,
                                      "block_size": bsz, "n_hashes": ts, "regions": len(runs),
-                                     "roofline": {k: roof_s[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
-                                                                         "kernel_ms", "algorithmic_bytes")}}
+                                     "roofline": {k: roof_s[k] for k in ("bound", "bound_evidence", "achieved", "peak", "unit", "frac",
+                                                                         "kernel", "kernel_ms", "algorithmic_bytes", "traffic",
+                                                                         "mfma_busy_frac")}}
+                        rec[prec]["roofline"]["kernel_launched"] = roof_s["traffic_source"]["kernel_launched"]
+                        if roof_s["traffic"] is None:
+                            rec[prec]["roofline"]["traffic_refused"] = roof_s["traffic_source"].get("refused")
                         del attn_s, step_s
                     sub[key] = rec
             if tables_per_gpu != 1:
@@ -564,22 +663,13 @@ def worker(args) -> int:
     line = None
     if rank == 0:
         roof = roofline(n, C, tables_per_gpu, args.precision, attn_ms, n_rec)
-        # what an event pair around NOTHING reads on this stream: the bracket's own cost is inside kernel_ms (the
-        # rocprofv3 kernel trace in profiles/ shows the kernel itself shorter by about this much)
-        gaps = []
-        for _ in range(20):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            torch.cuda.synchronize()
-            gaps.append(e0.elapsed_time(e1))
-        roof["event_pair_overhead_ms"] = sorted(gaps)[len(gaps) // 2]
+        roof["event_pair_overhead_ms"] = event_pair_ms()
         n_tables = tables_per_gpu * world
         line = {
             "metric": "attention-fwd points/sec", "value": world * n_raw / (elapsed / args.steps), "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": "bf16" if args.precision == "bf16" else "f32 (split-bf16 tile products)", "data": "synthetic",
             "config": {"workload": f"{WORKLOAD}: N_raw={n_raw} padded N={n}, block_size={B}, n_hashes={tables_per_gpu}/GPU "
                                    f"({n_tables} total), H={H}, D={D}, C={C}, tiles {args.precision}",
                        "parallelism": f"tables sharded {tables_per_gpu}/GPU over {world} GPU(s)" +
@@ -594,6 +684,10 @@ def worker(args) -> int:
         }
         if exch:
             line["exchange"] = exch
+    if not multi:
+        ws = whole_step(step, n, C, tables_per_gpu, args.precision, ms_per_step)
+        if rank == 0:
+            line.update(ws)
     del attn, step
     if multi:
         sub = sub_records()

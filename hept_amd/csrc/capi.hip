@@ -50,12 +50,15 @@ Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
 }
 
 // ---- optional stage timing (hept_profile_*): a pool of HIP events recorded on the caller's stream
-constexpr int PROF_SLOTS = 7;   // events per call: 6 stages (the table-sharded call has two more than hept_forward)
+constexpr int PROF_SLOTS = 8;   // events per call: 6 stages (the table-sharded call has two more than hept_forward) + the
+                                // mark between the sort's two launches (PROF_SORT_MID, outside the chain of stages)
+constexpr int PROF_SORT_MID = 7;
 struct Profiler {
     int mode = 0, max_calls = 0, n_calls = 0;
     int stride = 1, seen = 0;  // only every `stride`-th forward call is bracketed
     hipEvent_t* ev = nullptr;  // [max_calls][PROF_SLOTS]
     int* last = nullptr;       // [max_calls] highest slot recorded in the call
+    int* mid = nullptr;        // [max_calls] the call recorded PROF_SORT_MID
 } g_prof;
 
 inline bool prof_active() {
@@ -65,8 +68,13 @@ inline void prof_mark(int slot, hipStream_t st) {
     if (!prof_active()) return;
     if (g_prof.mode == 1 && slot != 2 && slot != 3) return;
     (void)hipEventRecord(g_prof.ev[(size_t)g_prof.n_calls * PROF_SLOTS + slot], st);
+    if (slot == PROF_SORT_MID) {
+        g_prof.mid[g_prof.n_calls] = 1;
+        return;
+    }
     int& last = g_prof.last[g_prof.n_calls];
     const bool opens = slot == (g_prof.mode == 1 ? 2 : 0);   // first event of a call: the pool entry is reused
+    if (opens) g_prof.mid[g_prof.n_calls] = 0;
     if (opens || slot > last) last = slot;
 }
 inline void prof_call_done() {
@@ -157,7 +165,12 @@ int run_tables(const float* q, const float* k, const float* v, const float* coor
 
 }  // namespace
 
-extern "C" int hept_abi_version(void) { return 18; }
+// internal (common.h): the sort marks the boundary between its two launches (mode 2 only; first chunk of tables only)
+void hept_prof_mark_sort_mid(void* stream) {
+    if (g_prof.mode == 2 && prof_active() && !g_prof.mid[g_prof.n_calls]) prof_mark(PROF_SORT_MID, (hipStream_t)stream);
+}
+
+extern "C" int hept_abi_version(void) { return 19; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -640,8 +653,10 @@ extern "C" int hept_profile_enable(int mode, int max_calls) {
         for (size_t i = 0; i < (size_t)g_prof.max_calls * PROF_SLOTS; ++i) (void)hipEventDestroy(g_prof.ev[i]);
         delete[] g_prof.ev;
         delete[] g_prof.last;
+        delete[] g_prof.mid;
         g_prof.ev = nullptr;
         g_prof.last = nullptr;
+        g_prof.mid = nullptr;
     }
     g_prof.mode = mode;
     g_prof.n_calls = 0;
@@ -650,6 +665,7 @@ extern "C" int hept_profile_enable(int mode, int max_calls) {
     if (g_prof.max_calls) {
         g_prof.ev = new hipEvent_t[(size_t)g_prof.max_calls * PROF_SLOTS];
         g_prof.last = new int[g_prof.max_calls]();
+        g_prof.mid = new int[g_prof.max_calls]();
         for (size_t i = 0; i < (size_t)g_prof.max_calls * PROF_SLOTS; ++i)
             if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return HEPT_ERR_LAUNCH;
     }
@@ -665,7 +681,7 @@ extern "C" int hept_profile_stride(int stride) {
 
 extern "C" int hept_profile_read(float* ms, int* n_calls) {
     if (!ms || !n_calls) return HEPT_ERR_ARG;
-    for (int i = 0; i < PROF_SLOTS - 1; ++i) ms[i] = 0.f;
+    for (int i = 0; i < 7; ++i) ms[i] = 0.f;
     *n_calls = g_prof.n_calls;
     for (int c = 0; c < g_prof.n_calls; ++c) {
         hipEvent_t* e = g_prof.ev + (size_t)c * PROF_SLOTS;
@@ -676,6 +692,11 @@ extern "C" int hept_profile_read(float* ms, int* n_calls) {
             float dt = 0.f;
             if (hipEventElapsedTime(&dt, e[sidx], e[sidx + 1]) != hipSuccess) return HEPT_ERR_LAUNCH;
             ms[sidx] += dt;
+        }
+        if (g_prof.mode == 2 && g_prof.mid[c] && last >= 2) {   // first launch of the sort: end of the row builder -> the mark
+            float dt = 0.f;
+            if (hipEventElapsedTime(&dt, e[1], e[PROF_SORT_MID]) != hipSuccess) return HEPT_ERR_LAUNCH;
+            ms[6] += dt;
         }
     }
     g_prof.n_calls = 0;

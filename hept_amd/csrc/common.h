@@ -186,6 +186,8 @@ int hept_sort_tables_src_rows(const float* qproj, const float* kproj, const floa
                               const float* cfac, float* minmax, int N, int H, int T, int t0, int Tl, void* sort_ws,
                               int32_t* qpos, int32_t* kpos, const HeptRowsJob* rows, void* stream, bool zeroed = false);
 void hept_sort_zero_block(void* sort_ws, int N, int H, int Tl, void** ptr, size_t* bytes);
+// stage timing (capi.hip, hept_profile_*): the sort calls this between its two launches
+void hept_prof_mark_sort_mid(void* stream);
 // hept_segmented_argsort for a caller that knows finite bounds of its keys (prepare.hip: packed code keys): the
 // per-segment range pass (a fill and a kernel) is skipped; any bounds give the exact stable sort
 int hept_segmented_argsort_bounded(const float* keys, int S, int L, float lo, float hi, void* ws, int32_t* pos,

@@ -1346,6 +1346,7 @@ int run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t
         hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED, true>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes,
                            eta, phi, cfac, minmax, bounds ? nullptr : b.range, bounds ? bounds[0] : 0.f,
                            bounds ? bounds[1] : 0.f, N, H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab, b.rg);
+        if (MODE != 2) hept_prof_mark_sort_mid(st);
         hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED, 64, true>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb,
                                b.params, b.tab, N, n_chunks, pos, rows, b.rg);
         return HEPT_OK;
@@ -1353,6 +1354,7 @@ int run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t
     hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED, false>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes, eta,
                        phi, cfac, minmax, bounds ? nullptr : b.range, bounds ? bounds[0] : 0.f, bounds ? bounds[1] : 0.f, N,
                        H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab, RegionArgs{});
+    if (MODE != 2) hept_prof_mark_sort_mid(st);
     if ((size_t)N <= (size_t)NTOP * (BKT_CAP_SMALL / 2))
         hipLaunchKernelGGL((bucket_sort_kernel<BKT_CAP_SMALL, EMBED, 64, false>), grid4, dim3(BKT_THREADS), 0, st, b.pa, b.pb, b.params,
                            b.tab, N, n_chunks, pos, rows, RegionArgs{});

@@ -783,9 +783,10 @@ def profile_read() -> Tuple[Dict[str, float], int]:
     """Summed milliseconds per stage over the recorded calls, and the number of calls; resets the pool."""
     import ctypes
 
-    ms = (ctypes.c_float * 6)()
+    ms = (ctypes.c_float * 7)()
     n = ctypes.c_int(0)
     _lib.check(_lib.load().hept_profile_read(ms, ctypes.byref(n)), "hept_profile_read")
-    # (the sharded call: "combine" = the exposed push / transfer of the last head group, then its own two stages)
-    return dict(zip(("prep_hash", "sort_tables", "block_attn", "combine", "sharded_combine", "sharded_gather"),
+    # (the sharded call: "combine" = the exposed push / transfer of the last head group, then its own two stages;
+    #  "chunk_sort" = the first of the sort's two launches, inside "sort_tables")
+    return dict(zip(("prep_hash", "sort_tables", "block_attn", "combine", "sharded_combine", "sharded_gather", "chunk_sort"),
                     [float(x) for x in ms])), int(n.value)

@@ -175,6 +175,8 @@ def make_inputs_src(
 WORKLOADS = {
     "example-4k": dict(cloud_sizes=[4096], block_size=64, n_hashes=2, coords_dim=6, num_regions=150),
     "tracking-6k": dict(cloud_sizes=[6000], block_size=128, n_hashes=3, coords_dim=6, num_regions=150),
+    # ten tracking-6k clouds in one call: the batch index goes into the AND code (example/transformer.py:55-56)
+    "tracking-6k-x10": dict(cloud_sizes=[6000] * 10, block_size=128, n_hashes=3, coords_dim=6, num_regions=150),
     "tracking-60k": dict(cloud_sizes=[60000], block_size=128, n_hashes=3, coords_dim=6, num_regions=150),
     "tracking-60k-t8": dict(cloud_sizes=[60000], block_size=128, n_hashes=8, coords_dim=6, num_regions=150),
     "pileup-8clouds": dict(

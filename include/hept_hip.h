@@ -434,10 +434,12 @@ int hept_ln_ffn_bwd(const float* x1, const float* d_out, const float* ln_w, cons
  * mode 0: off (default).  mode 1: bracket the block_attn kernel only (2 events per call).
  * mode 2: bracket every stage (5 events per hept_forward call, 7 per hept_forward_sharded call).  `max_calls`
  * sizes the event pool; calls beyond it are not recorded.  hept_profile_read waits for the recorded events, adds
- * up the elapsed milliseconds per stage over the recorded calls into ms[6] -- [prep (with the RPE weight math),
+ * up the elapsed milliseconds per stage over the recorded calls into ms[7] -- [prep (with the RPE weight math),
  * sort, block_attn, combine/reduce, 0, 0] for hept_forward, [prep, sort, block_attn (all head groups, with the pushes
  * they carry), exposed push or transfer of the last head group, combine (+ output slice to the ranks), output
- * gather] for hept_forward_sharded -- stores the number of calls in *n_calls and resets the pool. */
+ * gather] for hept_forward_sharded; ms[6] (mode 2) = the FIRST of the sort's two launches (chunk sort; 0 for clouds
+ * short enough for the one-launch sort), so that ms[1] - ms[6] is the second (bucket sort + v-row riders) -- stores
+ * the number of calls in *n_calls and resets the pool. */
 int hept_profile_enable(int mode, int max_calls);
 int hept_profile_read(float* ms, int* n_calls);
 /* Bracket only every `stride`-th forward call (default 1): an event pair costs a few microseconds of

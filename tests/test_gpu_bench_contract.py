@@ -27,31 +27,58 @@ def _run(*args, **env_extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("precision,bound,dtype", [("bf16", "hbm", "bf16"), ("fp32", "hbm", "f32")])
-def test_bench_line(precision, bound, dtype, gpu_device):
+def _check_whole_step(rec, n_launches):
+    """round 5: every launch of the step with its algorithmic bytes, and the step's bytes over the timed step time"""
+    ks = rec["kernels"]
+    assert len(ks) == n_launches and all(k["ms"] > 0 and k["algorithmic_bytes"] > 0 and 0.0 < k["frac"] < 1.5 for k in ks)
+    sr = rec["step_roofline"]
+    assert sr["algorithmic_bytes"] == sum(k["algorithmic_bytes"] for k in ks)
+    assert abs(sr["achieved"] - sr["algorithmic_bytes"] / (rec["ms_per_step"] * 1e-3) / 1e9) / sr["achieved"] < 1e-6
+    assert 0.0 < sr["frac"] < 1.0 and abs(sr["frac"] - sr["achieved"] / 8000.0) < 1e-9
+    # the event-timed launches add up to about the step (no gaps between them; the brackets' own cost is taken off)
+    assert 0.7 < sum(k["ms"] for k in ks) / rec["ms_per_step"] < 1.3
+
+
+@pytest.mark.parametrize("precision,dtype", [("bf16", "bf16"), ("fp32", "f32")])
+def test_bench_line(precision, dtype, gpu_device):
     d = _run("--precision", precision, "--no-cpu-baseline")
+    _check_whole_step(d, 5)
+    assert [k["name"].split()[0] for k in d["kernels"]][1:3] == ["chunk_sort_kernel", "bucket_sort_kernel"]
     if precision == "bf16":  # the default run carries the reference-precision record and BASELINE config 4
         f = d["fp32"]
-        assert f["dtype"] == "f32" and f["ms_per_step"] > d["ms_per_step"] and 0.0 < f["roofline"]["frac"] < 1.0
-        assert f["roofline"]["bound"] == "hbm" and f["roofline"]["kernel"] == "block_attn_split_kernel"
+        assert f["dtype"].startswith("f32 rows") and "split-bf16" in f["dtype"]
+        assert f["ms_per_step"] > d["ms_per_step"] and 0.0 < f["roofline"]["frac"] < 1.0
+        assert f["roofline"]["bound"] in ("hbm", "mfma") and f["roofline"]["kernel"] == "block_attn_split_kernel"
+        _check_whole_step(f, 5)
         assert d["c4"]["ms_per_step"] < d["ms_per_step"] and "n_hashes=1" in d["c4"]["workload"]
         assert 0.5 < d["mixed16"]["ms_per_step"] / d["ms_per_step"] < 1.5      # the every-row-tight 16-bit mode
-        # every other BASELINE configuration (round 4): c1, c2, c5 and the reference's own block size, both precisions
-        for key, n_raw, bs in (("c1", 4096, 64), ("c2", 6000, 128), ("c5", 60000, 256), ("b100", 60000, 100)):
+        # every other BASELINE configuration: c1, c2, c5, the reference's own block size and (round 5) ten tracking-6k
+        # clouds batched into one call, both precisions.  (No cross-precision timing ratio for the short clouds: those
+        # forwards are 35-55 us against 33 us of host issue, medians of three 20-step regions on a shared host.)
+        for key, n_raw, bs in (("c1", 4096, 64), ("c2", 6000, 128), ("c2x10", 60000, 128), ("c5", 60000, 256),
+                               ("b100", 60000, 100)):
             for prec in ("fp32", "bf16"):
                 rec = d[key][prec]
                 assert rec["n_raw"] == n_raw and rec["block_size"] == bs and rec["ms_per_step"] > 0
                 assert abs(rec["value"] - n_raw / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-6
-                assert rec["roofline"]["bound"] == "hbm" and 0.0 < rec["roofline"]["frac"] < 1.0
-            assert d[key]["fp32"]["ms_per_step"] > 0.8 * d[key]["bf16"]["ms_per_step"]
+                roof = rec["roofline"]
+                assert roof["bound"] in ("hbm", "mfma") and 0.0 < roof["frac"] < 1.0
+                # the bound is read off counters when a PMC record of this build exists for the launched template
+                if roof["traffic"] is None:
+                    assert roof["bound"] == "hbm" and roof["traffic_refused"]
+                else:
+                    ev = roof["bound_evidence"]
+                    assert (roof["bound"] == "hbm") == (ev["hbm_frac_of_copy_on_traffic"] >= ev["issue_frac"])
+        # the batched call runs ten 6k clouds at the per-point rate of one 60k cloud, not of one 6k cloud
+        assert d["c2x10"]["bf16"]["value"] > 2.0 * d["c2"]["bf16"]["value"]
     assert d["config"]["rccl_ranks"] == 0
     assert KEYS <= set(d) and ROOF <= set(d["roofline"])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["metric"] == "attention-fwd points/sec" and d["unit"] == "points/s" and d["scaling"] == "weak"
-    assert d["dtype"] == dtype and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["dtype"].startswith(dtype) and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "tracking-60k" in d["config"]["workload"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == bound and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["frac_of_copy"] - r["achieved"] / 6290.0) < 1e-9
     # PMC traffic is copied from profiles/ only when the record belongs to this build and this kernel template
     src = r["traffic_source"]

@@ -12,14 +12,15 @@ bash tools/pmc.sh bf16r > /dev/null 2>&1
 bash tools/pmc.sh fp32r --precision fp32 > /dev/null 2>&1
 python3 tools/pmc_summary.py gpurun_out/pmc_bf16r > $O/pmc_bf16.txt 2>&1
 python3 tools/pmc_summary.py gpurun_out/pmc_fp32r > $O/pmc_fp32.txt 2>&1
-python3 tools/make_traffic.py gpurun_out/pmc_bf16r gpurun_out/pmc_fp32r $O/attn_traffic.json > /dev/null 2>&1
+bash tools/pmc_shapes.sh > /dev/null 2>&1     # block 256 (pileup), block 100, the batched tracking-6k clouds: both precisions
+python3 tools/make_traffic.py $O/attn_traffic.json gpurun_out/pmc_bf16r gpurun_out/pmc_fp32r gpurun_out/pmcs_* > $O/attn_traffic_summary.txt 2>&1
 cp $O/attn_traffic.json profiles/attn_traffic.json
 python3 - <<'PY' > $O/traffic_check.txt 2>&1
 import bench
-for prec in ("bf16", "fp32"):
-    t, b, src = bench.pmc_record(prec)
-    print(prec, "traffic", t, "mfma_busy", b, "refused:", src.get("refused"))
-    assert t is not None, src
+for prec, bs in (("bf16", 128), ("fp32", 128), ("bf16", 256), ("fp32", 256), ("bf16", 100), ("fp32", 100)):
+    ent, src = bench.pmc_record(prec, bs)
+    print(prec, bs, "traffic", ent and ent["traffic"], "mfma_busy", ent and ent["mfma_busy_frac"], "valu_issue", ent and ent["valu_issue_frac"], "refused:", src.get("refused"))
+    assert ent is not None, src
 PY
 cat $O/traffic_check.txt
 cd /tmp
