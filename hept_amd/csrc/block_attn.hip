@@ -290,9 +290,10 @@ void block_attn_kernel(const char* __restrict__ qhat,
 // with ah = bf16(a), am = bf16(a - ah), al = bf16(a - ah - am) (each residual is exact in f32), and
 //     a.b = ah.bh + (ah.bm + am.bh) + (am.bm + ah.bl + al.bh) + O(2^-26 |a||b|)
 // -- six bf16 MFMAs with f32 accumulation instead of eight f32 MFMAs of 1/16 the rate each (3/8 of the issue
-// slots, 1/16 of the cycles per slot).  Both products use all six terms (VP = 3 planes for V and three pieces of
-// P): measured against the CPU oracle the output error is then that of the f32 MFMA kernel (1.4e-8 vs 2.0e-8 mean
-// on the pileup case); with two pieces for P.V (VP = 2, relative error 2^-17) it is 7x larger.  K^ and V are split
+// slots, 1/16 of the cycles per slot).  The logits K^.Q^ use all six terms (they are differences of large numbers); V
+// keeps VP = 3 planes (with VP = 2 the output error is 7x larger); P, a weight in [0, 1], is split into HEPT_SPLIT_PP
+// pieces -- two since round 4, see below: the accuracy contract of HEPT_PREC_F32 is "f32 rows and accumulation, the
+// logits to f32 accuracy, P to 16 significand bits"; HEPT_PREC_F32_MFMA is the exact f32 mode.  K^ and V are split
 // once per workgroup while they are staged (3 + VP bf16 planes in LDS, 384 B per key instead of 256; 64 keys at a
 // time, the next 64 gathered rows wait in registers while the current ones are computed), the wave's Q^ rows once
 // into registers, P in registers after the exp.  The norms -|q|^2/2, -|k|^2/2 ride in the product

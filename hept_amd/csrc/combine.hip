@@ -132,8 +132,10 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     // written (lanes >= D read column D-1: their MFMA output columns are never stored); the pad head of an odd H is 0.
     // Packed rows (16-bit tiles): the weight column of a lane comes straight from W -- 24 consecutive floats of row
     // `lc`, six 16-B loads per head pair that hit L1 / L2 (W is 18 KB) -- so the launch has no staging prologue and no
-    // barrier in front of its first tile: 27.3 -> 25.6 us at tracking-60k.  f32 rows keep the LDS slab: their waves
-    // already carry 21 row loads per head pair, and six more cost 4.5 us (54.7 against 50.2).
+    // barrier in front of its first tile: 27.3 -> 25.6 us at tracking-60k.  f32 rows loaded lane by lane keep the LDS slab
+    // (their waves already carry 21 row loads per head pair, and six more cost 4.5 us: 54.7 against 50.2); STAGED f32
+    // rows (their row loads are direct-to-LDS, no registers) take the column from W as well.  Both forms read W and the
+    // rows as 16-B pieces: combine_launch refuses bases that are not 16-B aligned.
     constexpr bool WDIRECT = (P16 || STG) && DT == 24;
     if constexpr (!WDIRECT) {
         for (int i = tid; i < D * HD; i += CMB_THREADS) {
@@ -867,6 +869,7 @@ inline bool staged_combine_off() {
     return off;
 }
 
+constexpr int CMB_NO_LDS = -1;   // internal: the device refused the staged rows' LDS size (never leaves this file)
 template <bool P16, bool FFN, int DT, bool PUSH, bool STG>
 int combine_launch_impl(hipStream_t st, const float* part, int Tl, int N, int H, int D, int n0, int n_count,
                         const float* W, const float* b, float* out, const FfnIn& ffn, int HG, size_t gstride,
@@ -886,7 +889,7 @@ int combine_launch_impl(hipStream_t st, const float* part, int Tl, int N, int H,
         if (hept_raise_lds(split ? raised_split : raised_flat,
                            split ? reinterpret_cast<const void*>(&combine_out_kernel<P16, FFN, DT, true, PUSH, STG>)
                                  : reinterpret_cast<const void*>(&combine_out_kernel<P16, FFN, DT, false, PUSH, STG>), lds))
-            return HEPT_ERR_LAUNCH;
+            return STG ? CMB_NO_LDS : HEPT_ERR_LAUNCH;   // (staged rows: the caller takes the lane-by-lane kernel instead)
     }
     if (split) {
         hipLaunchKernelGGL((combine_out_kernel<P16, FFN, DT, true, PUSH, STG>), dim3(n_tiles < HEPT_CMB_SPLIT_GRID ? n_tiles : HEPT_CMB_SPLIT_GRID), dim3(CMB_THREADS), lds, st, part,
@@ -907,10 +910,15 @@ int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int 
                    const float* b, float* out, const FfnIn& ffn, int HG = 0, size_t gstride = 0,
                    const P2pDev& px = P2pDev{}) {
     if (HG <= 0) HG = H;
+    // D = 24 rows are read as 16-B pieces (direct-to-LDS loads of whole rows, the weight column as f32x4 loads): a base
+    // that is not 16-B aligned would fault inside the kernel instead of failing here (include/hept_hip.h says so)
+    if (DT == 24 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(part)) & 15)) return HEPT_ERR_ARG;
     // staged rows: packed rows of the plain layout (no head groups), even head count
     if constexpr (DT == 24 && !PUSH) {
-        if (HG == H && H % 2 == 0 && !staged_combine_off())
-            return combine_launch_impl<P16, FFN, DT, PUSH, true>(st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn, HG, gstride, px);
+        if (HG == H && H % 2 == 0 && !staged_combine_off()) {
+            const int rc = combine_launch_impl<P16, FFN, DT, PUSH, true>(st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn, HG, gstride, px);
+            if (rc != CMB_NO_LDS) return rc;   // (the raise of the dynamic LDS limit failed: lane-by-lane loads need less)
+        }
     }
     return combine_launch_impl<P16, FFN, DT, PUSH, false>(st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn, HG, gstride, px);
 }

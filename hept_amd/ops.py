@@ -62,7 +62,10 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
         raise RuntimeError(f"{name} must live on the GPU (hept_amd has no CPU path); got device {t.device}")
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")
-    return t.contiguous()
+    t = t.contiguous()
+    # the kernels read rows and weight columns as 16-byte pieces (include/hept_hip.h: hept_combine_out refuses other
+    # bases): a contiguous VIEW at an odd storage offset gets an aligned copy here instead of an error there
+    return t.clone() if t.data_ptr() % 16 else t
 
 
 def _dims(q: torch.Tensor, coords: torch.Tensor, alpha: torch.Tensor) -> Tuple[int, int, int, int, int]:

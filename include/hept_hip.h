@@ -146,7 +146,9 @@ int hept_reduce_heads(const float* part, int part_precision, int Tl, int N, int 
 
 /* replaces the cross-table combine (example/hept.py:79) and out_linear (:80) for points
  * [n0, n0+n_count): out[n] = bias + W . (sum_t numer / sum_t denom).  `part` may hold Tl >= 1
- * tables (Tl == 1: an already reduced `acc`).  out points at row n0 of the (N, D) output. */
+ * tables (Tl == 1: an already reduced `acc`).  out points at row n0 of the (N, D) output.
+ * D == 24: `part` and `out_weight` must be 16-byte aligned (rows and weight columns are read as 16-B pieces);
+ * HEPT_ERR_ARG otherwise. */
 int hept_combine_out(const float* part, int part_precision, int Tl, int N, int H, int D, int n0,
                      int n_count, const float* out_weight, const float* out_bias, float* out,
                      void* stream);

@@ -248,3 +248,68 @@ def test_in_place_update_of_w_rpe_through_data_is_seen(precision, gpu_device):
     staged = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], sw, g["alpha"], g["out_weight"],
                          g["out_bias"], block_size=inp["block_size"], w_per_dist=0, precision=precision)
     assert torch.equal(staged, second)
+
+
+def test_out_linear_weight_at_an_odd_storage_offset(gpu_device):
+    """the D = 24 combine reads out_linear.weight and the partial rows as 16-byte pieces.  A contiguous
+    view at an odd storage offset is legal for the module (ops makes an aligned copy); a raw pointer that is not 16-byte
+    aligned is refused by the C ABI with HEPT_ERR_ARG instead of faulting inside the kernel."""
+    from hept_amd import _lib
+    inp, _ = cases.load_case("g1_rand512")
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    sw = ops.rpe_scale(g["w_rpe_weight"], 8, 24, 10)
+    want = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], sw, g["alpha"], g["out_weight"],
+                       g["out_bias"], block_size=inp["block_size"], w_per_dist=0)
+    store = torch.zeros(g["out_weight"].numel() + 1, device=gpu_device)
+    odd = store[1:].view_as(g["out_weight"])
+    odd.copy_(g["out_weight"])
+    assert odd.is_contiguous() and odd.data_ptr() % 16 == 4
+    got = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], sw, g["alpha"], odd, g["out_bias"],
+                      block_size=inp["block_size"], w_per_dist=0)
+    assert torch.equal(got, want)
+    lib = _lib.load()
+    n, h, d = g["q"].shape[0], 8, 24
+    part = torch.zeros(1, n, h, 32, device=gpu_device)
+    out = torch.empty(n, d, device=gpu_device)
+    rc = lib.hept_combine_out(part.data_ptr(), 0, 1, n, h, d, 0, n, odd.data_ptr(), None, out.data_ptr(), None)
+    assert rc == 3   # HEPT_ERR_ARG
+    rc = lib.hept_combine_out(part.data_ptr(), 0, 1, n, h, d, 0, n, g["out_weight"].data_ptr(), None, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0
+
+
+def test_combine_without_the_staged_rows_gives_the_same_bits(gpu_device):
+    """the staged combine (rows through LDS, > 64 KB of dynamic LDS for f32 rows with the feed-forward
+    epilogue on a short cloud) has a lane-by-lane fallback (taken when the device refuses the LDS size; forced here with
+    HEPT_NO_STAGED_COMBINE=1): both must give the same bits -- the fused Attn block on tracking-6k, fp32 and bf16."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, torch; sys.path.insert(0, %r)\n"
+        "from hept_amd import ops\n"
+        "from hept_amd.synthetic import workload_inputs\n"
+        "inp = workload_inputs('tracking-6k', seed=3)\n"
+        "dev = torch.device('cuda:0')\n"
+        "g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}\n"
+        "gen = torch.Generator().manual_seed(5)\n"
+        "r = lambda *s: (torch.randn(*s, generator=gen) * 0.2).to(dev)\n"
+        "x = torch.randn(g['q'].shape[0], 24, generator=gen).to(dev)\n"
+        "p = {'norm1.weight': r(24) + 1, 'norm1.bias': r(24), 'w_q.weight': r(192, 24), 'w_k.weight': r(192, 24),\n"
+        "     'w_v.weight': r(192, 24), 'w_rpe.weight': g['w_rpe_weight'], 'attn.e2lsh.alpha': g['alpha'],\n"
+        "     'attn.out_linear.weight': g['out_weight'], 'attn.out_linear.bias': g['out_bias'], 'norm2.weight': r(24) + 1,\n"
+        "     'norm2.bias': r(24), 'ff.0.weight': r(24, 24), 'ff.0.bias': r(24), 'ff.2.weight': r(24, 24), 'ff.2.bias': r(24)}\n"
+        "for prec in ('fp32', 'bf16'):\n"
+        "    y = ops.attn_block_forward(x, g['coords'], g['combined_shifts'], p, num_heads=8, block_size=128, w_per_dist=10,\n"
+        "                               precision=prec)\n"
+        "    print(prec, hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest(), bool(torch.isfinite(y).all()))\n"
+    ) % root
+    outs = []
+    for switch in ("0", "1"):
+        env = dict(os.environ, HEPT_NO_STAGED_COMBINE=switch)
+        run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs.append([ln for ln in run.stdout.splitlines() if ln.startswith(("fp32", "bf16"))])
+    assert len(outs[0]) == 2 and outs[0] == outs[1] and all(ln.endswith("True") for ln in outs[0]), outs

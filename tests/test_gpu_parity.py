@@ -359,6 +359,18 @@ def test_split_bf16_products_match_the_f32_mfma_kernel(name, gpu_device):
     tol = ATOL.get(name, 1e-5) + 1e-4 * ref.abs()
     assert float((err <= tol).float().mean()) >= 0.995
     assert float((got[..., d + 1:]).abs().max()) == 0.0
+    # P enters P.V in TWO bf16 pieces (16 significand bits) since round 4 -- pinned per ROW against the
+    # exact f32 kernel on the same rows and blocks: every row of what the combine forms (table-summed numerators over the
+    # table-summed denominator, per head) within SPLIT_ROW_X of the fp32 tolerance, dominant-key rows (pileup,
+    # checkpoint clouds) included; rows whose denominators are at the 1e-20 floor in every table are 0/0-like in both
+    num_g, den_g = got[..., :d].double().sum(0), got[..., d].double().sum(0).unsqueeze(-1)
+    num_r, den_r = ref[..., :d].double().sum(0), ref[..., d].double().sum(0).unsqueeze(-1)
+    live = den_r.squeeze(-1) > 1e-10
+    row_g, row_r = (num_g / den_g)[live], (num_r / den_r)[live]
+    row_x = float(((row_g - row_r).abs() / (ATOL.get(name, 1e-5) + 1e-4 * row_r.abs())).max())
+    print(f"{name}: per-head rows, split-bf16 (P in two pieces) vs the f32 MFMA kernel: worst element {row_x:.3f} x the tolerance "
+          f"({int(live.sum())} of {live.numel()} rows above the denominator floor)")
+    assert row_x <= SPLIT_ROW_X
     # the whole operator through the other kernel: both f32 modes agree on >= 99.5 % of rows
     a = _forward(g, inp, "fp32").cpu()
     b = _forward(g, inp, "fp32_mfma").cpu()
@@ -473,7 +485,49 @@ def test_full_size_with_the_references_own_block_size(gpu_device):
 # every precision stays finite; fp32 with the reference's permutations reproduces the reference where it is
 # well defined -- rows whose reference denominators are all 0 (+1e-20) in every table come out exactly as the
 # reference's (bias only), and the well-conditioned majority of rows agree at the G3 tolerance.
+SPLIT_ROW_X = 6.0   # measured 0.11-0.16 on the dominant-key cases (pileup, block 100, checkpoint), 2.4 / 3.6 on the default-init
+                    # cases g1 / g2, whose worst rows sit just above the denominator floor (total weight ~1e-9: f32 round-off of the logits)
 G7_MIN_ROWS_AT_G3_TOL = 0.7   # measured 0.80 (printed below); see DESIGN.md section 4
+# against the float64 evaluation of the reference (fixture out_fp64): the fp32 reference itself keeps 81.9 % of its rows
+# inside the G3 tolerance (median row error 1.6e-4, worst 0.133); the HIP fp32 output has to do as well, up to this slack
+G7_FP64_ROWS_SLACK = 0.02
+G7_FP64_FACTOR = 1.5
+G7_FP64_FAR_ROWS = 20     # 0.33 % of the rows (measured 8)
+
+
+def test_unrescaled_checkpoint_fp32_is_as_close_to_float64_as_the_reference(gpu_device):
+    """Pins the G7 claim (round 5): on the shipped layer-0 scales with raw coordinates the fp32 REFERENCE is rounding
+    noise -- so the yardstick is the reference's arithmetic evaluated in float64 on the same blocks (fixture field
+    ``out_fp64``, generated by the real reference's stage functions on double inputs with its fp32 permutations).
+    The HIP fp32 output (same permutations injected) has to be as close to that as the reference's own fp32 output is:
+    as many rows inside the G3 tolerance, no larger typical or worst row error, and no row far off where the
+    reference is close."""
+    inp, fx = cases.load_case("g7_ckpt_rawcoords")
+    g = _gpu(inp, gpu_device)
+    qp = torch.from_numpy(fx["q_positions"].astype(np.int32)).to(gpu_device)
+    kp = torch.from_numpy(fx["k_positions"].astype(np.int32)).to(gpu_device)
+    got = _staged(g, inp, "fp32", qp, kp)["out"].cpu().double()
+    ref32, ref64 = torch.from_numpy(fx["out"]).double(), torch.from_numpy(fx["out_fp64"])
+    tol = ATOL["g3_ckpt6k"] + 1e-4 * ref64.abs()
+    e_hip, e_ref = (got - ref64).abs(), (ref32 - ref64).abs()
+    rows_hip, rows_ref = float((e_hip <= tol).all(1).float().mean()), float((e_ref <= tol).all(1).float().mean())
+    r_hip, r_ref = e_hip.amax(1), e_ref.amax(1)          # worst element of every row
+    print(f"g7 vs float64: rows within the G3 tolerance: HIP {rows_hip:.4f}, reference fp32 {rows_ref:.4f}; "
+          f"median row error HIP {float(r_hip.median()):.3e} / ref {float(r_ref.median()):.3e}; "
+          f"mean {float(r_hip.mean()):.3e} / {float(r_ref.mean()):.3e}; max {float(r_hip.max()):.3e} / {float(r_ref.max()):.3e}; "
+          f"rows where HIP is worse than 4x the reference's error and outside the tolerance: "
+          f"{int(((r_hip > 4 * r_ref) & ~(e_hip <= tol).all(1)).sum())}")
+    assert rows_hip >= rows_ref - G7_FP64_ROWS_SLACK
+    assert float(r_hip.median()) <= G7_FP64_FACTOR * float(r_ref.median())
+    # ... except for a handful of rows: a row whose only weight is its own key (true logit ~ -0.1, computed as a
+    # difference of 3e8-sized terms) is lost when the rounding noise of that difference (sigma ~ 20 in any fp32
+    # evaluation, the reference's included) happens to push the logit below -46 = log(1e-20), the denominator floor
+    # (example/hept.py:14) -- the output then falls back to the bias.  Measured: 8 of 6016 rows off by more than 0.5
+    # (the native f32 MFMA kernel: 4; the reference's own fp32 run: 0 on this seed); asserted as a count, not hidden in
+    # a mean
+    far = int((r_hip > 0.5).sum())
+    print(f"g7 vs float64: rows off by more than 0.5: HIP {far}, reference fp32 {int((r_ref > 0.5).sum())}")
+    assert far <= G7_FP64_FAR_ROWS
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "mixed16"])
