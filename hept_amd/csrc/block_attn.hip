@@ -43,8 +43,13 @@ namespace {
 #ifndef HEPT_RAGGED16_WAVES
 #define HEPT_RAGGED16_WAVES 7
 #endif
+// (B = 96 with f32 partial rows -- D != 24, an off-the-shipped-shapes instance -- spilled 4 registers at the 64-VGPR cap as
+//  well, and at 72: 6 waves = 80 VGPRs)
+constexpr int attn_waves(int nkt, bool bf16, bool p16, bool full) {
+    return bf16 ? ((nkt == 3 && !p16 && full) ? 6 : (full ? 8 : HEPT_RAGGED16_WAVES)) : (full ? 6 : 4);
+}
 template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL>
-__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(BF16 ? (FULL ? 8 : HEPT_RAGGED16_WAVES) : (FULL ? 6 : 4), BF16 ? (FULL ? 8 : HEPT_RAGGED16_WAVES) : (FULL ? 6 : 4))))
+__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(attn_waves(NKT, BF16, P16, FULL), attn_waves(NKT, BF16, P16, FULL))))
 void block_attn_kernel(const char* __restrict__ qhat,
                                                               const char* __restrict__ kvhat,
                                                               const int* __restrict__ qpos,

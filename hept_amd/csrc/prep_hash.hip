@@ -169,7 +169,8 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
                                           const int64_t* __restrict__ codes, int N, int raw_size, int t0, int Tl,
                                           char* __restrict__ out_rows, float* __restrict__ proj,
                                           float* __restrict__ red_s, f32x4* __restrict__ tile_s,
-                                          float* __restrict__ minmax, int slot, FusedIn fin = FusedIn{}) {
+                                          float* __restrict__ minmax, int slot, unsigned int* __restrict__ cmax_s,
+                                          FusedIn fin = FusedIn{}) {
     constexpr int H = 8, E = D + C, HD = H * D, D4 = D / 4;
     constexpr int WAVES = PREP_THREADS / HEPT_WAVE;
     constexpr bool BF16 = TILE != HEPT_PREC_F32;      // 16-bit tiles
@@ -192,9 +193,24 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
         wslot[j] = (c / D4) * ROW4 + (c % D4);
     }
 
-    float mn[TMAX], mx[TMAX], cm[TMAX];
+    // ... and, where the LDS has room (not FUSED: there the per-wave partials replace red_s), the hash range as well: a wave-
+    // private [min | max] word per (table, head), LDS float atomics per tile instead of 2 TMAX loop-carried registers
+    constexpr bool RANGE_LDS = !FUSED;
+    float mn[RANGE_LDS ? 1 : TMAX], mx[RANGE_LDS ? 1 : TMAX];
+    float* rgw = red_s + w * 2 * TMAX * H;   // RANGE_LDS: red_s is [wave][min | max][TMAX][H]
+    if constexpr (RANGE_LDS) {
+        for (int i = lane; i < 2 * TMAX * H; i += 64) rgw[i] = i < TMAX * H ? INFINITY : -INFINITY;
+    } else {
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; cm[t] = 0.f; }
+        for (int t = 0; t < TMAX; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; }
+    }
+    // the largest code seen lives in LDS, not in TMAX loop-carried registers (the tile loop sits on the 128-VGPR boundary):
+    // a wave-private word per (table, head), raised by an LDS atomic in the tiles that look at the codes (codes are
+    // >= 0: their float bit patterns order like the values).  A wave's LDS operations execute in order: no barrier.
+    unsigned int* cmw = cmax_s + w * TMAX * H;
+    if (ROLE == 0) {
+        for (int i = lane; i < TMAX * H; i += 64) cmw[i] = 0u;
+    }
 
     const int ntiles = (N + PREP_POINTS - 1) / PREP_POINTS;
     for (int tile_i = blockIdx.x * WAVES + w; tile_i < ntiles; tile_i += gridDim.x * WAVES) {
@@ -267,7 +283,8 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
                 // of int64 codes instead of 11.5 MB at tracking-60k.  Deterministic (tiles, not random numbers).
 #pragma unroll
                 for (int t = 0; t < TMAX; ++t)
-                    if (t < Tl && live) cm[t] = fmaxf(cm[t], __ll2float_ru(codes[((size_t)(t0 + t) * H + h) * N + n]));
+                    if (t < Tl && live)
+                        atomicMax(&cmw[t * H + h], __float_as_uint(fmaxf(__ll2float_ru(codes[((size_t)(t0 + t) * H + h) * N + n]), 0.f)));
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) a[D + c] = sw_s[h * C + c] * cs[c];
@@ -326,8 +343,15 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
         //  straight-line block instead of being sunk into TMAX branches with every alpha word live)
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
-            mn[t] = fminf(mn[t], live ? acc[t] : INFINITY);
-            mx[t] = fmaxf(mx[t], live ? acc[t] : -INFINITY);
+            if constexpr (RANGE_LDS) {
+                if (t < Tl && live) {
+                    __hip_atomic_fetch_min(&rgw[t * H + h], acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_max(&rgw[TMAX * H + t * H + h], acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            } else {
+                mn[t] = fminf(mn[t], live ? acc[t] : INFINITY);
+                mx[t] = fmaxf(mx[t], live ? acc[t] : -INFINITY);
+            }
             if (t < Tl && live) proj[((size_t)t * H + h) * N + n] = is_pad ? INFINITY : acc[t];
         }
         float ss = 0.f;
@@ -369,23 +393,25 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
     }
     if (ROLE == 2) return;
 
-    // per-workgroup partial hash range: lane keeps one head (h = lane & 7); fold the 8 point-lanes, then the waves
-    // (FUSED: red_s lives in the wave buffers -- LDS is what limits that kernel's occupancy -- so every wave has to be
-    //  done with its tiles first)
+    // per-workgroup partial hash range: fold the waves' partials (RANGE_LDS: they are in LDS already; else lane keeps one
+    // head (h = lane & 7): fold the 8 point-lanes first.  FUSED: red_s lives in the wave buffers -- LDS is what limits that
+    // kernel's occupancy -- so every wave has to be done with its tiles first)
     if constexpr (FUSED) __syncthreads();
+    if constexpr (!RANGE_LDS) {
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-        if (t < Tl) {
-            float lo = mn[t], hi = mx[t], c = cm[t];
+        for (int t = 0; t < TMAX; ++t) {
+            if (t < Tl) {
+                float lo = mn[t], hi = mx[t];
 #pragma unroll
-            for (int off = 8; off <= 32; off <<= 1) {
-                lo = fminf(lo, __shfl_xor(lo, off));
-                hi = fmaxf(hi, __shfl_xor(hi, off));
-                c = fmaxf(c, __shfl_xor(c, off));
-            }
-            if (p == 0) {
-                float* r = red_s + ((w * TMAX + t) * H + h) * 4;
-                r[0] = lo; r[1] = hi; r[2] = c;
+                for (int off = 8; off <= 32; off <<= 1) {
+                    lo = fminf(lo, __shfl_xor(lo, off));
+                    hi = fmaxf(hi, __shfl_xor(hi, off));
+                }
+                if (p == 0) {
+                    float* r = red_s + w * 2 * TMAX * H;
+                    r[t * H + h] = lo;
+                    r[TMAX * H + t * H + h] = hi;
+                }
             }
         }
     }
@@ -395,10 +421,10 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
         float lo = INFINITY, hi = -INFINITY, c = 0.f;
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) {
-            const float* r = red_s + ((ww * TMAX + t) * H + hh) * 4;
-            lo = fminf(lo, r[0]);
-            hi = fmaxf(hi, r[1]);
-            c = fmaxf(c, r[2]);
+            const float* r = red_s + ww * 2 * TMAX * H;
+            lo = fminf(lo, r[t * H + hh]);
+            hi = fmaxf(hi, r[TMAX * H + t * H + hh]);
+            if (ROLE == 0) c = fmaxf(c, __uint_as_float(cmax_s[(ww * TMAX + t) * H + hh]));
         }
         // layout [Tl][H][HEPT_PREP_GRID][4]: the sort kernels reduce one (t,h) row with contiguous 16-B loads.  The
         // launch may have fewer workgroups per role than the role has slots: the spare slots get neutral values
@@ -454,8 +480,9 @@ void prep_hash_kernel(
     zero_block(zero);
     __shared__ __attribute__((aligned(16))) float alpha_s[H * alpha_pitch(E, TMAX)];
     __shared__ float sw_s[H * C];
-    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * TMAX * H * 4];
+    __shared__ float red_s[(PREP_THREADS / HEPT_WAVE) * 2 * TMAX * H];   // per wave [min | max][TMAX][H]
     __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * PREP_WAVE_SLOTS];
+    __shared__ unsigned int cmax_s[(PREP_THREADS / HEPT_WAVE) * TMAX * H];
     static_assert(64 * ((D / 4) | 1) <= PREP_WAVE_SLOTS, "input tile does not fit the wave buffer");
     const int role = blockIdx.y;
     if (role != 2) {
@@ -471,20 +498,20 @@ void prep_hash_kernel(
     }
     if (role == 0)
         prep_role<D, C, TILE, 0, TMAX>(q, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(qhat_), qproj,
-                                 red_s, tile_s, minmax, blockIdx.x);
+                                 red_s, tile_s, minmax, blockIdx.x, cmax_s);
     else if (role == 1)
         prep_role<D, C, TILE, 1, TMAX>(k, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), kproj,
-                                 red_s, tile_s, minmax, PREP_SLOTS_PER_ROLE + blockIdx.x);
+                                 red_s, tile_s, minmax, PREP_SLOTS_PER_ROLE + blockIdx.x, cmax_s);
     else
         prep_role<D, C, TILE, 2, TMAX>(v, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_), nullptr,
-                                 red_s, tile_s, minmax, 0);
+                                 red_s, tile_s, minmax, 0, cmax_s);
 }
 
 // Attn-block front end: LayerNorm + the three projections fused into the row builder (D = 24 only)
 // 16-bit rows, 4 table slots: 39.9 KB of LDS = 4 workgroups per CU, and the registers are held to that occupancy too
 template <int C, int TILE, int TMAX>
 __global__ __launch_bounds__(PREP_THREADS)
-__attribute__((amdgpu_waves_per_eu((TILE != HEPT_PREC_F32 && TMAX == 4) ? 4 : 2, (TILE != HEPT_PREC_F32 && TMAX == 4) ? 4 : 3)))
+__attribute__((amdgpu_waves_per_eu((TILE != HEPT_PREC_F32 && TMAX == 4) ? (C == 4 ? 3 : 4) : 2, (TILE != HEPT_PREC_F32 && TMAX == 4) ? 4 : 3)))
 void prep_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
     const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
@@ -500,8 +527,9 @@ void prep_fused_kernel(
     constexpr int WSLOTS = 64 * (TILE != HEPT_PREC_F32 ? 4 : 8) + 8;
     __shared__ f32x4 tile_s[(PREP_THREADS / HEPT_WAVE) * WSLOTS];
     float* red_s = reinterpret_cast<float*>(tile_s);
-    static_assert((PREP_THREADS / HEPT_WAVE) * TMAX * H * 4 * 4 <= (PREP_THREADS / HEPT_WAVE) * WSLOTS * 16, "red_s fits the wave buffers");
+    static_assert((PREP_THREADS / HEPT_WAVE) * 2 * TMAX * H * 4 <= (PREP_THREADS / HEPT_WAVE) * WSLOTS * 16, "red_s fits the wave buffers");
     __shared__ __attribute__((aligned(16))) float w_s[H * FUSED_WPITCH];
+    __shared__ unsigned int cmax_s[(PREP_THREADS / HEPT_WAVE) * TMAX * H];
     const int role = blockIdx.y;
     const float* wsrc = role == 0 ? wq : (role == 1 ? wk : wv);
     for (int i = threadIdx.x; i < H * D * D; i += PREP_THREADS) {  // W row (h, d), column j  ->  slab h, [j][d]
@@ -521,13 +549,13 @@ void prep_fused_kernel(
     const FusedIn fin{ln_w, ln_b, w_s, eps};
     if (role == 0)
         prep_role<D, C, TILE, 0, TMAX, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(qhat_),
-                                       qproj, red_s, tile_s, minmax, blockIdx.x, fin);
+                                       qproj, red_s, tile_s, minmax, blockIdx.x, cmax_s, fin);
     else if (role == 1)
         prep_role<D, C, TILE, 1, TMAX, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
-                                       kproj, red_s, tile_s, minmax, PREP_SLOTS_PER_ROLE + blockIdx.x, fin);
+                                       kproj, red_s, tile_s, minmax, PREP_SLOTS_PER_ROLE + blockIdx.x, cmax_s, fin);
     else
         prep_role<D, C, TILE, 2, TMAX, true>(x, coords, sw_s, alpha_s, codes, N, raw_size, t0, Tl, reinterpret_cast<char*>(kvhat_),
-                                       nullptr, red_s, tile_s, minmax, 0, fin);
+                                       nullptr, red_s, tile_s, minmax, 0, cmax_s, fin);
 }
 
 template <int C>
