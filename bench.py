@@ -507,6 +507,60 @@ def worker(args) -> int:
                            exposed_push_us=us["combine"], combine_us=us["sharded_combine"], gather_us=us["sharded_gather"])
         return rec
 
+    def exchange_proxy(precision, steps=100):
+        """BASELINE config 4's per-rank shape (one table) on a ONE-rank communicator with the exchange forced on, per
+        transport: what the sharded step costs in launches, local copies and stores into the (uncached) exchange buffers
+        before any xGMI traffic -- the terms of the exchange a single GPU can measure, so that the line
+        shows which transport tune() would be choosing between.  us per step."""
+        import torch.distributed as dist
+        from hept_amd.sharding import TableSharding
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
+        rec = {}
+        with c_stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+            dist.barrier()
+            torch.cuda.synchronize()
+        try:
+            inp1 = workload_inputs(WORKLOAD, seed=0, n_hashes=1)
+            host_inputs.append(inp1)
+            g1 = {k: v.to(dev) for k, v in inp1.items() if torch.is_tensor(v)}
+            c1 = inp1["coords"].shape[1]
+            w_rpe1 = torch.nn.Linear(inp1["w_rpe_weight"].shape[1], inp1["w_rpe_weight"].shape[0]).to(dev)
+            with torch.no_grad():
+                w_rpe1.weight.copy_(g1["w_rpe_weight"])
+            kw1 = dict(w_rpe=w_rpe1, coords=g1["coords"], combined_shifts=g1["combined_shifts"])
+            for name, mode, via in (("plain", None, None), ("one_sided", "all_to_all", "p2p"), ("rccl", "all_to_all", "rccl"),
+                                    ("all_reduce", "all_reduce", None)):
+                m = HEPTAttention(D + c1, h_dim=D, num_heads=H, block_size=B, n_hashes=1, num_w_per_dist=10, precision=precision,
+                                  process_group=dist.group.WORLD if mode else None)
+                if mode:
+                    m.sharding = TableSharding(1, dist.group.WORLD, mode=mode, always_exchange=True, head_groups=1)
+                    if via:
+                        m.sharding.exchange = via
+                m.load_state_dict({"out_linear.weight": inp1["out_weight"], "out_linear.bias": inp1["out_bias"],
+                                   "e2lsh.alpha": inp1["alpha"]}, strict=True)
+                m = m.to(dev).eval()
+                with torch.no_grad(), c_stdout_to_stderr():
+                    for _ in range(10):
+                        m(g1["q"], g1["k"], g1["v"], **kw1)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        m(g1["q"], g1["k"], g1["v"], **kw1)
+                    torch.cuda.synchronize()
+                    rec[name] = round((time.perf_counter() - t0) / steps * 1e6, 1)
+                if mode:
+                    m.sharding.check()
+                del m
+        except Exception as exc:  # noqa: BLE001  (a record beside the contract's line: never fail the run for it)
+            rec["error"] = repr(exc)
+        finally:
+            with c_stdout_to_stderr():
+                dist.destroy_process_group()
+        return rec
+
     tables_per_gpu = args.tables_per_gpu
     inp, attn, step = build(tables_per_gpu, args.precision)
     n, n_raw, C = inp["q"].shape[0], inp["n_raw"], inp["coords"].shape[1]
@@ -694,6 +748,8 @@ def worker(args) -> int:
     if rank == 0:
         line.update(sub)
 
+    if rank == 0 and world == 1 and not multi and not args.no_extra and "c4" in line:
+        line["c4"]["exchange_on_one_rank_us"] = exchange_proxy(args.precision)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(inp, B)
