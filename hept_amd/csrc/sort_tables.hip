@@ -515,7 +515,10 @@ static_assert(LOBINS % BKT_THREADS == 0, "every thread owns the same number of b
 // bins array (now one past the last slot of every group) the group's bounds; a group of one or two pairs (92 % of the
 // pairs at tracking-60k) is ranked by two tile reads and two compares, without a loop.  No validity masks, no
 // run lookups, no second pass: ~45 % of the general path's instructions (the kernel is bound by instruction issue).
-constexpr int LEAN_SLOTS = 4;
+#ifndef HEPT_LEAN_SLOTS
+#define HEPT_LEAN_SLOTS 4
+#endif
+constexpr int LEAN_SLOTS = HEPT_LEAN_SLOTS;
 // pr[u] = pair u * threads + tid of the bucket for every u with u * threads < nb (anything where that position is >= nb)
 __device__ __forceinline__ void bucket_lean(const unsigned long long (&pr)[LEAN_SLOTS], int nb, int start,
                                             unsigned long long* __restrict__ tile_s, unsigned int* __restrict__ cur_s,
