@@ -1333,6 +1333,10 @@ SortBuffers carve_sort(void* sort_ws, int segs, int N) {
     b.bytes = off;
     return b;
 }
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned int* __restrict__ p, unsigned int words) {
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+    if (i < words) p[i] = 0u;
+}
 constexpr int BKT_CAP_SMALL = HEPT_BKT_CAP;  // LDS tile: the average bucket is N/NTOP
 constexpr int BKT_CAP_LARGE = 6 * HEPT_BKT_CAP;  // 48 KiB tile for longer segments (average bucket up to ~3000 pairs)
 static_assert(REGION_MAX_N == NTOP * (BKT_CAP_SMALL / 2), "the REGION layout serves exactly the small-tile bucket kernel");
@@ -1345,7 +1349,12 @@ int run_passes_impl(const SortBuffers& b, int segs, int N, int* pos, hipStream_t
     const int n_chunks = (N + SORT_CHUNK - 1) / SORT_CHUNK;
     const dim3 grid4(NTOP, segs + rows.vy);   // rider rows first
     if (b.rg.region && !region_sort_off()) {
-        if (!zeroed && hipMemsetAsync(b.rg.cnt, 0, b.zero_bytes, st) != hipSuccess) return HEPT_ERR_LAUNCH;
+        // (a caller whose preceding kernel did not clear the counters: a 48-workgroup kernel of our own -- the runtime's
+        //  fill kernel took 4.9 us for these 49 KB)
+        if (!zeroed) {
+            const unsigned int words = (unsigned int)(b.zero_bytes / 4);
+            hipLaunchKernelGGL(zero_words_kernel, dim3((words + 255) / 256), dim3(256), 0, st, b.rg.cnt, words);
+        }
         hipLaunchKernelGGL((chunk_sort_kernel<MODE, EMBED, true>), dim3(n_chunks, segs), dim3(SCT), 0, st, qproj, kproj, codes,
                            eta, phi, cfac, minmax, bounds ? nullptr : b.range, bounds ? bounds[0] : 0.f,
                            bounds ? bounds[1] : 0.f, N, H, t0, Tl, n_chunks, seg_len, b.params, b.pa, b.tab, b.rg);
