@@ -135,9 +135,10 @@ class HEPTAttention(nn.Module):
         with torch.no_grad():
             # (w_rpe.weight goes to the C call as it is: sqrt_w (H, C), reference example/hept.py:22-25, is computed in
             #  the row builder's prologue on every forward -- nothing derived from a parameter is cached here)
-            q2 = query.reshape(n, h * d).float()
-            k2 = key.reshape(n, h * d).float()
-            v2 = value.reshape(n, h * d).float()
+            f32 = torch.float32
+            q2 = query if (query.dtype is f32 and query.dim() == 2) else query.reshape(n, h * d).float()
+            k2 = key if (key.dtype is f32 and key.dim() == 2) else key.reshape(n, h * d).float()
+            v2 = value if (value.dtype is f32 and value.dim() == 2) else value.reshape(n, h * d).float()
             if self.sharding is None and torch.compiler.is_compiling():
                 # one opaque graph node instead of a ctypes call Dynamo cannot trace (hept_amd/library.py)
                 from .library import forward_op, forward_src_op
@@ -165,7 +166,7 @@ class HEPTAttention(nn.Module):
                                       **common)
             else:
                 out = self._forward_sharded(q2, k2, v2, coords.float(), w_rpe_weight, src, kwargs, common)
-        return out.to(query.dtype)
+        return out if query.dtype is torch.float32 else out.to(query.dtype)
 
     def _forward_sharded(self, q2, k2, v2, coords, w_rpe_weight, src, kwargs, common):
         """Tables [t0, t0 + tl) of this rank, then the exchange (reference coupling: example/hept.py:79)."""

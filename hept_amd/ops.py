@@ -58,6 +58,8 @@ def _on_device(fn):
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype is torch.float32 and t.is_cuda and t.is_contiguous() and not (t.data_ptr() & 15):
+        return t   # the usual case, checked first: this function runs a dozen times per forward
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (hept_amd has no CPU path); got device {t.device}")
     if t.dtype != torch.float32:
@@ -77,8 +79,19 @@ def _dims(q: torch.Tensor, coords: torch.Tensor, alpha: torch.Tensor) -> Tuple[i
     return n, h, hd // h, c, t
 
 
+@functools.lru_cache(maxsize=256)
+def _workspace_bytes_cached(n: int, h: int, d: int, c: int, tl: int, b: int, prec: int) -> int:
+    # a pure function of the sizes (no tensor, no parameter): remembered per shape -- one ctypes round trip less per call
+    return int(_lib.load().hept_workspace_bytes(n, h, d, c, tl, b, prec))
+
+
+@functools.lru_cache(maxsize=256)
+def _check_shape_cached(n: int, h: int, d: int, c: int, tl: int, b: int) -> int:
+    return int(_lib.load().hept_check_shape(n, h, d, c, tl, b))
+
+
 def workspace_bytes(n, h, d, c, tl, b, precision) -> int:
-    return int(_lib.load().hept_workspace_bytes(n, h, d, c, tl, b, precision_code(precision)))
+    return _workspace_bytes_cached(int(n), int(h), int(d), int(c), int(tl), int(b), precision_code(precision))
 
 
 def exchange_bytes(n, h, d, world, precision) -> int:
@@ -384,8 +397,8 @@ def forward(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *
     q, k, v, coords, codes, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, codes, w_rpe_weight, alpha,
                                                                 block_size, w_per_dist)
     prec = precision_code(precision)
-    _lib.check(lib.hept_check_shape(n, h, d, c, t, block_size), "hept_check_shape")
-    need = int(lib.hept_workspace_bytes(n, h, d, c, t, block_size, prec))
+    _lib.check(_check_shape_cached(n, h, d, c, t, block_size), "hept_check_shape")
+    need = _workspace_bytes_cached(n, h, d, c, t, block_size, prec)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, device=q.device, dtype=torch.uint8)
     ow = _f32c(out_weight, "out_linear.weight")
