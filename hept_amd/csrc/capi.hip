@@ -119,7 +119,9 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
     // role there (tracking-60k, T = 1: 111.0 -> 104.7 us per forward; two tables and more, and f32 rows at any count,
     // are faster with riders: profiles/r04_experiments.txt)
     const bool f32_rows = precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA;
-    const bool ride = Tl <= HEPT_MAX_TABLES && (Tl >= 2 || f32_rows) && hept_sort_carries_rows(N, H, D) && !row_riders_off();
+    // (HEPT_FORCE_ROW_RIDERS=1: riders at any table count -- A/B measurements; read once)
+    static const bool force_ride = [] { const char* e = getenv("HEPT_FORCE_ROW_RIDERS"); return e && *e && *e != '0'; }();
+    const bool ride = Tl <= HEPT_MAX_TABLES && (Tl >= 2 || f32_rows || force_ride) && hept_sort_carries_rows(N, H, D) && !row_riders_off();
     const HeptRowsJob job{v, w.kvhat, N, raw_size, H, D, precision};
     const HeptRowsJob* rows = ride ? &job : nullptr;
     for (int c0 = 0; c0 < Tl; c0 += HEPT_MAX_TABLES) {   // chunks of tables (the rows are rewritten identically)
