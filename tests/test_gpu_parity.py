@@ -377,6 +377,32 @@ def test_split_bf16_products_match_the_f32_mfma_kernel(name, gpu_device):
     assert _rows_ok(a, b, ATOL.get(name, 1e-5), 1e-4) >= 0.995
 
 
+@pytest.mark.parametrize("n", [6016, 16384])
+def test_sort_is_exact_when_the_sampled_code_maximum_misses_the_largest_codes(n, gpu_device):
+    """Round 5: the row builder takes the largest AND code from every 8th tile of 8 points only -- it merely scales the
+    sort's bucket ids.  Adversarial case: every SAMPLED point has code 0 and all the others a large code, so the bound is
+    far too small and 7/8 of the keys land beyond it (they share the last bucket id: one bucket far over its region's
+    capacity at 16 384 points, the one-launch sort at 6 016).  The permutation must still be the exact stable sort."""
+    g_ = torch.Generator().manual_seed(23)
+    h, d, c, t = 8, 24, 6, 3
+    q, k, v = (torch.randn(n, h * d, generator=g_) for _ in range(3))
+    coords = torch.randn(n, c, generator=g_)
+    alpha = torch.randn(h, d + c, t, generator=g_)
+    sqrt_w = torch.rand(h, c, generator=g_) + 0.5
+    tile = torch.arange(n) // 8
+    codes = torch.where(tile % 8 == 0, torch.zeros(n, dtype=torch.int64), 900 + torch.arange(n) % 37)
+    codes = codes.expand(t, h, n).contiguous()
+    dev = gpu_device
+    ph = ops.prep_hash(q.to(dev), k.to(dev), v.to(dev), coords.to(dev), sqrt_w.to(dev), alpha.to(dev), codes.to(dev), "fp32")
+    mm = ph["minmax"]
+    assert float(mm[..., 2].max()) == 0.0          # the sample saw code 0 only
+    qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], codes.to(dev), mm)
+    span = mm[..., 1].amax(-1) - mm[..., 0].amin(-1)
+    offs = codes.to(dev).float() * span[..., None]
+    for pos, proj in ((qpos, ph["qproj"]), (kpos, ph["kproj"])):
+        assert torch.equal(pos.long(), torch.sort(proj + offs, dim=-1, stable=True).indices)
+
+
 def _almost_sorted(keys, pos, tol):
     """Largest amount by which a key, taken in the order `pos`, lies below an earlier one (0 = sorted)."""
     ks = torch.gather(keys, -1, pos)
