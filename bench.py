@@ -531,12 +531,16 @@ def worker(args) -> int:
             with torch.no_grad():
                 w_rpe1.weight.copy_(g1["w_rpe_weight"])
             kw1 = dict(w_rpe=w_rpe1, coords=g1["coords"], combined_shifts=g1["combined_shifts"])
-            for name, mode, via in (("plain", None, None), ("one_sided", "all_to_all", "p2p"), ("rccl", "all_to_all", "rccl"),
+            # one_sided_view: TableSharding(out_view=True) -- the step ends at the last output flag, the caller reads the
+            # gathered output in the exchange buffer (no copy out of it)
+            for name, mode, via in (("plain", None, None), ("one_sided", "all_to_all", "p2p"),
+                                    ("one_sided_view", "all_to_all", "p2p"), ("rccl", "all_to_all", "rccl"),
                                     ("all_reduce", "all_reduce", None)):
                 m = HEPTAttention(D + c1, h_dim=D, num_heads=H, block_size=B, n_hashes=1, num_w_per_dist=10, precision=precision,
                                   process_group=dist.group.WORLD if mode else None)
                 if mode:
-                    m.sharding = TableSharding(1, dist.group.WORLD, mode=mode, always_exchange=True, head_groups=1)
+                    m.sharding = TableSharding(1, dist.group.WORLD, mode=mode, always_exchange=True, head_groups=1,
+                                               out_view=name.endswith("_view"))
                     if via:
                         m.sharding.exchange = via
                 m.load_state_dict({"out_linear.weight": inp1["out_weight"], "out_linear.bias": inp1["out_bias"],

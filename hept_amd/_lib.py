@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 # (kept in step with hept_amd/build.py, which is not imported here so that `python -m hept_amd.build` runs clean)
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
 ROW = 32
 MAX_TABLES = 8
@@ -88,6 +88,8 @@ SIGNATURES = {
     "hept_comm_status": (c_int, [_P, _P]),
     "hept_comm_p2p_flags": (c_int, [_P, _P, _P]),
     "hept_comm_reset_status": (c_int, [_P]),
+    "hept_comm_set_out_view": (c_int, [_P, c_int]),
+    "hept_comm_out_view": (c_int, [_P, _P]),
     "hept_prepare_src_workspace_bytes": (c_size_t, [c_int]),
     "hept_prepare_input_src": (c_int, [_P, c_int, _P] + [c_int] * 3 + [_P, c_int, c_int, _P, c_size_t] + [_P] * 5),
     "hept_rows_wgrad_scratch_bytes": (c_size_t, [c_int, c_int]),

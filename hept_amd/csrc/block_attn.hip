@@ -283,8 +283,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
             }
         }
     }
-    // direct mode: the last workgroup of the launch raises this rank's row flag in every rank's buffer
-    if (pa.direct) signal_when_all_done(pa.counter, pa.peers, pa.world, pa.flag_idx, pa.epoch);
+    // (direct mode: this rank's row flags are raised by the next kernel of the stream, p2p_dev.h raise_flags)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -533,7 +532,6 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
             }
         }
     }
-    if (pa.direct) signal_when_all_done(pa.counter, pa.peers, pa.world, pa.flag_idx, pa.epoch);
 }
 
 template <bool FULL, int VP>

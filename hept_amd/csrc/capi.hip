@@ -172,7 +172,7 @@ void hept_prof_mark_sort_mid(void* stream) {
     if (g_prof.mode == 2 && prof_active() && !g_prof.mid[g_prof.n_calls]) prof_mark(PROF_SORT_MID, (hipStream_t)stream);
 }
 
-extern "C" int hept_abi_version(void) { return 19; }
+extern "C" int hept_abi_version(void) { return 20; }
 
 extern "C" int hept_part_precision(int precision, int D) {
     return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
@@ -376,13 +376,22 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
                   const float* out_weight, const float* out_bias, int N, int H, int D, int C, int K, int T, int t0,
                   int Tl, int B, int precision, int head_groups, bool one_sided, const Workspace& w, void* xbuf,
                   float* out_full, void* stream) {
-    const P2pLayout lay = hept_p2p_layout(N, H, D, comm->world, precision);
+    P2pLayout lay = hept_p2p_layout(N, H, D, comm->world, precision);
+    // view mode: the gathered output of step e lies in region e & 1 and is read there by the caller
+    const bool view = one_sided && comm->out_view;
+    if (view && (comm->epoch & 1u)) lay.out_off += lay.out_bytes;
     hipStream_t st = (hipStream_t)stream;
     const int world = comm->world, hg = H / head_groups;
     const int per = (N + world - 1) / world, n_pad = per * world;
     const int aprec = hept_part_precision(precision, D);
     const size_t row = aprec == HEPT_PREC_BF16 ? 64 : 128;
     const size_t group_bytes = (size_t)n_pad * hg * row;       // one head group, all ranks' slices
+    // this rank's points [rank * per, ...): the `world` received slices are the "tables" of the combine
+    const int first = comm->rank * per;
+    const int cnt = first >= N ? 0 : (N - first < per ? N - first : per);
+    // one-sided transport with the fused combine: the rows this rank owes ITSELF stay in ordinary device memory
+    // (hept_comm::p2p_self) instead of the uncached buffer -- 1 / world of the rows at cached speed on both sides
+    const bool mirror = one_sided && D == 24 && cnt >= 1;
     char* send = reinterpret_cast<char*>(xbuf);
     char* recv = one_sided ? comm->p2p_local + lay.recv_off : send + up256((size_t)n_pad * H * row);
     int rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
@@ -400,7 +409,7 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
         // links while the kernel runs; only the drain of the last stores is exposed.
         for (int g = 0; g < head_groups; ++g) {
             PushArgs pa;
-            rc = hept_p2p_direct_args(comm, N, H, D, g * hg, hg, g, aprec, lay, &pa);
+            rc = hept_p2p_direct_args(comm, N, H, D, g * hg, hg, g, aprec, lay, mirror, &pa);
             if (rc) return rc;
             if (rec) prof_mark(2, st);
             rc = hept_block_attn_heads_push(w.qhat, w.kvhat, qpos, kpos, N, H, D, 1, B, precision, g * hg, hg, hg, g * hg,
@@ -425,7 +434,7 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
             const bool carry = g > 0;
             if (carry) {
                 rc = hept_p2p_push_args(comm, w.part, pprec, Tl, N, H, D, (g - 1) * hg, hg, g - 1, aprec, lay, PUSH_WGS,
-                                        &pa);
+                                        mirror, &pa);
                 if (rc) return rc;
             }
             if (rec) prof_mark(2, st);
@@ -439,7 +448,7 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
         }
         if (rec_all) prof_mark(3, st);
         rc = hept_p2p_reduce_push(comm, w.part, pprec, Tl, N, H, D, (head_groups - 1) * hg, hg, head_groups - 1, aprec,
-                                  lay, st);
+                                  lay, mirror, st);
         if (rc) return rc;
         if (rec_all) prof_mark(4, st);   // the exposed push: table sum + rows of the last head group
     }
@@ -483,15 +492,13 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
         (hipEventRecord(comm->join, comm->side) != hipSuccess || hipStreamWaitEvent(st, comm->join, 0) != hipSuccess))
         return HEPT_ERR_LAUNCH;
     if (rec_all && !one_sided) prof_mark(4, st);   // the exposed transfer: last group's table sum + all-to-all (+ join)
-    // this rank's points [rank * per, ...): the `world` received slices are the "tables" of the combine
-    const int first = comm->rank * per;
-    const int cnt = first >= N ? 0 : (N - first < per ? N - first : per);
-    if (one_sided && D == 24 && cnt >= 1) {
+    if (mirror) {
         // wait for the rows + combine + push of the output slice + output flag in one kernel, then gather
-        rc = hept_p2p_combine_push(comm, head_groups, per, cnt, H, hg, aprec, out_weight, out_bias, lay, st);
+        rc = hept_p2p_combine_push(comm, head_groups, per, cnt, H, hg, aprec, out_weight, out_bias, lay, out_full, st);
         if (rc) return rc;
         if (rec_all) prof_mark(5, st);   // wait for the rows + combine + output slice to every rank
-        rc = hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, st);
+        rc = out_full ? hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, true, st) : hept_p2p_wait_out(comm, N, D, lay, st);
+        if (!rc && view) comm->last_out = reinterpret_cast<const float*>(comm->p2p_local + lay.out_off);
         if (rec_all) {
             prof_mark(6, st);            // wait for every rank's slice + copy out
             prof_call_done();
@@ -515,7 +522,8 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
         rc = hept_p2p_push_out(comm, per, D, lay, st);
         if (rc) return rc;
         if (rec_all) prof_mark(5, st);
-        rc = hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, st);
+        rc = out_full ? hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, false, st) : hept_p2p_wait_out(comm, N, D, lay, st);
+        if (!rc && view) comm->last_out = reinterpret_cast<const float*>(comm->p2p_local + lay.out_off);
     } else {
         if (rec_all) prof_mark(5, st);
         rc = hept_comm_all_gather_f32(comm, out_full, (size_t)per * D, st);
@@ -534,9 +542,10 @@ int forward_sharded_impl(hept_comm* comm, const float* q, const float* k, const 
                          size_t workspace_bytes, void* xbuf, size_t xbuf_bytes, float* out_full, void* stream) {
     // Everything that can be refused is refused BEFORE the step takes its epoch: a rank that bails out here has not
     // moved, and the others time out against it once (and say so) instead of running one epoch apart for good.
-    if (!comm || !q || !k || !v || !coords || !w_rpe || !alpha || !out_weight || !workspace || !out_full)
-        return HEPT_ERR_ARG;
+    if (!comm || !q || !k || !v || !coords || !w_rpe || !alpha || !out_weight || !workspace) return HEPT_ERR_ARG;
     const bool one_sided = transport == HEPT_TRANSPORT_ONE_SIDED;
+    // no output pointer: the one-sided transport in view mode only (the output is read in the exchange buffer)
+    if (!out_full && !(one_sided && comm->out_view)) return HEPT_ERR_ARG;
     if (!one_sided && (transport != HEPT_TRANSPORT_RCCL || !xbuf)) return HEPT_ERR_ARG;
     int rc = hept_check_shape(N, H, D, C, Tl, B);
     if (rc) return rc;

@@ -95,8 +95,10 @@ constexpr int FFN_D = 24, FFN_PITCH = 25, FFN_WFLOATS = 2 * FFN_D * FFN_D + 4 * 
 // the arrival flags of every (head group, source rank) -- and the finished rows go to this rank's slice of the
 // gathered output in EVERY rank's exchange buffer: the 32 x D tile passes through LDS so that each lane stores 16-B
 // pieces of contiguous rows (a 4-byte scatter per accumulator register would put 4-byte writes on the xGMI links);
-// the last workgroup raises this rank's output flag everywhere.
-// STG (packed rows, D = 24, plain (Tl, N, H, row) layout, even H): the rows reach the lanes THROUGH LDS.  A lane that
+// the kernel that follows on the stream (the gather) raises this rank's output flag everywhere.
+// STG (D = 24, an even number of heads per head group -- the plain (Tl, N, H, row) layout and, since round 5, the receive
+// region of the table-sharded step, whose rows lie in uncached memory where a 16-B piece per lane is a memory request of
+// its own): the rows reach the lanes THROUGH LDS.  A lane that
 // loads "its" row touches 64 different lines per wave instruction, 16 B of each (the texture addresser works through them
 // one by one, and the L1 has to hold every line until its fourth piece is asked for); here a wave instruction is a
 // direct-to-LDS load (global_load_lds_dwordx4) of 8 points x 128 B -- the two rows of a head pair, whole lines -- into a
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                                                                   FfnIn ffn = FfnIn{}, P2pDev px = P2pDev{},
                                                                   int stg_off = 0) {
     static_assert(!PUSH || (DT == 24 && !FFN), "the pushing epilogue is built for D = 24 rows");
-    static_assert(!STG || (DT == 24 && !PUSH), "staged rows: D = 24 rows of the plain layout");
+    static_assert(!STG || DT == 24, "staged rows: D = 24");
     constexpr int ROWF = P16 ? 16 : 32;   // row pitch in 4-byte units
     extern __shared__ __attribute__((aligned(16))) float wt_s[];  // [H (even-padded)][28 (d)][32 (c, zero padded)]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
@@ -151,6 +153,8 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     float* stage_s = ffn_s + FFN_WFLOATS + w * 32 * FFN_PITCH;  // this wave's 32 x D tile
     float* stage_s_end = ffn_s + (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0);
     if constexpr (PUSH) {
+        // the launches that stored this rank's rows into the owners' buffers have ended: announce them (raise_flags)
+        if (blockIdx.x < RAISE_WGS) raise_flags(px.peers, px.world, px.wait_groups, px.me, HEPT_MAX_RANKS_DEV, px.epoch);
         if (tid < px.wait_groups * px.world) {
             const int g = tid / px.world, src = tid - g * px.world;
             wait_flag(flag_word(px.local, g * HEPT_MAX_RANKS_DEV + src), px.epoch, px.status, 1u, px.timeout);
@@ -168,11 +172,17 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     const int n_tiles = (n_count + 31) / 32;
     const int hp0 = SPLIT ? 2 * w : 0, hstep = SPLIT ? 2 * CMB_WAVES : 2;
     const int tpre = Tl < 3 ? Tl : 3;
-    auto row_at = [&](int tile, int hp) {
+    // table t's rows.  PUSH: the "tables" are the source ranks' slices of the receive region, and the slice this rank
+    // sent to itself lies in ordinary (cached) device memory instead (P2pDev::self_rows, same layout)
+    auto tbl = [&](int t) {
+        if constexpr (PUSH) return (t == px.me ? px.self_rows : part) + (size_t)t * tstride;
+        else return part + (size_t)t * tstride;
+    };
+    auto row_at = [&](int tile, int hp) {   // offset of this lane's row inside a table
         const int i = tile * 32 + li;
         const int n = n0 + (i < n_count ? i : n_count - 1);
         const int head = hp + hh < H ? hp + hh : 0, g = head / HG;
-        return part + (size_t)n * HG * ROWF + (size_t)g * gstride + (size_t)(head - g * HG) * ROWF;
+        return (size_t)n * HG * ROWF + (size_t)g * gstride + (size_t)(head - g * HG) * ROWF;
     };
     const int tile_first = SPLIT ? blockIdx.x : blockIdx.x * CMB_WAVES + w;
     RawRow<P16> cur[3], nxt[3];  // up to 3 tables in flight; more tables are loaded in place below
@@ -197,7 +207,9 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
             const int slot = j * 64 + lane, pt = slot >> 4, sub = (slot & 15) ^ (pt & 15);
             const int i2 = u.tile * 32 + pt;
             const int n = n0 + (i2 < n_count ? i2 : n_count - 1);
-            const char* g = reinterpret_cast<const char*>(part + (size_t)u.t * tstride) + ((size_t)n * H + u.hp) * 128 + sub * 16;
+            const int grp = u.hp / HG;   // (a head pair never straddles two head groups: HG is even)
+            const char* g = reinterpret_cast<const char*>(tbl(u.t) + (size_t)grp * gstride) +
+                            ((size_t)n * HG + (u.hp - grp * HG)) * 128 + sub * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(stg + slot_buf * STG32_UNIT_BYTES + j * 1024),
                                              16, 0, 0);
@@ -213,8 +225,9 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                     const int slot = j * 64 + lane, pt = slot >> 3, sub = (slot & 7) ^ ((pt >> 1) & 7);
                     const int i2 = tile * 32 + pt;
                     const int n = n0 + (i2 < n_count ? i2 : n_count - 1);
-                    const char* g = reinterpret_cast<const char*>(part + (size_t)t * tstride) +
-                                    ((size_t)n * H + hp) * 64 + sub * 16;
+                    const int grp = hp / HG;
+                    const char* g = reinterpret_cast<const char*>(tbl(t) + (size_t)grp * gstride) +
+                                    ((size_t)n * HG + (hp - grp * HG)) * 64 + sub * 16;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(stg + t * STG_TABLE_BYTES + j * 1024),
                                                      16, 0, 0);
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         else {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
-                if (t < tpre) cur[t].load(row_at(tile_first, hp0) + (size_t)t * tstride);
+                if (t < tpre) cur[t].load(tbl(t) + row_at(tile_first, hp0));
         }
     }
     if constexpr (FFN) {
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
                     if ((more || wrap) && t < tpre)
-                        nxt[t].load((more ? row_of(hp + hstep) : row_at(tile_next, hp0)) + (size_t)t * tstride);
+                        nxt[t].load(tbl(t) + (more ? row_of(hp + hstep) : row_at(tile_next, hp0)));
             }
             // this head's weight column, requested before the rows are unpacked (LDS latency hides under the VALU work)
             float wv[28];
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                 if (t < tpre) den += cur[t].add_to(s, D);
             for (int t = 3; t < Tl; ++t) {  // beyond three tables: plain loads
                 RawRow<P16> extra;
-                extra.load(row_of(hp) + (size_t)t * tstride);
+                extra.load(tbl(t) + row_of(hp));
                 den += extra.add_to(s, D);
             }
             }
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
                     if ((more || wrap) && t < tpre)
-                        cur[t].load((more ? row_of(hp + hstep) : row_at(tile_next, hp0)) + (size_t)t * tstride);
+                        cur[t].load(tbl(t) + (more ? row_of(hp + hstep) : row_at(tile_next, hp0)));
             }
             const float inv = 1.0f / den;
 #pragma unroll
@@ -453,7 +466,13 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                 if (c < rows * 6) {
                     u32x4 v = *reinterpret_cast<const u32x4*>(push_s + 4 * c);
                     if (poisoned) v = u32x4{0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u};
-                    for (int s = 0; s < px.world; ++s) store16_system(px.peers[s] + tile_off + (size_t)c * 16, v);
+                    for (int s = 0; s < px.world; ++s) {
+                        // (own slice: an ordinary store into the caller's output, when the step has one -- the gather
+                        //  then copies the other ranks' slices only; view mode reads it in the exchange buffer)
+                        if (s == px.me && px.out_local)
+                            *reinterpret_cast<u32x4*>(px.out_local + tile_off - px.out_base + (size_t)c * 16) = v;
+                        else store16_system(px.peers[s] + tile_off + (size_t)c * 16, v);
+                    }
                 }
             }
         } else {
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         }
         if constexpr (SPLIT) __syncthreads();
     }
-    if constexpr (PUSH) signal_when_all_done(px.counter, px.peers, px.world, OUT_FLAG_WORD + px.me, px.epoch);
+    // (PUSH: this rank's output flag is raised by the gather kernel that follows, p2p.hip)
 }
 
 // 16 consecutive columns [16*hh, 16*hh+16) of one partial row, widened to fp32 (reduce_tables)
@@ -913,9 +932,10 @@ int combine_launch(hipStream_t st, const float* part, int Tl, int N, int H, int 
     // D = 24 rows are read as 16-B pieces (direct-to-LDS loads of whole rows, the weight column as f32x4 loads): a base
     // that is not 16-B aligned would fault inside the kernel instead of failing here (include/hept_hip.h says so)
     if (DT == 24 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(part)) & 15)) return HEPT_ERR_ARG;
-    // staged rows: packed rows of the plain layout (no head groups), even head count
-    if constexpr (DT == 24 && !PUSH) {
-        if (HG == H && H % 2 == 0 && !staged_combine_off()) {
+    // staged rows: an even number of heads per head group (a staged unit is the two rows of a head pair, contiguous in
+    // a point's slot) -- the plain layout, and the receive region of the table-sharded step (PUSH; "tables" = source ranks)
+    if constexpr (DT == 24) {
+        if (HG % 2 == 0 && H % 2 == 0 && !staged_combine_off()) {
             const int rc = combine_launch_impl<P16, FFN, DT, PUSH, true>(st, part, Tl, N, H, D, n0, n_count, W, b, out, ffn, HG, gstride, px);
             if (rc != CMB_NO_LDS) return rc;   // (the raise of the dynamic LDS limit failed: lane-by-lane loads need less)
         }

@@ -20,17 +20,22 @@ struct hept_comm {
     hipEvent_t join = nullptr;
     // ---- one-sided transport
     char* p2p_local = nullptr;   // this rank's exchange buffer: [flags | received rows | gathered output]
+    char* p2p_self = nullptr;    // ordinary device memory of the same size and layout: the rows this rank sends to itself
     size_t p2p_bytes = 0;
     char* p2p_peer[HEPT_MAX_RANKS] = {};  // every rank's buffer as mapped here (own rank: p2p_local)
     bool p2p_open = false;
     char** d_peer = nullptr;     // device copy of p2p_peer
-    unsigned int* d_state = nullptr;  // device words: [0..7] per-group completion counters, [8] output counter, [16] status,
+    unsigned int* d_state = nullptr;  // device words: [0..8] unused since round 5 (completion counters of rounds 2-4), [16] status,
                                       // [18, 19] device address of h_status (p2p_dev.h: HEPT_STATE_*)
     unsigned int* h_status = nullptr; // host-mapped copy of the status word: a kernel whose wait timed out writes it
     bool broken = false;              // a step failed on the host after it had taken its epoch: the ranks' epochs may
                                       // differ, the transport refuses further steps until hept_comm_reset_status
     unsigned int epoch = 0;      // one per forward call, the same on every rank
     unsigned long long timeout_ticks = 0;  // bound of a device-side wait in wall_clock64 ticks (HEPT_P2P_TIMEOUT_S, 20 s)
+    // Output gather without the copy (hept_comm_set_out_view): the gathered output stays in the exchange buffer, in one
+    // of two regions taken in turn (epoch parity), and hept_comm_out_view hands the caller the region of the last step
+    bool out_view = false;
+    const float* last_out = nullptr;
 };
 
 // all-to-all of `bytes_per_peer` bytes per rank pair on `st` (ncclAllToAll on bytes)
@@ -43,20 +48,21 @@ void hept_p2p_release(hept_comm* c);        // unmap / free the one-sided buffer
 
 // one-sided transport (p2p.hip); layouts in bytes from the start of a rank's exchange buffer
 struct P2pLayout {
-    size_t recv_off, out_off, bytes;
+    size_t recv_off, out_off, out_bytes, bytes;   // two gathered-output regions of out_bytes each at out_off
 };
 P2pLayout hept_p2p_layout(int N, int H, int D, int world, int precision);
 // sum over the local tables of heads [h0, h0 + hg) -> rows stored into the owners' receive buffers, then flags
+// (mirror: this rank's own rows go to hept_comm::p2p_self instead of its uncached buffer -- the fused combine reads them there)
 int hept_p2p_reduce_push(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0,
-                         int hg, int g, int acc_precision, const P2pLayout& lay, hipStream_t st);
+                         int hg, int g, int acc_precision, const P2pLayout& lay, bool mirror, hipStream_t st);
 // the same work described as kernel arguments, for a block-attention launch that carries it as extra workgroups
 struct PushArgs;
 int hept_p2p_push_args(hept_comm* c, const float* part, int part_precision, int Tl, int N, int H, int D, int h0, int hg,
-                       int g, int acc_precision, const P2pLayout& lay, int push_wgs, PushArgs* out);
+                       int g, int acc_precision, const P2pLayout& lay, int push_wgs, bool mirror, PushArgs* out);
 // one local table per rank: arguments of a block-attention launch that scatters its rows straight into the owners'
 // receive buffers and raises the flags itself (PushArgs::direct)
 int hept_p2p_direct_args(hept_comm* c, int N, int H, int D, int h0, int hg, int g, int acc_precision,
-                         const P2pLayout& lay, PushArgs* out);
+                         const P2pLayout& lay, bool mirror, PushArgs* out);
 int hept_block_attn_heads_push(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
                                int H, int D, int Tl, int B, int precision, int h0, int hg, int hout, int hsub,
                                int n_rows_out, float* part, const PushArgs* push, void* stream);   // block_attn.hip
@@ -65,9 +71,15 @@ int hept_p2p_wait_rows(hept_comm* c, int head_groups, hipStream_t st);
 int hept_p2p_push_out(hept_comm* c, int per, int D, const P2pLayout& lay, hipStream_t st);
 // the three steps above fused into the combine (D == 24): wait for the rows, combine `cnt` >= 1 points of this rank,
 // store them into every rank's gathered output, raise the output flag
+// (own rows are read in p2p_self; out_local: the caller's (n_pad, D) output or null -- own slice is stored there directly)
 int hept_p2p_combine_push(hept_comm* c, int head_groups, int per, int cnt, int H, int hg, int acc_precision,
-                          const float* out_weight, const float* out_bias, const P2pLayout& lay, hipStream_t st);
+                          const float* out_weight, const float* out_bias, const P2pLayout& lay, float* out_local,
+                          hipStream_t st);
 // wait for every rank's slice, then copy the gathered (n_pad, D) output to `dst`
 // (rows [N, n_pad) are written as zeros; the whole output as NaN when a wait of the step timed out)
-int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int N, int D, const P2pLayout& lay, float* dst, hipStream_t st);
+// (skip_own: this rank's slice has been stored into dst by the combine itself)
+int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int N, int D, const P2pLayout& lay, float* dst, bool skip_own,
+                           hipStream_t st);
+// view mode: wait for every rank's slice; the gathered output stays where it is (NaN-filled when a wait timed out)
+int hept_p2p_wait_out(hept_comm* c, int N, int D, const P2pLayout& lay, hipStream_t st);
 int hept_p2p_failed(const hept_comm* c);   // non-zero: a wait timed out or a step failed mid-way (no device sync)

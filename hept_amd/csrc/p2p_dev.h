@@ -11,11 +11,13 @@ struct P2pDev {
     char* local;                 // this rank's exchange buffer
     int world, me;
     unsigned int epoch;
-    unsigned int* counter;       // completion counter of the kernel that signals
     unsigned int* status;        // sticky error word
     unsigned long long timeout;  // bound of a wait, in wall_clock64 ticks
     int wait_groups;             // flags to wait for before reading received rows: wait_groups * world
     size_t slice_off;            // bytes from a buffer's start to this rank's slice of the gathered output
+    const float* self_rows;      // the rows this rank sent to itself: ordinary device memory, laid out like the receive region
+    char* out_local;             // the caller's (n_pad, D) output, or null (view mode): this rank's own slice goes there
+    size_t out_base;             // bytes from a buffer's start to row 0 of the gathered output
 };
 
 // One head group's table sum + one-sided push (p2p.hip: reduce_push_kernel), as a body that can also ride in the
@@ -29,14 +31,16 @@ struct PushArgs {
     char* const* peers;
     size_t recv_off, group_off;
     unsigned int epoch;
-    unsigned int* counter;
     int flag_idx;
     int push_wgs;             // workgroups of the launch that push (the first ones of the grid); 0: none
     // direct != 0 (one local table per rank, BASELINE config 4): nothing is summed and nothing is carried -- the block
     // attention of heads [h0, h0 + hg) stores every finished row straight into the receive buffer of the rank that
-    // owns the point (direct_row below; `part`, `Tl`, `push_wgs` are unused), and the launch's last workgroup raises
-    // the flags.  No extra pass over the rows, no separate push: only the drain of the last stores is exposed.
+    // owns the point (direct_row below; `part`, `Tl`, `push_wgs` are unused).  No extra pass over the rows, no
+    // separate push: only the drain of the last stores is exposed.
     int direct;
+    // Rows whose owner is THIS rank never leave the GPU: they go to an ordinary (cached) mirror of the exchange buffer
+    // (same offsets) instead of the uncached buffer the peers store into -- the combine reads its own "table" there.
+    char* self;
 };
 
 namespace {
@@ -49,7 +53,7 @@ __device__ __forceinline__ unsigned int* flag_word(char* base, int idx) {
 
 // 16 bytes to a (possibly remote) exchange buffer as two system-scope stores (global_store_dwordx2 sc0 sc1): written
 // through to the destination whatever caching the mapping of a peer's buffer has, and counted by vmcnt until the
-// write has been acknowledged -- which is what lets one fence per kernel (signal_when_all_done) stand for all of them.
+// write has been acknowledged -- a wave cannot end before that, which is what raise_flags relies on.
 __device__ __forceinline__ void store16_system(void* dst, const u32x4& v) {
     // (the pointer comes out of a table of peer bases: tell the compiler it is global memory, not a FLAT address)
     typedef unsigned long long __attribute__((address_space(1))) * gptr_t;
@@ -93,29 +97,22 @@ __device__ __forceinline__ bool wait_flag(const unsigned int* flag, unsigned int
     return true;
 }
 
-// The last workgroup of a kernel to get here raises `flag_idx` = epoch in every rank's buffer.
-// Ordering: every store into an exchange buffer is a system-scope store (store16_system): written through, and the
-// wave's vmcnt reaches zero only when it has been acknowledged.  __syncthreads() makes every wave of the workgroup wait
-// wave's vmcnt reaches zero only when it has been acknowledged: every wave waits for that explicitly (s_waitcnt
-// vmcnt(0), no cache maintenance), the workgroup meets at a barrier and counts itself in.  Only the single thread that sees the count complete pays for a system-scope fence before it writes the
-// flags.  (A system-scope fence in every thread was the first build: thousands of L2 write-backs per launch while the
-// block attention keeps the L2 dirty -- 153 us for a kernel that moves 12 us of data.)
-__device__ __forceinline__ void signal_when_all_done(unsigned int* counter, char* const* peers, int world, int flag_idx,
-                                                     unsigned int epoch, unsigned int n_workgroups = 0) {
-    if (n_workgroups == 0) n_workgroups = gridDim.x;   // every workgroup of the launch takes part
-    // every wave waits for the acknowledgement of its own stores: vmcnt counts loads AND stores on gfx9, and the
-    // workgroup barrier below does not wait for it (its fence is workgroup scope: s_waitcnt lgkmcnt(0) only -- checked
-    // in the ISA), so without this line the flag could overtake stores that are still in flight
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == n_workgroups - 1) {
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            for (int s = 0; s < world; ++s)
-                __hip_atomic_store(flag_word(peers[s], flag_idx), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+// Arrival flags are raised by the NEXT kernel of the stream, not by the kernel that stored the data: a kernel starts
+// only after every wave of its predecessor has ended, and a wave ends only when its stores -- system-scope, written
+// through (store16_system) -- have been acknowledged, so "the producer has finished" is known for free at the
+// consumer's first instruction.  (Rounds 2-4 had the producers count themselves in: every workgroup drained its stores,
+// met at a barrier and waited for a device-scope atomic to come back before it could retire -- which kept the block
+// attention's workgroups resident ~45 % longer: 57 instead of 33 us for the one-table launch at tracking-60k.)
+// Threads [0, n_flags * world) of the calling workgroup store flag[base + f * pitch] = epoch in every rank's buffer;
+// the stores are idempotent, so any number of workgroups may do it (the callers use the first few of the grid: a
+// workgroup that waits for this rank's own flag must never depend on a later workgroup getting a slot).
+constexpr int RAISE_WGS = 16;
+__device__ __forceinline__ void raise_flags(char* const* peers, int world, int n_flags, int base, int pitch,
+                                            unsigned int epoch) {
+    const int i = threadIdx.x;
+    if (i < n_flags * world) {
+        const int f = i / world, s = i - f * world;
+        __hip_atomic_store(flag_word(peers[s], base + f * pitch), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -125,7 +122,7 @@ __device__ __forceinline__ void signal_when_all_done(unsigned int* counter, char
 __device__ __forceinline__ char* direct_row(const PushArgs& a, int n, int hl, int rowb, bool& remote) {
     const int dest = n / a.per;
     remote = dest != a.me;
-    return a.peers[dest] + a.recv_off + a.group_off + (((size_t)a.me * a.per + (n - dest * a.per)) * a.hg + hl) * rowb;
+    return (remote ? a.peers[dest] : a.self) + a.recv_off + a.group_off + (((size_t)a.me * a.per + (n - dest * a.per)) * a.hg + hl) * rowb;
 }
 __device__ __forceinline__ void store4_system(void* dst, unsigned int v) {
     typedef unsigned int __attribute__((address_space(1))) * gptr_t;
@@ -194,12 +191,13 @@ __device__ __forceinline__ void reduce_push_body(const PushArgs& a, int wg_index
             }
         }
         const int dest = n / a.per;
-        char* row = a.peers[dest] + a.recv_off + a.group_off + (((size_t)a.me * a.per + (n - dest * a.per)) * a.hg + hl) * ROWB;
-        // own rows: the buffer is this rank's uncached memory (write-through as it is): one 16-B store
+        char* row = (dest == a.me ? a.self : a.peers[dest]) + a.recv_off + a.group_off +
+                    (((size_t)a.me * a.per + (n - dest * a.per)) * a.hg + hl) * ROWB;
+        // own rows: ordinary memory, one 16-B store
         if (dest == a.me) *reinterpret_cast<u32x4*>(row + pc * 16) = v;
         else store16_system(row + pc * 16, v);
     }
-    signal_when_all_done(a.counter, a.peers, a.world, a.flag_idx, a.epoch, (unsigned int)a.push_wgs);
+    // (no signal: the flags of every head group are raised by the kernel that waits for the rows, see raise_flags)
 }
 
 }  // namespace

@@ -190,7 +190,7 @@ class HEPTAttention(nn.Module):
                 return ops.forward_sharded(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
                                            self.e2lsh.alpha, self.out_linear.weight, self.out_linear.bias, comm=comm,
                                            world=sh.world, t0=t0, tl=tl, head_groups=sh.groups_for(h), workspace=ws,
-                                           xbuf=xbuf, one_sided=one_sided, geo=geo, **common)
+                                           xbuf=xbuf, one_sided=one_sided, geo=geo, out_view=sh.out_view, **common)
             # the same pipeline driven from Python over torch.distributed (gloo in the tests; fallback)
             dims = ops.partial_begin(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
                                      self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, geo=geo, **common)

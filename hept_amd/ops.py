@@ -678,12 +678,14 @@ def combine_groups(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: 
 def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *, comm: int, world: int,
                     block_size: int, w_per_dist: int, t0: int, tl: int, head_groups: int, precision="fp32",
                     workspace: torch.Tensor, xbuf: Optional[torch.Tensor] = None, one_sided: bool = False,
-                    geo=None) -> torch.Tensor:
+                    geo=None, out_view: bool = False) -> torch.Tensor:
     """Table-sharded operator in one C call (``hept_forward_sharded``): this rank's tables [t0, t0+tl), the RCCL
     exchange pipelined by head groups on the communicator's side stream, combine of this rank's points and the
     all-gather; returns the full (N, D) output.  ``comm`` is a ``hept_comm*`` (see ``hept_amd.sharding``);
     ``one_sided`` selects the transport that stores rows straight into the peers' mapped exchange buffers
-    (``hept_comm_p2p_*``; ``xbuf`` is then not needed)."""
+    (``hept_comm_p2p_*``; ``xbuf`` is then not needed).  ``out_view`` (one-sided transport, the communicator in view
+    mode -- ``hept_comm_set_out_view``): the result is a tensor over the communicator's exchange buffer instead of a
+    copy; it is overwritten by the SECOND next sharded call on this communicator (``TableSharding(out_view=True)``)."""
     lib = _lib.load()
     q, k, v, coords, codes, w, alpha, (n, h, d, c, t) = _prepare(q, k, v, coords, codes, w_rpe_weight, alpha,
                                                                 block_size, w_per_dist)
@@ -696,11 +698,12 @@ def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out
     ow = _f32c(out_weight, "out_linear.weight")
     ob = _f32c(out_bias, "out_linear.bias") if out_bias is not None else None
     per = (n + world - 1) // world
-    out_full = torch.empty(per * world, d, device=q.device, dtype=torch.float32)
+    view = bool(out_view and one_sided)
+    out_full = None if view else torch.empty(per * world, d, device=q.device, dtype=torch.float32)
     tail = (n, h, d, c, w_per_dist, t, t0, tl, block_size, prec, head_groups,
             _lib.TRANSPORT_ONE_SIDED if one_sided else _lib.TRANSPORT_RCCL, workspace.data_ptr(), workspace.numel(),
             xbuf.data_ptr() if xbuf is not None else None, xbuf.numel() if xbuf is not None else 0,
-            out_full.data_ptr(), _stream(q))
+            out_full.data_ptr() if out_full is not None else None, _stream(q))
     if geo is None:
         rc = lib.hept_forward_sharded(comm, q.data_ptr(), k.data_ptr(), v.data_ptr(), coords.data_ptr(),
                                       codes.data_ptr(), w.data_ptr(), alpha.data_ptr(), ow.data_ptr(),
@@ -713,7 +716,22 @@ def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out
                                           alpha.data_ptr(), ow.data_ptr(), ob.data_ptr() if ob is not None else None,
                                           *tail)
     _lib.check(rc, "hept_forward_sharded")
+    if view:
+        import ctypes
+
+        ptr = ctypes.c_void_p()
+        _lib.check(lib.hept_comm_out_view(comm, ctypes.byref(ptr)), "hept_comm_out_view")
+        return torch.as_tensor(_DeviceRows(ptr.value, n, d), device=q.device)
     return out_full[:n]
+
+
+class _DeviceRows:
+    """(n, d) f32 rows at a device address owned by the C library (the exchange buffer of a communicator), for
+    ``torch.as_tensor`` (zero-copy through ``__cuda_array_interface__``)"""
+
+    def __init__(self, ptr: int, n: int, d: int):
+        self.__cuda_array_interface__ = {"shape": (n, d), "typestr": "<f4", "data": (ptr, False), "version": 2,
+                                         "strides": None}
 
 
 # ---- the dense tail of the Attn block's training step (csrc/block_train.hip; rows of 24 floats)

@@ -54,8 +54,13 @@ def table_slice(n_tables: int, rank: int, world: int) -> Tuple[int, int]:
 
 class TableSharding:
     def __init__(self, n_tables: int, group=None, mode: Optional[str] = None, always_exchange: bool = False,
-                 head_groups: Optional[int] = None):
+                 head_groups: Optional[int] = None, out_view: bool = False):
         self.group = group
+        # one-sided transport only, opt-in: the sharded forward returns a tensor over the exchange buffer instead of
+        # copying the gathered output out of it (include/hept_hip.h, hept_comm_set_out_view).  The tensor is
+        # overwritten by the SECOND next sharded forward on this object: not for callers that keep outputs around
+        # (autograd, several HEPT layers sharing one TableSharding with a skip connection across two of them).
+        self.out_view = bool(out_view)
         # head groups of the pipelined all-to-all; None = by transport (one-sided stores: 4 -- a group's push rides in
         # the next group's attention launch at no extra cost, and the last, exposed push is a quarter of the rows;
         # collectives: 2 -- every further group is another collective launch and cross-stream hand-over)
@@ -161,6 +166,7 @@ class TableSharding:
             if ok:
                 ok = lib.hept_comm_p2p_open(comm, b"".join(hb for _, hb in gathered)) == 0
         if self._agree(ok, device):
+            lib.hept_comm_set_out_view(comm, 1 if self.out_view else 0)
             # every rank's buffer (and its zeroed flags) exists before anybody stores into it
             dist.barrier(group=self.group)
             return True

@@ -258,6 +258,15 @@ int hept_comm_reset_status(hept_comm* comm);   /* collective restart after a fai
  * output flags [source rank] u32 at byte 2048; each holds the epoch of the last arrival) and its own epoch */
 #define HEPT_P2P_FLAG_BYTES 4096
 int hept_comm_p2p_flags(hept_comm* comm, void* out_flags, unsigned int* epoch);
+/* Output gather WITHOUT the final copy (one-sided transport; opt-in, collective: every rank sets the same mode between
+ * steps).  With the mode on, hept_forward_sharded accepts out_full == NULL: the gathered (N, D) f32 output stays in this
+ * rank's exchange buffer -- uncached device memory -- and hept_comm_out_view returns its address after the call (work
+ * that reads it must be ordered after the call on `stream`).  The steps alternate between two output regions, so a
+ * view stays intact during the NEXT hept_forward_sharded on this communicator and is overwritten by the one after it:
+ * consume (or copy) it before the second next call.  After a timed-out wait the view holds NaN, like out_full would.
+ * (What it saves is a 4 N D-byte copy out of uncached memory behind the last flag: 11 -> 3 us at tracking-60k.) */
+int hept_comm_set_out_view(hept_comm* comm, int on);
+int hept_comm_out_view(hept_comm* comm, const float** out);
 int hept_forward_sharded(hept_comm* comm, const float* q, const float* k, const float* v, const float* coords,
                          const int64_t* codes, const float* w_rpe, const float* alpha,
                          const float* out_weight, const float* out_bias,

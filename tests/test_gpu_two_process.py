@@ -115,7 +115,7 @@ def test_sharded_training_matches_single_process(gpu_device):
 _SIZES = [int(os.environ["HEPT_TEST_BIG"])] if os.environ.get("HEPT_TEST_BIG") else [1500, 700]
 
 
-def _synthetic_worker(rank, world, port, precision, exchange, ret, groups=2):
+def _synthetic_worker(rank, world, port, precision, exchange, ret, groups=2, view=False):
     """BASELINE config 4 in miniature: n_hashes = world, one table per rank, the production exchange."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -131,15 +131,22 @@ def _synthetic_worker(rank, world, port, precision, exchange, ret, groups=2):
         g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
         m = HEPTAttention(30, h_dim=24, num_heads=8, block_size=128, n_hashes=world, num_w_per_dist=10,
                           precision=precision, process_group=dist.group.WORLD)
-        m.sharding = TableSharding(world, dist.group.WORLD, mode="all_to_all", head_groups=groups)
+        m.sharding = TableSharding(world, dist.group.WORLD, mode="all_to_all", head_groups=groups, out_view=view)
         m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],
                            "e2lsh.alpha": inp["alpha"]})
         m = m.to(dev).eval()
         w_rpe = torch.nn.Linear(50, 192).to(dev)
         with torch.no_grad():
             w_rpe.weight.copy_(g["w_rpe_weight"])
-            for _ in range(3):  # epochs advance, buffers are reused
-                out = m(g["q"], g["k"], g["v"], w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+            prev = kept = None
+            for j in range(3):  # epochs advance, buffers are reused
+                # (view mode: other values every step, the last step's are the ones compared with the plain operator;
+                #  the output of step j must survive step j + 1, which writes the other region)
+                v = g["v"] * float(3 - j) if view else g["v"]
+                out = m(g["q"], g["k"], v, w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+                if view and prev is not None:
+                    assert out.data_ptr() != prev.data_ptr() and torch.equal(prev, kept)
+                prev, kept = out, out.clone()
         torch.cuda.synchronize()
         m.sharding.check()
         ret[rank] = (out.cpu(), m.sharding.describe())
@@ -147,19 +154,21 @@ def _synthetic_worker(rank, world, port, precision, exchange, ret, groups=2):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision,groups", [("fp32", 2), ("bf16", 2), ("bf16", None), ("mixed16", 1)])
-def test_eight_ranks_one_table_each_match_the_unsharded_operator(precision, groups, gpu_device):
+@pytest.mark.parametrize("precision,groups,view", [("fp32", 2, False), ("bf16", 2, False), ("bf16", None, False),
+                                                   ("mixed16", 1, False), ("bf16", None, True), ("fp32", 2, True)])
+def test_eight_ranks_one_table_each_match_the_unsharded_operator(precision, groups, view, gpu_device):
     """8 processes (sharing this GPU), n_hashes = 8, one table per rank, rows exchanged with the one-sided transport
     (buffers mapped across processes through HIP IPC) -- against the plain operator on all 8 tables.  One table per
     rank takes the DIRECT path: the block attention stores its rows straight into the owners' receive buffers and
-    raises the flags itself (no table sum, no separate push); groups = None is the transport's own choice (1 launch)."""
+    raises the flags itself (no table sum, no separate push); groups = None is the transport's own choice (1 launch).
+    view: TableSharding(out_view=True) -- the output is read in the exchange buffer (two regions taken in turn)."""
     world = 8
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_synthetic_worker, args=(world, port, precision, "p2p", ret, groups), nprocs=world, join=True)
+    mp.spawn(_synthetic_worker, args=(world, port, precision, "p2p", ret, groups, view), nprocs=world, join=True)
     assert all(torch.equal(ret[0][0], ret[r][0]) for r in range(1, world))
     assert "one-sided" in ret[0][1] and (groups is not None or "in auto head" in ret[0][1])
     from hept_amd import ops

@@ -20,5 +20,5 @@ grep -v amdgpu.ids $O/model_and_prepare.txt > profiles/${P}_model_and_prepare.tx
 grep -v amdgpu.ids $O/host_overhead.txt > profiles/${P}_host_overhead.txt
 {
   for how in plain p2p rccl; do echo "== 3 tables, $how"; grep -v amdgpu.ids $O/timeline_$how.txt; done
-  for how in plain p2p rccl; do echo "== 1 table (BASELINE config 4 on one rank), $how"; grep -v amdgpu.ids $O/timeline_T1_$how.txt; done
+  for how in plain p2p p2pview rccl; do echo "== 1 table (BASELINE config 4 on one rank), $how"; grep -v amdgpu.ids $O/timeline_T1_$how.txt; done
 } > profiles/${P}_timelines.txt

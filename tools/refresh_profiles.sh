@@ -57,7 +57,7 @@ for how in plain p2p rccl; do
 done
 # BASELINE config 4 on one rank: one table, the direct-scatter exchange (one head group)
 export HEPT_TRACE_TABLES=1
-for how in plain p2p rccl; do
+for how in plain p2p p2pview rccl; do
   rocprofv3 --kernel-trace --output-format csv -d $O/tr1_$how -- python3 $R/tools/trace_step.py $how 1 30 > $O/tr1_$how.log 2>&1
   python3 $R/tools/trace_summary.py $O/tr1_$how > $O/timeline_T1_$how.txt 2>&1
 done

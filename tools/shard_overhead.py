@@ -25,16 +25,18 @@ w_rpe = torch.nn.Linear(50, 192).to(dev)
 with torch.no_grad():
     w_rpe.weight.copy_(g["w_rpe_weight"])
 kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
-for mode in (None, "all_to_all/1/p2p", "all_to_all/2/p2p", "all_to_all/4/p2p", "all_to_all/8/p2p", "all_to_all/1/rccl", "all_to_all/2/rccl",
+# ".../p2p+view": TableSharding(out_view=True) -- no copy of the gathered output out of the exchange buffer
+for mode in (None, "all_to_all/1/p2p", "all_to_all/1/p2p+view", "all_to_all/2/p2p", "all_to_all/4/p2p", "all_to_all/8/p2p", "all_to_all/1/rccl", "all_to_all/2/rccl",
              "all_to_all/2/torch", "reduce_scatter", "all_reduce"):
     mode, _, rest = (mode or "").partition("/")
     groups, _, via = rest.partition("/")
+    via, _, view = via.partition("+")
     mode = mode or None
     m = HEPTAttention(24 + C, h_dim=24, num_heads=8, block_size=128, n_hashes=tables, num_w_per_dist=10, precision=prec,
                       process_group=dist.group.WORLD if mode else None)
     if mode:
         m.sharding = TableSharding(tables, dist.group.WORLD, mode=mode, always_exchange=True,
-                                   head_groups=int(groups) if groups else None)
+                                   head_groups=int(groups) if groups else None, out_view=bool(view))
         if via:
             m.sharding.exchange = via
     m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"],

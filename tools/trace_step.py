@@ -1,5 +1,5 @@
 """A few forwards of one configuration, for `rocprofv3 --kernel-trace` timelines (tools/trace_summary.py reads the CSV).
-python tools/trace_step.py [plain|p2p|rccl|torch] [groups] [steps]"""
+python tools/trace_step.py [plain|p2p|p2pview|rccl|torch] [groups] [steps]   (p2pview: TableSharding(out_view=True))"""
 import os
 import sys
 
@@ -33,7 +33,8 @@ T = inp["alpha"].shape[2]
 m = HEPTAttention(inp["alpha"].shape[1], h_dim=24, num_heads=8, block_size=WORKLOADS[wl]["block_size"], n_hashes=T,
                   num_w_per_dist=10, precision=prec, process_group=group)
 if group is not None:
-    m.sharding = TableSharding(T, group, mode="all_to_all", always_exchange=True, head_groups=groups)
+    m.sharding = TableSharding(T, group, mode="all_to_all", always_exchange=True, head_groups=groups,
+                               out_view=how == "p2pview")
     if how in ("torch", "rccl"):
         m.sharding.exchange = how
 m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"], "e2lsh.alpha": inp["alpha"]})
