@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void wait_out_kernel(char* local, int world, u
         store16_system(local + out_off + i * 16, nan4);
 }
 
+#ifndef HEPT_COPY_OUT_WGS
+#define HEPT_COPY_OUT_WGS 256
+#endif
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int CMB_WAIT_MAX = 256;  // threads of the combine that poll one arrival flag each
 
@@ -415,7 +418,12 @@ int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int N, int D, const P2pLayou
         if (hi > valid / 16) hi = valid / 16;
         if (lo > hi) lo = hi;
     }
-    hipLaunchKernelGGL(wait_copy_out_kernel, dim3((unsigned)(blocks < 1024 ? (blocks ? blocks : 1) : 1024)), dim3(256), 0,
+    // One workgroup per CU: every workgroup polls the same flag words, and reads of one uncached address are served
+    // one after the other (1024 workgroups: ~6 us of polling before the first byte moved); 256 x 256 threads x 4 pieces
+    // in flight are 4 MB of outstanding reads, more than the copy needs.
+    static const size_t max_wgs = [] { const char* e = getenv("HEPT_COPY_OUT_WGS"); return e && atoi(e) > 0 ? (size_t)atoi(e) : (size_t)HEPT_COPY_OUT_WGS; }();
+    const unsigned grid = (unsigned)(blocks < max_wgs ? (blocks ? blocks : 1) : max_wgs);
+    hipLaunchKernelGGL(wait_copy_out_kernel, dim3(grid), dim3(256), 0,
                        st, c->p2p_local, c->world, c->epoch, lay.out_off, bytes, valid, dst, c->d_state + HEPT_STATE_STATUS,
                        c->timeout_ticks, lo, hi, c->d_peer, c->rank);
     return hept_launch_status();

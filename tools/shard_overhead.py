@@ -26,8 +26,11 @@ with torch.no_grad():
     w_rpe.weight.copy_(g["w_rpe_weight"])
 kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
 # ".../p2p+view": TableSharding(out_view=True) -- no copy of the gathered output out of the exchange buffer
-for mode in (None, "all_to_all/1/p2p", "all_to_all/1/p2p+view", "all_to_all/2/p2p", "all_to_all/4/p2p", "all_to_all/8/p2p", "all_to_all/1/rccl", "all_to_all/2/rccl",
-             "all_to_all/2/torch", "reduce_scatter", "all_reduce"):
+MODES = (None, "all_to_all/1/p2p", "all_to_all/1/p2p+view", "all_to_all/2/p2p", "all_to_all/4/p2p", "all_to_all/8/p2p", "all_to_all/1/rccl", "all_to_all/2/rccl",
+         "all_to_all/2/torch", "reduce_scatter", "all_reduce")
+if os.environ.get("HEPT_SHARD_MODES"):   # a subset, comma separated ("plain" = no sharding)
+    MODES = tuple(None if m == "plain" else m for m in os.environ["HEPT_SHARD_MODES"].split(","))
+for mode in MODES:
     mode, _, rest = (mode or "").partition("/")
     groups, _, via = rest.partition("/")
     via, _, view = via.partition("+")
