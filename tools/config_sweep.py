@@ -11,7 +11,8 @@ from hept_amd import HEPTAttention  # noqa: E402
 from hept_amd.synthetic import WORKLOADS, workload_inputs  # noqa: E402
 
 dev = torch.device("cuda", 0)
-for name in WORKLOADS:
+ONLY = [w for w in os.environ.get("HEPT_SWEEP_ONLY", "").split(",") if w]   # a subset of the workloads
+for name in (ONLY or WORKLOADS):
     inp = workload_inputs(name, seed=0)
     g = {k: v.to(dev) for k, v in inp.items() if torch.is_tensor(v)}
     h, e, t = inp["alpha"].shape
