@@ -231,11 +231,13 @@ size_t hept_exchange_bytes(int N, int H, int D, int world, int precision);
  * (hept_comm_p2p_alloc), the HEPT_IPC_HANDLE_BYTES-byte HIP IPC handles reach every rank by any host-side means,
  * and every rank maps the others' buffers (hept_comm_p2p_open, handles in rank order).  With transport
  * HEPT_TRANSPORT_ONE_SIDED hept_forward_sharded then stores each table-summed row straight into the buffer of the
- * rank that finishes its point, raises an epoch flag there when a head group is complete, polls its own flags before
- * the combine, stores its finished output slice into every rank's buffer and copies the gathered output to out_full
- * once every slice has arrived (xbuf is not used).  Calls are collective: every rank makes the same sequence.
+ * rank that finishes its point; the kernel that follows on the stream (the combine) raises the epoch flags that
+ * announce them -- a kernel boundary says that every store of the kernels before it has been acknowledged -- and polls
+ * its own flags before it reads; it stores its finished output slice into every rank's buffer, and the gather kernel
+ * raises the output flag and copies the gathered output to out_full once every slice has arrived (xbuf is not used).
+ * Calls are collective: every rank makes the same sequence.
  * One local table per rank (Tl == 1, BASELINE config 4): the block attention itself stores every finished row into
- * the owner's buffer (16-byte pieces of 64-byte rows) and raises the flags -- no table sum, no separate push.
+ * the owner's buffer (16-byte pieces of 64-byte rows) -- no table sum, no separate push.
  * A wait is bounded (20 s, HEPT_P2P_TIMEOUT_S; sticky).  After a timeout the step's output is written as NaN on the
  * rank that timed out and the slice it sends to the others is NaN as well -- a lost or slow peer never turns into
  * plausible numbers -- and every later hept_forward_sharded on that communicator returns HEPT_ERR_COMM at once (the
