@@ -369,12 +369,31 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
 #pragma unroll
             for (int j = 0; j < 8; ++j) pre[it][j] = 0.f;
             if (ci < CK * 8 && key < (FULL ? KEYS : B)) {
-                const float* src = kvbase + (size_t)kp[key] * 64 + c * 8;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
-                pre[it][0] = a0[0]; pre[it][1] = a0[1]; pre[it][2] = a0[2]; pre[it][3] = a0[3];
-                pre[it][4] = a1[0]; pre[it][5] = a1[1]; pre[it][6] = a1[2]; pre[it][7] = a1[3];
-                if (c == 3) pre[it][6] = 1.f;  // k^ columns (30, 31) = (1, -|k|^2/2)
+                const int ks = kp[key];
+                if (c >= 4 && hr.vsrc) {
+                    // value columns 8 (c - 4) .. + 7 of [v (D) | 1.0 | 0 ..] straight from the caller's v (D % 4 == 0:
+                    // whole 16-B pieces); padding rows of the src variant (>= raw_size) are zero but for the 1.0
+                    const int col = 8 * (c - 4);
+                    const float* src = hr.vsrc + ((size_t)ks * H + h) * D + col;
+                    const bool real = ks < hr.raw_size;
+                    if (real && col < D) {
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+                        pre[it][0] = a0[0]; pre[it][1] = a0[1]; pre[it][2] = a0[2]; pre[it][3] = a0[3];
+                    }
+                    if (real && col + 4 < D) {
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
+                        pre[it][4] = a1[0]; pre[it][5] = a1[1]; pre[it][6] = a1[2]; pre[it][7] = a1[3];
+                    }
+                    if (col == D) pre[it][0] = 1.f;
+                    if (col + 4 == D) pre[it][4] = 1.f;
+                } else {
+                    const float* src = kvbase + (size_t)ks * 64 + c * 8;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
+                    pre[it][0] = a0[0]; pre[it][1] = a0[1]; pre[it][2] = a0[2]; pre[it][3] = a0[3];
+                    pre[it][4] = a1[0]; pre[it][5] = a1[1]; pre[it][6] = a1[2]; pre[it][7] = a1[3];
+                    if (c == 3) pre[it][6] = 1.f;  // k^ columns (30, 31) = (1, -|k|^2/2)
+                }
             }
         }
     };
@@ -608,8 +627,16 @@ int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char
 
 namespace {
 int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N, int H, int D,
-                    int Tl, int B, int precision, const HeadRange& hr, float* part, void* stream,
-                    const PushArgs* push = nullptr) {
+                    int Tl, int B, int precision, const HeadRange& hr_in, float* part, void* stream,
+                    const PushArgs* push = nullptr, VSrc vs = VSrc{}) {
+    HeadRange hr = hr_in;
+    hr.vsrc = nullptr;
+    hr.raw_size = N;
+    if (vs.v) {   // only the f32-row split kernel reads v in place (D % 4 == 0: 16-B pieces of the caller's rows)
+        if (precision != HEPT_PREC_F32 || D % 4 != 0 || (reinterpret_cast<uintptr_t>(vs.v) & 15)) return HEPT_ERR_ARG;
+        hr.vsrc = vs.v;
+        hr.raw_size = vs.raw_size;
+    }
     if (!qhat || !kvhat || !qpos || !kpos || (!part && !(push && push->direct))) return HEPT_ERR_ARG;
     if (N < 1 || H < 1 || Tl < 1 || B < 1 || B > HEPT_MAX_BLOCK || N % B != 0 || D < 1 || D > 28)
         return HEPT_ERR_SHAPE;
@@ -654,15 +681,15 @@ int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, co
 // internal: hept_block_attn_heads whose launch also carries the one-sided push of another head group (comm.h)
 int hept_block_attn_heads_push(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
                                int H, int D, int Tl, int B, int precision, int h0, int hg, int hout, int hsub,
-                               int n_rows_out, float* part, const PushArgs* push, void* stream) {
+                               int n_rows_out, float* part, const PushArgs* push, void* stream, VSrc vs) {
     if (n_rows_out < N) return HEPT_ERR_SHAPE;
-    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout};
-    return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, hr, part, stream, push);
+    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout, nullptr, 0};
+    return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, hr, part, stream, push, vs);
 }
 
 extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
                                int H, int D, int Tl, int B, int precision, float* part, void* stream) {
-    const HeadRange all{0, H, H, 0, (long long)N * H};
+    const HeadRange all{0, H, H, 0, (long long)N * H, nullptr, 0};
     return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, all, part, stream);
 }
 
@@ -670,6 +697,6 @@ extern "C" int hept_block_attn_heads(const void* qhat, const void* kvhat, const 
                                      int N, int H, int D, int Tl, int B, int precision, int h0, int hg, int hout,
                                      int hsub, int n_rows_out, float* part, void* stream) {
     if (n_rows_out < N) return HEPT_ERR_SHAPE;
-    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout};
+    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout, nullptr, 0};
     return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, hr, part, stream);
 }

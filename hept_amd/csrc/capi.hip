@@ -97,11 +97,17 @@ inline bool row_riders_off() {
     return off;
 }
 
+// Value rows read from the caller's v (run_begin: `dv`) pay where the block attention is bound by issue, not by its
+// gathers: blocks above 128 points (pileup batch, f32 rows: 413.9 -> 405.7 us per forward; at B = 128 the second gather
+// stream costs the kernel what the riders cost the sort, 294 vs 294-298 us, and short clouds lose 1-3 us --
+// profiles/r05_experiments.txt)
+static inline bool direct_v_pays(int B) { return B > 128; }
+
 // everything before the block attention, for tables [t0, t0 + Tl): parameter math, augmented rows + hashes, sort.
 // Leaves qhat / kvhat and the permutations (w.pos: q then k, (Tl, H, N) each) in the workspace.
 int run_begin(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
               const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T,
-              int t0, int Tl, int precision, const Workspace& w, void* stream) {
+              int t0, int Tl, int precision, const Workspace& w, void* stream, VSrc* dv = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     prof_mark(0, st);
     // K > 0: `w_rpe` is w_rpe.weight and the row builder computes sqrt_w (H, C) from it in its prologue, every call
@@ -121,7 +127,15 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
     const bool f32_rows = precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA;
     // (HEPT_FORCE_ROW_RIDERS=1: riders at any table count -- A/B measurements; read once)
     static const bool force_ride = [] { const char* e = getenv("HEPT_FORCE_ROW_RIDERS"); return e && *e && *e != '0'; }();
-    const bool ride = Tl <= HEPT_MAX_TABLES && (Tl >= 2 || f32_rows || force_ride) && hept_sort_carries_rows(N, H, D) && !row_riders_off();
+    // f32 rows, round 5: nobody builds the v half at all when the caller of run_begin runs the block attention itself
+    // (`dv`): the split-bf16 kernel stages its value planes from the caller's v rows (96 of 128 fetched bytes used, the
+    // same sectors as a padded kvhat row) and the bucket sort loses its riders -- 46 MB read + 61.5 MB written per call
+    // at tracking-60k (HEPT_NO_DIRECT_V=1: A/B measurements; read once)
+    static const bool no_direct_v = [] { const char* e = getenv("HEPT_NO_DIRECT_V"); return e && *e && *e != '0'; }();
+    const bool direct_v = dv && precision == HEPT_PREC_F32 && D % 4 == 0 && !no_direct_v &&
+                          (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+    if (dv) *dv = direct_v ? VSrc{v, raw_size} : VSrc{};
+    const bool ride = !direct_v && Tl <= HEPT_MAX_TABLES && (Tl >= 2 || f32_rows || force_ride) && hept_sort_carries_rows(N, H, D) && !row_riders_off();
     const HeptRowsJob job{v, w.kvhat, N, raw_size, H, D, precision};
     const HeptRowsJob* rows = ride ? &job : nullptr;
     for (int c0 = 0; c0 < Tl; c0 += HEPT_MAX_TABLES) {   // chunks of tables (the rows are rewritten identically)
@@ -131,8 +145,8 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
         size_t zbytes = 0;
         hept_sort_zero_block(w.sort_ws, N, H, tc, &zptr, &zbytes);
         rc = hept_prep_hash_rpe(q, k, v, coords, w_rpe, K, alpha, codes, N, raw_size, H, D, C, T,
-                                t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream, ride ? 2 : 3,
-                                zptr, zbytes);
+                                t0 + c0, tc, precision, w.qhat, w.kvhat, w.qproj, w.kproj, w.minmax, stream,
+                                (ride || direct_v) ? 2 : 3, zptr, zbytes);
         if (rc) return rc;
         if (c0 == 0) prof_mark(1, st);
         // the sort writes one (2, tc, H, N) array: straight into w.pos when the call is a single chunk
@@ -158,9 +172,12 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
 int run_tables(const float* q, const float* k, const float* v, const float* coords, const int64_t* codes,
                const GeoShift& geo, const float* w_rpe, const float* alpha, int N, int H, int D, int C, int K, int T,
                int t0, int Tl, int B, int precision, const Workspace& w, float* part, void* stream) {
-    int rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
+    VSrc dv;
+    int rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream,
+                       direct_v_pays(B) ? &dv : nullptr);
     if (rc) return rc;
-    rc = hept_block_attn(w.qhat, w.kvhat, w.pos, w.pos + (size_t)Tl * H * N, N, H, D, Tl, B, precision, part, stream);
+    rc = hept_block_attn_heads_push(w.qhat, w.kvhat, w.pos, w.pos + (size_t)Tl * H * N, N, H, D, Tl, B, precision, 0, H, H,
+                                    0, N, part, nullptr, stream, dv);
     prof_mark(3, (hipStream_t)stream);
     return rc;
 }
@@ -394,7 +411,9 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
     const bool mirror = one_sided && D == 24 && cnt >= 1;
     char* send = reinterpret_cast<char*>(xbuf);
     char* recv = one_sided ? comm->p2p_local + lay.recv_off : send + up256((size_t)n_pad * H * row);
-    int rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream);
+    VSrc dv;
+    int rc = run_begin(q, k, v, coords, codes, geo, w_rpe, alpha, N, H, D, C, K, T, t0, Tl, precision, w, stream,
+                       direct_v_pays(B) ? &dv : nullptr);
     if (rc) return rc;
     const int pprec = hept_part_precision(precision, D);
     const bool direct = Tl == 1 && !one_sided;   // one local table: block_attn scatters straight into the send buffer
@@ -413,7 +432,7 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
             if (rc) return rc;
             if (rec) prof_mark(2, st);
             rc = hept_block_attn_heads_push(w.qhat, w.kvhat, qpos, kpos, N, H, D, 1, B, precision, g * hg, hg, hg, g * hg,
-                                            n_pad, nullptr, &pa, stream);
+                                            n_pad, nullptr, &pa, stream, dv);
             if (rec) {
                 prof_mark(3, st);
                 prof_call_done();
@@ -439,7 +458,7 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
             }
             if (rec) prof_mark(2, st);
             rc = hept_block_attn_heads_push(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, g * hg, hg, H, 0, N,
-                                            w.part, carry ? &pa : nullptr, stream);
+                                            w.part, carry ? &pa : nullptr, stream, dv);
             if (rec) {
                 prof_mark(3, st);
                 prof_call_done();
@@ -465,11 +484,11 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
             if (n_pad > N && hipMemsetAsync(reinterpret_cast<char*>(dst) + (size_t)N * row_bytes, 0,
                                             (size_t)(n_pad - N) * row_bytes, st) != hipSuccess)
                 return HEPT_ERR_LAUNCH;
-            rc = hept_block_attn_heads(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, g * hg, hg, hg, g * hg,
-                                       n_pad, dst, stream);
+            rc = hept_block_attn_heads_push(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, g * hg, hg, hg, g * hg,
+                                            n_pad, dst, nullptr, stream, dv);
         } else {
-            rc = hept_block_attn_heads(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, g * hg, hg, H, 0, N,
-                                       w.part, stream);
+            rc = hept_block_attn_heads_push(w.qhat, w.kvhat, qpos, kpos, N, H, D, Tl, B, precision, g * hg, hg, H, 0, N,
+                                            w.part, nullptr, stream, dv);
         }
         if (rec) {
             prof_mark(3, st);

@@ -65,7 +65,8 @@ int hept_p2p_direct_args(hept_comm* c, int N, int H, int D, int h0, int hg, int 
                          const P2pLayout& lay, bool mirror, PushArgs* out);
 int hept_block_attn_heads_push(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
                                int H, int D, int Tl, int B, int precision, int h0, int hg, int hout, int hsub,
-                               int n_rows_out, float* part, const PushArgs* push, void* stream);   // block_attn.hip
+                               int n_rows_out, float* part, const PushArgs* push, void* stream,
+                               VSrc vs = VSrc{});   // block_attn.hip (vs: value rows read from the caller's v, f32 rows only)
 int hept_p2p_wait_rows(hept_comm* c, int head_groups, hipStream_t st);
 // this rank's finished (cnt, D) rows (already in its slice of the local output region) -> every other rank, then flags
 int hept_p2p_push_out(hept_comm* c, int per, int D, const P2pLayout& lay, hipStream_t st);

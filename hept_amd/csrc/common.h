@@ -19,6 +19,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct HeadRange {
     int h0, hg, hout, hsub;
     long long tstride_rows;
+    // f32 rows (HEPT_PREC_F32), round 5: the value rows are read where the caller left them -- v (N, H * D) f32, the
+    // 1.0 of column D supplied by the kernel, rows >= raw_size zero -- instead of from the v half of the kvhat rows,
+    // which then nobody builds (null: the kvhat rows carry v, as in every other mode)
+    const float* vsrc;
+    int raw_size;
+};
+struct VSrc {
+    const float* v = nullptr;
+    int raw_size = 0;
 };
 
 static inline int hept_launch_status() {

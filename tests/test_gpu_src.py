@@ -238,3 +238,34 @@ def test_src_full_size_all_rows_vs_oracle(precision, gpu_device):
         assert _rows_ok(out[:raw], want[:raw], 1e-5) >= 0.995
     else:
         assert _rows_ok(out[:raw], want[:raw], atol=5e-3, rtol=8e-3) >= 0.995
+
+
+@pytest.mark.parametrize("raw", [3000, 2900])
+def test_src_block_256_fp32_value_rows_read_in_place(raw, gpu_device):
+    """f32 rows with blocks above 128 points (round 5): the block attention stages its value planes from the caller's
+    v instead of from kvhat rows nobody builds any more -- here on the src variant, whose padding rows (>= raw_size)
+    must count as v = 0 with the denominator's 1.0, against the oracle on every real row and, bit for bit, against
+    the same call composed from the public stages (which build and read the kvhat rows)."""
+    from hept_amd.synthetic import make_inputs_src
+
+    inp = make_inputs_src(raw, block_size=256, n_hashes=2, seed=9)
+    inp["block_size"], inp["w_per_dist"] = 256, 10
+    g = _gpu(inp, gpu_device)
+    assert g["q"].shape[0] % 256 == 0 and g["q"].shape[0] > raw
+    out = ops.forward_src(g["q"], g["k"], g["v"], g["coords"], (g["eta_idx"], g["phi_idx"]), g["regions_h"], raw,
+                          g["w_rpe_weight"], g["alpha"], g["out_weight"], g["out_bias"], block_size=256, w_per_dist=10,
+                          precision="fp32")
+    want = _oracle(inp, keep=False)["out"]
+    assert bool(torch.isfinite(out).all())
+    assert _rows_ok(out[:raw].cpu(), want[:raw], 1e-5) >= 0.995
+    # the composed path: partial rows of each table through the public stages (kvhat rows with their v half), summed
+    acc = ops.forward_partial_src(g["q"], g["k"], g["v"], g["coords"], (g["eta_idx"], g["phi_idx"]), g["regions_h"], raw,
+                                  g["w_rpe_weight"], g["alpha"], t0=0, tl=2, block_size=256, w_per_dist=10,
+                                  precision="fp32")
+    n, h = g["q"].shape[0], 8
+    sq = ops.rpe_scale(g["w_rpe_weight"], h, 24, 10)
+    eta, phi, cfac = ops.geo_args((g["eta_idx"], g["phi_idx"]), g["regions_h"], 2, h, n)
+    ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sq, g["alpha"], None, "fp32", raw_size=raw)
+    qp, kp = ops.sort_tables_src(ph["qproj"], ph["kproj"], eta, phi, cfac, ph["minmax"])
+    part = ops.block_attn(ph["qhat"], ph["kvhat"], qp, kp, 24, 256)
+    assert torch.equal(ops.reduce_tables(part, 24), acc)
