@@ -284,6 +284,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
         }
     }
     // (direct mode: this rank's row flags are raised by the next kernel of the stream, p2p_dev.h raise_flags)
+    if (pa.direct) drain_remote_stores();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
             }
         }
     }
+    if (pa.direct) drain_remote_stores();   // see block_attn_kernel
 }
 
 template <bool FULL, int VP>

@@ -485,6 +485,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         if constexpr (SPLIT) __syncthreads();
     }
     // (PUSH: this rank's output flag is raised by the gather kernel that follows, p2p.hip)
+    if constexpr (PUSH) drain_remote_stores();
 }
 
 // 16 consecutive columns [16*hh, 16*hh+16) of one partial row, widened to fp32 (reduce_tables)

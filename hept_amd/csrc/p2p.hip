@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void push_out_kernel(char* const* peers, int w
         for (int s = 0; s < world; ++s)
             if (s != me) store16_system(peers[s] + slice_off + i * 16, v);
     }
+    drain_remote_stores();
 }
 
 // `bytes` = the whole (n_pad, D) output, `valid_bytes` = its first N rows: the padding rows are written as zeros (the

@@ -107,6 +107,11 @@ __device__ __forceinline__ bool wait_flag(const unsigned int* flag, unsigned int
 // the stores are idempotent, so any number of workgroups may do it (the callers use the first few of the grid: a
 // workgroup that waits for this rank's own flag must never depend on a later workgroup getting a slot).
 constexpr int RAISE_WGS = 16;
+// Last statement of a kernel that stored into other ranks' buffers: the wave does not end before its stores have been
+// acknowledged.  (The hardware waits for a wave's outstanding memory operations before it retires the wave anyway --
+// S_ENDPGM implies S_WAITCNT 0 -- and the queue's end-of-kernel release waits for the dispatch's writes; this line
+// makes the protocol's one assumption explicit in the code instead of leaving it to those two.)
+__device__ __forceinline__ void drain_remote_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void raise_flags(char* const* peers, int world, int n_flags, int base, int pitch,
                                             unsigned int epoch) {
     const int i = threadIdx.x;
@@ -198,6 +203,7 @@ __device__ __forceinline__ void reduce_push_body(const PushArgs& a, int wg_index
         else store16_system(row + pc * 16, v);
     }
     // (no signal: the flags of every head group are raised by the kernel that waits for the rows, see raise_flags)
+    drain_remote_stores();
 }
 
 }  // namespace
