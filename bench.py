@@ -658,6 +658,12 @@ def worker(args) -> int:
                         # region is at the mercy of one scheduling hiccup of a shared host: median of three regions
                         # (three regions for the long clouds as well: one hiccup -- an allocator call of the module built
                         #  before, a scheduling pause of the host -- doubled a 40 ms region in one run of round 5)
+                        # ... and the device idled while build() made this record's inputs on the host: a short cloud's three
+                        # regions (7 ms each) can all fall inside its clock ramp (one refresh of round 5 read 98 us per
+                        # forward for example-4k that way, 35 us in the runs before and after) -- keep it busy for 30 ms first
+                        t_busy = time.perf_counter()
+                        while time.perf_counter() - t_busy < 0.03:
+                            step_s()
                         runs = sorted((measure(step_s, sub_steps, sub_warm) for _ in range(3)), key=lambda r: r[0])
                         el, ams, nrec = runs[len(runs) // 2]
                         roof_s = roofline(ns, cs, ts, prec, ams, nrec, bsz)
