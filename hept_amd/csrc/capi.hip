@@ -513,10 +513,13 @@ int sharded_steps(hept_comm* comm, const float* q, const float* k, const float* 
     if (rec_all && !one_sided) prof_mark(4, st);   // the exposed transfer: last group's table sum + all-to-all (+ join)
     if (mirror) {
         // wait for the rows + combine + push of the output slice + output flag in one kernel, then gather
-        rc = hept_p2p_combine_push(comm, head_groups, per, cnt, H, hg, aprec, out_weight, out_bias, lay, out_full, st);
+        // (view mode: the gathered output in the exchange buffer must be whole, so this rank's own slice goes there
+        //  too -- and from there into out_full, if the caller passed one all the same)
+        rc = hept_p2p_combine_push(comm, head_groups, per, cnt, H, hg, aprec, out_weight, out_bias, lay,
+                                   view ? nullptr : out_full, st);
         if (rc) return rc;
         if (rec_all) prof_mark(5, st);   // wait for the rows + combine + output slice to every rank
-        rc = out_full ? hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, true, st) : hept_p2p_wait_out(comm, N, D, lay, st);
+        rc = out_full ? hept_p2p_wait_copy_out(comm, n_pad, N, D, lay, out_full, !view, st) : hept_p2p_wait_out(comm, N, D, lay, st);
         if (!rc && view) comm->last_out = reinterpret_cast<const float*>(comm->p2p_local + lay.out_off);
         if (rec_all) {
             prof_mark(6, st);            // wait for every rank's slice + copy out

@@ -165,6 +165,23 @@ def test_sharded_forward_returns_a_view_of_the_gathered_output(tables, precision
         b3 = view(g["q"], 3 * g["k"], g["v"], **kwargs)          # the first region again
         assert b3.data_ptr() == b.data_ptr() and not torch.equal(b, kept)
         assert torch.equal(b2, a2)
+        # a caller that passes an output buffer all the same (the C ABI allows it in view mode): the copy AND the view
+        # of that step are whole (this rank's own slice included)
+        import ctypes
+
+        from hept_amd import _lib, ops
+
+        sh = view.sharding
+        n, h, d = g["q"].shape[0], 8, 24
+        ws = torch.empty(ops.workspace_bytes(n, h, d, 6, tables, 128, precision), dtype=torch.uint8, device=gpu_device)
+        full = ops.forward_sharded(g["q"], g["k"], g["v"], g["coords"], shifts, g["w_rpe_weight"], alpha.to(gpu_device),
+                                   g["out_weight"], g["out_bias"], comm=sh.native_comm(gpu_device), world=1, block_size=128,
+                                   w_per_dist=10, t0=0, tl=tables, head_groups=sh.groups_for(8), precision=precision,
+                                   workspace=ws, one_sided=True, out_view=False)
+        ptr = ctypes.c_void_p()
+        _lib.check(_lib.load().hept_comm_out_view(sh.native_comm(gpu_device), ctypes.byref(ptr)), "hept_comm_out_view")
+        seen = torch.as_tensor(ops._DeviceRows(ptr.value, n, d), device=gpu_device)
+        assert torch.equal(full, a) and torch.equal(seen, a)
     for m in mods:
         m.sharding.check()
         assert "one-sided" in m.sharding.describe()
