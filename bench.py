@@ -424,6 +424,10 @@ def worker(args) -> int:
         exists, and is "hbm" with ``traffic`` null otherwise."""
         tile_bytes = 4 if precision == "fp32" else 2
         nbytes = algorithmic_bytes(n, H, D, c, tables, tile_bytes)
+        # the event pair's own cost sits inside what it brackets: half of a lone pair's reading is taken off, as for the
+        # `kernels` list (whole_step) -- with it the duration agrees with the rocprofv3 kernel trace of profiles/ within
+        # 1-2 % (raw: 2-5 % above it); the raw reading stays in the record
+        attn_raw_ms, attn_ms = attn_ms, max(attn_ms - event_pair_ms() / 2, 1e-6)
         ach = nbytes / (attn_ms * 1e-3) / 1e9
         ent, source = pmc_record(precision, block_size)
         bound, evidence = ("hbm", None) if ent is None else bound_from_counters(ent, attn_ms)
@@ -431,7 +435,7 @@ def worker(args) -> int:
         return {"bound": bound, "bound_evidence": evidence, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "frac_of_copy": ach / HBM_COPY_GBS, "copy_peak": HBM_COPY_GBS,
                 "kernel": "block_attn_kernel" if precision != "fp32" else "block_attn_split_kernel",
-                "kernel_ms": attn_ms, "event_samples": n_rec, "algorithmic_bytes": nbytes,
+                "kernel_ms": attn_ms, "kernel_ms_raw": attn_raw_ms, "event_samples": n_rec, "algorithmic_bytes": nbytes,
                 "traffic": ent["traffic"] if ent else None, "traffic_source": source,
                 "mfma_busy_frac": ent.get("mfma_busy_frac") if ent else None,
                 "algorithmic_tflops": flops / (attn_ms * 1e-3) / 1e12, "mfma_bf16_peak_tflops": MFMA_BF16_PEAK_TF}
