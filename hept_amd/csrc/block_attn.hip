@@ -33,6 +33,32 @@
 
 namespace {
 
+// Cache policy of the partial-row stores (A/B switch)
+#ifndef HEPT_ATTN_STORE
+#define HEPT_ATTN_STORE 1
+#endif
+__device__ __forceinline__ void store16_rows(unsigned int* dst, const u32x4& v) {
+#if HEPT_ATTN_STORE == 1
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+#elif HEPT_ATTN_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+#elif HEPT_ATTN_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+#elif HEPT_ATTN_STORE == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+#elif HEPT_ATTN_STORE == 5
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(dst), "v"(v) : "memory");
+#else
+    *reinterpret_cast<u32x4*>(dst) = v;
+#endif
+}
+__device__ __forceinline__ void store4_rows(float* dst, float v) {
+#ifdef HEPT_ATTN_STORE32_NT
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
+#endif
+}
 
 // Register budget: a workgroup lives ~10 us, most of it waiting for its gathered rows, so throughput is set by how
 // many workgroups a CU holds.  16-bit tiles: 8 waves per SIMD (<= 64 VGPRs, no spills; 87 -> 80 us at tracking-60k);
@@ -82,7 +108,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
     const int bid = (int)blockIdx.x - pa.push_wgs;
     const int h = hr.h0 + bid % hr.hg;
     const int rest = bid / hr.hg;
-    const int b = rest % nb, t = rest / nb;
+    const int b = hr.tl > 0 ? rest / hr.tl : rest % nb, t = hr.tl > 0 ? rest % hr.tl : rest / nb;
     const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
     const int* __restrict__ kp = kpos + seg;
     const int* __restrict__ qp = qpos + seg;
@@ -92,14 +118,22 @@ void block_attn_kernel(const char* __restrict__ qhat,
     // ---- this wave's 32 query rows: HBM -> registers (B-operand layout), norm from the row tail
     const int qi = w * 32 + li;
     const bool qvalid = FULL || qi < B;
+#ifdef HEPT_ATTN_NT_IDX
+    const int qsrc = __builtin_nontemporal_load(qp + (qvalid ? qi : 0));
+#else
     const int qsrc = qp[qvalid ? qi : 0];
+#endif
     if (hh == 0) qidx_s[qi] = qvalid ? qsrc : -1;
     const char* qrow = qbase + (size_t)qsrc * QROW;
     const float qn = *reinterpret_cast<const float*>(qrow + QROW - 4);
     u32x4 qraw[BF16 ? 2 : 4];
 #pragma unroll
     for (int s = 0; s < (BF16 ? 2 : 4); ++s)
+#ifdef HEPT_ATTN_NT_Q
+        qraw[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qrow + (BF16 ? (s * 32 + hh * 16) : (hh * 64 + s * 16))));
+#else
         qraw[s] = *reinterpret_cast<const u32x4*>(qrow + (BF16 ? (s * 32 + hh * 16) : (hh * 64 + s * 16)));
+#endif
     if (hh == 1) qraw[BF16 ? 1 : 3][3] = 0u;  // the norm slot is not a feature
 
     // ---- stage K^ and V tiles: gathered rows, 16 B per lane, K^ XOR-swizzled against bank conflicts
@@ -109,8 +143,16 @@ void block_attn_kernel(const char* __restrict__ qhat,
         const int key = ci / CPR, c = ci % CPR;
         u32x4 val = {0u, 0u, 0u, 0u};
         if (FULL || key < B) {  // FULL: B == 32 * NKT, no ragged tile -> no masking code at all
+#ifdef HEPT_ATTN_NT_IDX
+            const int src = __builtin_nontemporal_load(kp + key);
+#else
             const int src = kp[key];
+#endif
+#ifdef HEPT_ATTN_NT_KV
+            val = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kvbase + (size_t)src * KVROW + c * 16));
+#else
             val = *reinterpret_cast<const u32x4*>(kvbase + (size_t)src * KVROW + c * 16);
+#endif
         }
         if (c < CH) {
             if (c == CH - 1) {
@@ -240,7 +282,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
                     if (remote) store16_system(rowp, v);
                     else *reinterpret_cast<u32x4*>(rowp) = v;
                 } else {
-                    *reinterpret_cast<u32x4*>(pt + (size_t)dst * hr.hout * 16 + pc * 4) = v;
+                    store16_rows(pt + (size_t)dst * hr.hout * 16 + pc * 4, v);
                 }
             }
         }
@@ -278,7 +320,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
                     if (remote) store4_system(rowp, __float_as_uint(val));
                     else *reinterpret_cast<float*>(rowp) = val;
                 } else {
-                    pt[(size_t)dst * hr.hout * 32] = val;
+                    store4_rows(pt + (size_t)dst * hr.hout * 32, val);
                 }
             }
         }
@@ -352,7 +394,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     const int bid = (int)blockIdx.x - pa.push_wgs;
     const int h = hr.h0 + bid % hr.hg;
     const int rest = bid / hr.hg;
-    const int b = rest % nb, t = rest / nb;
+    const int b = hr.tl > 0 ? rest / hr.tl : rest % nb, t = hr.tl > 0 ? rest % hr.tl : rest / nb;
     const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
     const int* __restrict__ kp = kpos + seg;
     const int* __restrict__ qp = qpos + seg;
@@ -548,7 +590,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
                 if (remote) store4_system(rowp, __float_as_uint(val));
                 else *reinterpret_cast<float*>(rowp) = val;
             } else {
-                pt[(size_t)dst * hr.hout * 32] = val;
+                store4_rows(pt + (size_t)dst * hr.hout * 32, val);
             }
         }
     }
@@ -634,6 +676,8 @@ int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, co
     HeadRange hr = hr_in;
     hr.vsrc = nullptr;
     hr.raw_size = N;
+    static const bool table_major = [] { const char* e = getenv("HEPT_ATTN_TABLE_MAJOR"); return e && *e && *e != '0'; }();
+    hr.tl = table_major ? 0 : Tl;
     if (vs.v) {   // only the f32-row split kernel reads v in place (D % 4 == 0: 16-B pieces of the caller's rows)
         if (precision != HEPT_PREC_F32 || D % 4 != 0 || (reinterpret_cast<uintptr_t>(vs.v) & 15)) return HEPT_ERR_ARG;
         hr.vsrc = vs.v;
@@ -685,13 +729,13 @@ int hept_block_attn_heads_push(const void* qhat, const void* kvhat, const int32_
                                int H, int D, int Tl, int B, int precision, int h0, int hg, int hout, int hsub,
                                int n_rows_out, float* part, const PushArgs* push, void* stream, VSrc vs) {
     if (n_rows_out < N) return HEPT_ERR_SHAPE;
-    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout, nullptr, 0};
+    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout, nullptr, 0, 0};
     return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, hr, part, stream, push, vs);
 }
 
 extern "C" int hept_block_attn(const void* qhat, const void* kvhat, const int32_t* qpos, const int32_t* kpos, int N,
                                int H, int D, int Tl, int B, int precision, float* part, void* stream) {
-    const HeadRange all{0, H, H, 0, (long long)N * H, nullptr, 0};
+    const HeadRange all{0, H, H, 0, (long long)N * H, nullptr, 0, 0};
     return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, all, part, stream);
 }
 
@@ -699,6 +743,6 @@ extern "C" int hept_block_attn_heads(const void* qhat, const void* kvhat, const 
                                      int N, int H, int D, int Tl, int B, int precision, int h0, int hg, int hout,
                                      int hsub, int n_rows_out, float* part, void* stream) {
     if (n_rows_out < N) return HEPT_ERR_SHAPE;
-    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout, nullptr, 0};
+    const HeadRange hr{h0, hg, hout, hsub, (long long)n_rows_out * hout, nullptr, 0, 0};
     return block_attn_impl(qhat, kvhat, qpos, kpos, N, H, D, Tl, B, precision, hr, part, stream);
 }

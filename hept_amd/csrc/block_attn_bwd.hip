@@ -53,7 +53,13 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_bwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int bid = blockIdx.x;
+    // the tables of a block run side by side (t fastest), as in the forward: the gathers of a point's rows meet in the L2
+#ifdef HEPT_BWD_TABLE_MAJOR
     const int h = bid % H, rest = bid / H, b = rest % nb, t = rest / nb;
+#else
+    const int tl_ = (int)gridDim.x / (H * nb);
+    const int h = bid % H, rest = bid / H, b = rest / tl_, t = rest % tl_;
+#endif
     const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
     const int* __restrict__ qp = qpos + seg;
     const int* __restrict__ kp = kpos + seg;
@@ -299,7 +305,13 @@ void block_attn_bwd_split_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int bid = blockIdx.x;
+    // the tables of a block run side by side (t fastest), as in the forward: the gathers of a point's rows meet in the L2
+#ifdef HEPT_BWD_TABLE_MAJOR
     const int h = bid % H, rest = bid / H, b = rest % nb, t = rest / nb;
+#else
+    const int tl_ = (int)gridDim.x / (H * nb);
+    const int h = bid % H, rest = bid / H, b = rest / tl_, t = rest % tl_;
+#endif
     const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
     const int* __restrict__ qp = qpos + seg;
     const int* __restrict__ kp = kpos + seg;
@@ -412,7 +424,7 @@ void block_attn_bwd_split_kernel(
             const int src = __shfl(qsrc, hept_acc_row(r, hh));
             const float rs = __shfl(z[r], 30 + 32 * hh);
             const float qv = plane_elem3(b_s, PL, el, r);
-            if (FULL || q2 < B) dst[(size_t)src * H * 32] = li < 30 ? z[r] - rs * qv : 0.f;
+            if (FULL || q2 < B) hept_st<HEPT_NT_BWD_ROWS>(dst + (size_t)src * H * 32, li < 30 ? z[r] - rs * qv : 0.f);
         }
     }
 #pragma unroll
@@ -481,8 +493,8 @@ void block_attn_bwd_split_kernel(
             const float kv = plane_elem3(a_s, PL, el, r);
             if (FULL || k2 < B) {
                 float* row = dst + (size_t)src * H * 64;
-                row[0] = li < 30 ? zk[r] - rs * kv : 0.f;
-                row[32] = li < D ? zv[r] : 0.f;
+                hept_st<HEPT_NT_BWD_ROWS>(row, li < 30 ? zk[r] - rs * kv : 0.f);
+                hept_st<HEPT_NT_BWD_ROWS>(row + 32, li < D ? zv[r] : 0.f);
             }
         }
     }
@@ -528,7 +540,13 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_bwd_bf16_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int bid = blockIdx.x;
+    // the tables of a block run side by side (t fastest), as in the forward: the gathers of a point's rows meet in the L2
+#ifdef HEPT_BWD_TABLE_MAJOR
     const int h = bid % H, rest = bid / H, b = rest % nb, t = rest / nb;
+#else
+    const int tl_ = (int)gridDim.x / (H * nb);
+    const int h = bid % H, rest = bid / H, b = rest / tl_, t = rest % tl_;
+#endif
     const size_t seg = ((size_t)t * H + h) * N + (size_t)b * B;
     const int* __restrict__ qp = qpos + seg;
     const int* __restrict__ kp = kpos + seg;

@@ -16,6 +16,9 @@
 
 namespace {
 
+#ifndef HEPT_CMB_STG_AUX
+#define HEPT_CMB_STG_AUX 2   // cache policy bits of the direct-to-LDS row loads (2 = nt: the partial rows are read once)
+#endif
 constexpr int CMB_THREADS = 256;
 constexpr int CMB_WAVES = CMB_THREADS / HEPT_WAVE;
 constexpr int WT_PITCH = 33;  // LDS pitch of one (head, d) weight row: odd, so the transposing writes of the staging
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                             ((size_t)n * HG + (u.hp - grp * HG)) * 128 + sub * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(stg + slot_buf * STG32_UNIT_BYTES + j * 1024),
-                                             16, 0, 0);
+                                             16, 0, HEPT_CMB_STG_AUX);
         }
     };
     int ring = 0;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
                                     ((size_t)n * HG + (hp - grp * HG)) * 64 + sub * 16;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(stg + t * STG_TABLE_BYTES + j * 1024),
-                                                     16, 0, 0);
+                                                     16, 0, HEPT_CMB_STG_AUX);
                 }
             }
     };
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i2 = tile * 32 + hept_acc_row(r, hh);
-                if (i2 < n_count && li < D) out[(size_t)i2 * D + li] = acc[r] + bia;
+                if (i2 < n_count && li < D) hept_st<HEPT_NT_OUT>(out + (size_t)i2 * D + li, acc[r] + bia);
             }
         }
         if constexpr (SPLIT) __syncthreads();

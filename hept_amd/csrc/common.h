@@ -24,6 +24,9 @@ struct HeadRange {
     // which then nobody builds (null: the kvhat rows carry v, as in every other mode)
     const float* vsrc;
     int raw_size;
+    // workgroup -> (table, block) map of a block_attn launch (blockIdx % hg is always the head): tl > 0: the tables of a
+    // block run side by side (t fastest), so that the three gathers of a point's rows meet in the XCD's L2; 0: table-major
+    int tl;
 };
 struct VSrc {
     const float* v = nullptr;
@@ -135,6 +138,47 @@ __device__ __forceinline__ void exp_clamped(const f32x16& x, float (&pr)[16]) {
         pr[2 * j] = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(t[0]), 0.f), 1.f);
         pr[2 * j + 1] = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(t[1]), 0.f), 1.f);
     }
+}
+
+// ---- cache policy of the once-read / once-written streams (round 6) ------------------------------------------------------
+// The forward's intermediates (q^ / k^|v rows, hashes, pairs, positions: ~140 MB with 16-bit rows) fit the 256 MB Infinity
+// Cache, and the block attention gathers them at the cache's rate instead of HBM's -- as long as the streams that are
+// touched exactly once (the caller's q, k, v: 138 MB; the sort's pairs on their way out; the partial rows) do not push
+// them out.  Those streams are loaded / stored non-temporal (`nt`): tracking-60k bf16 block attention 82 -> 57 us with no
+// other change (profiles/r06_experiments.txt).  Each switch is a build flag for A/B: -DHEPT_NT_<stream>=0.
+#ifndef HEPT_NT_PREP_IN
+#define HEPT_NT_PREP_IN 1     // row builder: q, k (and v) input tiles
+#endif
+#ifndef HEPT_NT_KA_IN
+#define HEPT_NT_KA_IN 1       // chunk sort: the hashes
+#endif
+#ifndef HEPT_NT_KB_IN
+#define HEPT_NT_KB_IN 1       // bucket sort: the bucket's pairs
+#endif
+#ifndef HEPT_NT_RIDER_IN32
+#define HEPT_NT_RIDER_IN32 1  // v rows converted by the riders of the bucket-sort launch, f32 rows (block attention -6 us)
+#endif
+#ifndef HEPT_NT_RIDER_IN16
+#define HEPT_NT_RIDER_IN16 0  // ... 16-bit rows: the riders' 16-B pieces of a line meet in L1, which nt loads bypass (sort +3 us)
+#endif
+#ifndef HEPT_NT_CODES
+#define HEPT_NT_CODES 0       // chunk sort: the int64 AND codes (read twice: q and k segments)
+#endif
+#ifndef HEPT_NT_OUT
+#define HEPT_NT_OUT 0         // combine: the (N, D) output rows
+#endif
+#ifndef HEPT_NT_BWD_ROWS
+#define HEPT_NT_BWD_ROWS 0    // backward (f32 tiles): the per-table gradient rows (553 MB, read once by bwd_reduce)
+#endif
+template <bool NT, typename T>
+__device__ __forceinline__ T hept_ld(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void hept_st(T* p, const T& v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
 }
 
 // ---- wave-wide scan / reductions on DPP (one VALU instruction per step; __shfl_up / __shfl_xor compile to ds_bpermute

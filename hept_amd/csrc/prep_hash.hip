@@ -258,7 +258,7 @@ __device__ __forceinline__ void prep_role(const float* __restrict__ x, const flo
             f32x4 xin[LOADS];
 #pragma unroll
             for (int j = 0; j < LOADS; ++j)
-                xin[j] = (j * 64 + lane < valid_chunks) ? src[j * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+                xin[j] = (j * 64 + lane < valid_chunks) ? hept_ld<HEPT_NT_PREP_IN>(src + j * 64 + lane) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < LOADS; ++j) buf[wslot[j]] = xin[j];
 #pragma unroll

@@ -174,13 +174,13 @@ __global__ __launch_bounds__(SCT) void chunk_sort_kernel(
     for (int i = 0; i < SCT_ITEMS / 4; ++i) {
         const int n = base + (i * SCT + tid) * 4;
         if (vec_ok && n + 3 < len) {
-            const f32x4 p4 = *reinterpret_cast<const f32x4*>(proj + n);
+            const f32x4 p4 = hept_ld<HEPT_NT_KA_IN>(reinterpret_cast<const f32x4*>(proj + n));
 #pragma unroll
             for (int e = 0; e < 4; ++e) pj[4 * i + e] = p4[e];
             if constexpr (MODE == 0) {
                 typedef __attribute__((ext_vector_type(2))) long long i64x2;
-                const i64x2 c01 = *reinterpret_cast<const i64x2*>(codes + row_off + n);
-                const i64x2 c23 = *reinterpret_cast<const i64x2*>(codes + row_off + n + 2);
+                const i64x2 c01 = hept_ld<HEPT_NT_CODES>(reinterpret_cast<const i64x2*>(codes + row_off + n));
+                const i64x2 c23 = hept_ld<HEPT_NT_CODES>(reinterpret_cast<const i64x2*>(codes + row_off + n + 2));
                 cd[4 * i] = c01[0]; cd[4 * i + 1] = c01[1]; cd[4 * i + 2] = c23[0]; cd[4 * i + 3] = c23[1];
             }
             if constexpr (MODE == 1) {
@@ -463,7 +463,7 @@ __device__ __forceinline__ void rows_rider(const RowsJob& jb, unsigned int wg, u
                     n[u] = n0 + ((i / PPR) & 7u);
                     hd[u] = i / (8 * PPR);
                     const bool data = hd[u] < H && n[u] < (unsigned int)jb.raw_size && 4 * k[u] < D;
-                    x[u] = data ? *reinterpret_cast<const f32x4*>(jb.v + (size_t)n[u] * HD + hd[u] * D + 4 * k[u])
+                    x[u] = data ? hept_ld<HEPT_NT_RIDER_IN32>(reinterpret_cast<const f32x4*>(jb.v + (size_t)n[u] * HD + hd[u] * D + 4 * k[u]))
                                 : f32x4{4 * k[u] == D ? 1.f : 0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
@@ -487,8 +487,8 @@ __device__ __forceinline__ void rows_rider(const RowsJob& jb, unsigned int wg, u
                     hd[u] = i / (8 * PPR);
                     const bool row = hd[u] < H && n[u] < (unsigned int)jb.raw_size;
                     const float* src = jb.v + (size_t)n[u] * HD + hd[u] * D + 8 * k[u];
-                    x[u][0] = (row && 8 * k[u] < D) ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    x[u][1] = (row && 8 * k[u] + 4 < D) ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    x[u][0] = (row && 8 * k[u] < D) ? hept_ld<HEPT_NT_RIDER_IN16>(reinterpret_cast<const f32x4*>(src)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    x[u][1] = (row && 8 * k[u] + 4 < D) ? hept_ld<HEPT_NT_RIDER_IN16>(reinterpret_cast<const f32x4*>(src + 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     // the 1.0 of column D (D % 4 == 0: the first element of one of the two quads)
                     if (8 * k[u] == D) x[u][0][0] = 1.f;
                     if (8 * k[u] + 4 == D) x[u][1][0] = 1.f;
@@ -619,7 +619,7 @@ __device__ __forceinline__ void bucket_body(const unsigned long long* __restrict
         const unsigned int* cseg = rga.cnt + (size_t)seg * NTOP;
         const unsigned long long* reg = rga.region + ((size_t)seg * NTOP + bucket) * rga.pitch;
 #pragma unroll
-        for (int u = 0; u < SPEC; ++u) spec[u] = reg[u * BKT_THREADS + tid];
+        for (int u = 0; u < SPEC; ++u) spec[u] = hept_ld<HEPT_NT_KB_IN>(reg + u * BKT_THREADS + tid);
         unsigned int in_front = 0;
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {

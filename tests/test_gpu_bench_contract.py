@@ -27,6 +27,15 @@ def _run(*args, **env_extra):
     return json.loads(lines[0])
 
 
+def _check_traffic(roof):
+    """round 6: a PMC record is copied only for ITS (workload, template) -- pmc_record compares WRITE_SIZE with the launch's
+    partial rows -- so the counters' traffic must sit near the launch's algorithmic bytes: at least the rows written plus
+    every gathered row once (the three tables' gathers of a row can meet in L2: >= 0.45), at most 1.5x (round 5 shipped a
+    6k cloud carrying the 60k cloud's 751 MB: 11.9x)."""
+    ratio = roof["traffic"] / roof["algorithmic_bytes"]
+    assert 0.45 <= ratio <= 1.5, ratio
+
+
 def _check_whole_step(rec, n_launches):
     """round 5: every launch of the step with its algorithmic bytes, and the step's bytes over the timed step time"""
     ks = rec["kernels"]
@@ -69,6 +78,7 @@ def test_bench_line(precision, dtype, gpu_device):
                 else:
                     ev = roof["bound_evidence"]
                     assert (roof["bound"] == "hbm") == (ev["hbm_frac_of_copy_on_traffic"] >= ev["issue_frac"])
+                    _check_traffic(roof)
         # the batched call runs ten 6k clouds at the per-point rate of one 60k cloud, not of one 6k cloud
         assert d["c2x10"]["bf16"]["value"] > 2.0 * d["c2"]["bf16"]["value"]
     assert d["config"]["rccl_ranks"] == 0
@@ -87,7 +97,19 @@ def test_bench_line(precision, dtype, gpu_device):
         assert "refused" in src
     else:
         assert "refused" not in src and src["kernel_launched"] in src["kernel_measured"].replace(" ", "")
-        assert r["traffic"] > 0.9 * r["algorithmic_bytes"] * 0.5
+        assert src["workload_key"] == f"c3/{precision}"
+        _check_traffic(r)
+    assert 0.0 < r["frac"] <= r["frac_adjusted"] < 1.0 and "HIP events" in r["timing_method"]
+    # the driver keeps the last 8 KB of stdout: the reference-precision record, the per-launch list and the summary close
+    # the line, the long per-configuration records open it
+    keys = list(d)
+    assert keys[-1] == "summary" and d["summary"]["ms_per_step"] == d["ms_per_step"]
+    assert keys.index("step_roofline") > keys.index("metric")
+    if precision == "bf16":
+        assert keys.index("fp32") > keys.index("c5") and keys.index("fp32") > keys.index("metric")
+        assert d["summary"]["fp32_ms_per_step"] == d["fp32"]["ms_per_step"]
+        tail = json.dumps(d)[-8192:]
+        assert '"fp32": {"ms_per_step"' in tail and '"step_roofline"' in tail and '"kernels"' in tail
     assert 1e7 < d["value"] < 1e10 and abs(d["value"] - 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 
