@@ -177,7 +177,11 @@ void block_attn_kernel(const char* __restrict__ qhat,
         const int key = kt * 32 + li;
         f32x16 x;
 #pragma unroll
+#ifdef HEPT_ABL_NOINIT
+        for (int r = 0; r < 16; ++r) x[r] = qn;
+#else
         for (int r = 0; r < 16; ++r) x[r] = qn + kn_s[kt * 32 + hept_acc_row(r, hh)];
+#endif
 
         if constexpr (BF16) {
 #pragma unroll
@@ -208,7 +212,12 @@ void block_attn_kernel(const char* __restrict__ qhat,
         // exp(min(x, 0)) written as min(exp(x), 1): identical value for every x (exp is monotone, exp(0) = 1),
         // and v_min on the v_exp result needs no NaN-canonicalising v_max in front of it
         float pr[16];
+#ifdef HEPT_ABL_NOEXP
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = x[r];
+#else
         exp_clamped(x, pr);
+#endif
         if (!FULL && (kt + 1) * 32 > B) {  // ragged last tile (B not a multiple of 32): padded keys carry no weight
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -252,6 +261,43 @@ void block_attn_kernel(const char* __restrict__ qhat,
         //      sixteen 4-byte ones, and the form the xGMI links want when the row belongs to another rank (direct mode).
 #ifndef HEPT_ATTN_DWORD_SCATTER
         __syncthreads();   // every wave is done reading k_s / v_s
+#if !defined(HEPT_ATTN_EPI_DPP)
+        // round 6: the wave's 32 x 32 accumulator tile goes to LDS as it stands (f32, one ds_write_b32 per register at an
+        // immediate offset: no address arithmetic), and the lane that stores piece pc of row `row` reads its eight values
+        // back (two ds_read_b128) and packs them there -- 8 conversions per lane instead of, per register, a DPP move, a
+        // conversion, two selects and a swizzled address (16 x 6 vector instructions; the kernel issues a vector
+        // instruction in 57 % of its cycles).  Same values, same rounding: word i = pack(column 2i, column 2i + 1).
+        float* tile = reinterpret_cast<float*>(smem) + w * 32 * 32;   // this wave's 4 KiB of the dead K^ / V tiles
+        {
+            float* wr = tile + (4 * hh) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * 32] = z[r];
+        }
+        unsigned int* __restrict__ pt =
+            reinterpret_cast<unsigned int*>(part) + (size_t)t * hr.tstride_rows * 16 + (size_t)(h - hr.hsub) * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (lane >> 2) + 16 * j, pc = lane & 3;
+            const int q2 = w * 32 + row;
+            const f32x4 f0 = *reinterpret_cast<const f32x4*>(tile + row * 32 + pc * 8);
+            const f32x4 f1 = *reinterpret_cast<const f32x4*>(tile + row * 32 + pc * 8 + 4);
+            u32x4 v = {hept_pack_bf16(f0[0], f0[1]), hept_pack_bf16(f0[2], f0[3]), hept_pack_bf16(f1[0], f1[1]),
+                       hept_pack_bf16(f1[2], f1[3])};
+            // P16 rows exist for D == 24 only: piece 3 = [denominator + 1e-20 (example/hept.py:14) as f32 | 0 | 0 | 0]
+            if (pc == 3) v = u32x4{__float_as_uint(f0[0] + 1e-20f), 0u, 0u, 0u};
+            if (FULL || q2 < B) {
+                const int dst = qidx_s[q2];
+                if (pa.direct) {
+                    bool remote;
+                    char* rowp = direct_row(pa, dst, h - hr.h0, 64, remote) + pc * 16;
+                    if (remote) store16_system(rowp, v);
+                    else *reinterpret_cast<u32x4*>(rowp) = v;
+                } else {
+                    store16_rows(pt + (size_t)dst * hr.hout * 16 + pc * 4, v);
+                }
+            }
+        }
+#else
         unsigned int* tile = reinterpret_cast<unsigned int*>(smem) + w * 32 * 16;   // this wave's 2 KiB of the K^ tile
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -286,6 +332,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
                 }
             }
         }
+#endif   // HEPT_ATTN_EPI_DPP
 #else
         unsigned int* __restrict__ pt =
             reinterpret_cast<unsigned int*>(part) + (size_t)t * hr.tstride_rows * 16 + (size_t)(h - hr.hsub) * 16 + (li >> 1);
@@ -575,7 +622,40 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
         }   // tile groups of the chunk
     }
 
-    // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
+    // ---- scatter: row = 32 floats = one 128-B line per query.  Round 6: the wave's 32 x 32 accumulator tile passes through
+    //      LDS (the planes are dead: f32, one ds_write_b32 per register at an immediate offset), and a lane stores a 16-B
+    //      piece, eight lanes a whole row: four store instructions per wave with four address computations instead of
+    //      sixteen 4-byte ones with a shuffle and a 64-bit multiply each (~110 vector instructions of the wave's ~870).
+#ifndef HEPT_SPLIT_EPI_DWORD
+    __syncthreads();   // every wave is done with the last chunk's planes
+    float* tile = reinterpret_cast<float*>(smem) + w * 32 * 32;
+    {
+        float* wr = tile + (4 * hh) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * 32] = z[r];
+    }
+    float* __restrict__ pt = part + (size_t)t * hr.tstride_rows * 32 + (size_t)(h - hr.hsub) * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (lane >> 3) + 8 * j, pc = lane & 7;
+        const int q2 = w * 32 + row;
+        const int dst = __shfl(qsrc, row);   // lane li holds the source row of query 32 w + li
+        f32x4 f = *reinterpret_cast<const f32x4*>(tile + row * 32 + pc * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (pc * 4 + e == D) f[e] += 1e-20f;  // example/hept.py:14
+        if (FULL || q2 < B) {
+            if (pa.direct) {   // see block_attn_kernel
+                bool remote;
+                char* rowp = direct_row(pa, dst, h - hr.h0, 128, remote) + pc * 16;
+                if (remote) store16_system(rowp, __builtin_bit_cast(u32x4, f));
+                else *reinterpret_cast<f32x4*>(rowp) = f;
+            } else {
+                *reinterpret_cast<f32x4*>(pt + (size_t)dst * hr.hout * 32 + pc * 4) = f;
+            }
+        }
+    }
+#else
     float* __restrict__ pt = part + (size_t)t * hr.tstride_rows * 32 + (size_t)(h - hr.hsub) * 32 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -594,6 +674,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
             }
         }
     }
+#endif
     if (pa.direct) drain_remote_stores();   // see block_attn_kernel
 }
 
@@ -602,7 +683,8 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
                       const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
 #define HEPT_SPLIT_CASE(K)                                                                                       \
     case K: {                                                                                                    \
-        constexpr size_t lds = (size_t)(3 + VP) * split_ck(K) * 64;                                              \
+        /* the planes, or the epilogue's 4 KiB per wave where that is more (B = 224: 7 waves) */                  \
+        constexpr size_t lds = (size_t)(3 + VP) * split_ck(K) * 64 > (size_t)K * 4096 ? (size_t)(3 + VP) * split_ck(K) * 64 : (size_t)K * 4096; \
         if (lds > 65536) {                                                                                       \
             static LdsRaised raised;                                                                             \
             if (hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_split_kernel<K, FULL, VP>), lds))   \
