@@ -13,7 +13,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhept_hip.so")
 
 ABI_VERSION = 20
-PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA = 0, 1, 2, 3
+PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA, PREC_F32_DIFF = 0, 1, 2, 3, 4
 ROW = 32
 MAX_TABLES = 8
 MAX_BLOCK = 256

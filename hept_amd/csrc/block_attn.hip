@@ -71,11 +71,19 @@ __device__ __forceinline__ void store4_rows(float* dst, float v) {
 #endif
 // (B = 96 with f32 partial rows -- D != 24, an off-the-shipped-shapes instance -- spilled 4 registers at the 64-VGPR cap as
 //  well, and at 72: 6 waves = 80 VGPRs)
-constexpr int attn_waves(int nkt, bool bf16, bool p16, bool full) {
+constexpr int attn_waves(int nkt, bool bf16, bool p16, bool full, bool diff = false) {
+    if (diff) return full ? 3 : 2;   // the difference form keeps 16 more accumulators: 157 / 180 VGPRs, no scratch (an accuracy mode)
     return bf16 ? ((nkt == 3 && !p16 && full) ? 6 : (full ? 8 : HEPT_RAGGED16_WAVES)) : (full ? 6 : 4);
 }
-template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL>
-__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(attn_waves(NKT, BF16, P16, FULL), attn_waves(NKT, BF16, P16, FULL))))
+// DIFF (HEPT_PREC_F32_DIFF, f32 rows on the native f32 MFMA): the logit -|q^ - k^|^2 / 2 with the COORDINATE part as explicit
+// differences.  The reference (example/hept.py:8-12) forms q^.k^ - |q^|^2/2 - |k^|^2/2; with the shipped checkpoint's
+// sqrt_w (up to 5.8e3) on raw coordinates those three terms are ~3e8 each and their fp32 sum is rounding noise (sigma ~ 20
+// in the logit, in the reference's own evaluation as well: DESIGN.md section 4, case G7).  Here only the D feature columns
+// go through the matrix product (q.k - |q|^2/2 - |k|^2/2 over d < D: O(10) terms), and every column from D on (the C
+// coordinate columns sqrt_w . coords and the zero padding up to column 29) contributes -(q^_c - k^_c)^2 / 2 from the
+// difference of the two stored values: no cancellation.  Mathematically the same logit; numerically the accurate one.
+template <int NKT, bool BF16, bool P16, bool F16QK, bool FULL, bool DIFF = false>
+__global__ __launch_bounds__(64 * NKT) __attribute__((amdgpu_waves_per_eu(attn_waves(NKT, BF16, P16, FULL, DIFF), attn_waves(NKT, BF16, P16, FULL, DIFF))))
 void block_attn_kernel(const char* __restrict__ qhat,
                                                               const char* __restrict__ kvhat,
                                                               const int* __restrict__ qpos,
@@ -125,7 +133,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
 #endif
     if (hh == 0) qidx_s[qi] = qvalid ? qsrc : -1;
     const char* qrow = qbase + (size_t)qsrc * QROW;
-    const float qn = *reinterpret_cast<const float*>(qrow + QROW - 4);
+    float qn = *reinterpret_cast<const float*>(qrow + QROW - 4);
     u32x4 qraw[BF16 ? 2 : 4];
 #pragma unroll
     for (int s = 0; s < (BF16 ? 2 : 4); ++s)
@@ -135,6 +143,22 @@ void block_attn_kernel(const char* __restrict__ qhat,
         qraw[s] = *reinterpret_cast<const u32x4*>(qrow + (BF16 ? (s * 32 + hh * 16) : (hh * 64 + s * 16)));
 #endif
     if (hh == 1) qraw[BF16 ? 1 : 3][3] = 0u;  // the norm slot is not a feature
+    if constexpr (DIFF) {
+        static_assert(!BF16, "the difference form runs on f32 rows");
+        // this lane holds columns 16 hh + 4 s + j: feature norm over the columns below D, everything from D on leaves
+        // the matrix product
+        float part = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool feat = 16 * hh + 4 * s2 + j < D;
+                const float qv = __uint_as_float(qraw[s2][j]);
+                part = feat ? fmaf(qv, qv, part) : part;
+                if (!feat) qraw[s2][j] = 0u;
+            }
+        qn = -0.5f * (part + __shfl_xor(part, 32));
+    }
 
     // ---- stage K^ and V tiles: gathered rows, 16 B per lane, K^ XOR-swizzled against bank conflicts
 #pragma unroll
@@ -166,6 +190,19 @@ void block_attn_kernel(const char* __restrict__ qhat,
         }
     }
     __syncthreads();
+    if constexpr (DIFF) {
+        // -|k|^2 / 2 over the feature columns of every staged key (the stored norm covers the coordinate columns too)
+        if (tid < KEYS) {
+            const int sw = (tid >> 1) & 7;
+            float acc = 0.f;
+            for (int col = 0; col < D; ++col) {
+                const float kv2 = *reinterpret_cast<const float*>(k_s + tid * QROW + (((col >> 2) ^ sw) * 16) + (col & 3) * 4);
+                acc = fmaf(kv2, kv2, acc);
+            }
+            kn_s[tid] = -0.5f * acc;
+        }
+        __syncthreads();
+    }
 
     f32x16 z;
 #pragma unroll
@@ -207,6 +244,26 @@ void block_attn_kernel(const char* __restrict__ qhat,
 #pragma unroll
             for (int s = 0; s < 16; ++s)
                 x = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], __uint_as_float(qraw[s >> 2][s & 3]), x, 0, 0, 0);
+            if constexpr (DIFF) {
+                // columns D .. 29: -(q^_c - k^_c)^2 / 2 from the stored values (the query's from its row -- an L1 hit --,
+                // the keys' from the staged tile: the lanes of a half read one key, a broadcast)
+                float dsq[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsq[r] = 0.f;
+                for (int col = D; col < 30; ++col) {
+                    const float qc = *reinterpret_cast<const float*>(qrow + col * 4);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kr = kt * 32 + hept_acc_row(r, hh);
+                        const float kc = *reinterpret_cast<const float*>(
+                            k_s + kr * QROW + (((col >> 2) ^ ((kr >> 1) & 7)) * 16) + (col & 3) * 4);
+                        const float dlt = qc - kc;
+                        dsq[r] = fmaf(dlt, dlt, dsq[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = fmaf(-0.5f, dsq[r], x[r]);
+            }
         }
 
         // exp(min(x, 0)) written as min(exp(x), 1): identical value for every x (exp is monotone, exp(0) = 1),
@@ -412,7 +469,10 @@ void block_attn_kernel(const char* __restrict__ qhat,
 #ifndef HEPT_SPLIT_CK8
 #define HEPT_SPLIT_CK8 128
 #endif
-constexpr int split_ck(int nkt) { return nkt == 8 ? HEPT_SPLIT_CK8 : (nkt >= 2 ? 64 : 32); }
+#ifndef HEPT_SPLIT_CK4
+#define HEPT_SPLIT_CK4 64
+#endif
+constexpr int split_ck(int nkt) { return nkt == 8 ? HEPT_SPLIT_CK8 : (nkt == 4 ? HEPT_SPLIT_CK4 : (nkt >= 2 ? 64 : 32)); }
 #ifndef HEPT_SPLIT_PP
 #define HEPT_SPLIT_PP 2
 #endif
@@ -710,7 +770,7 @@ int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, con
     return hept_launch_status();
 }
 
-template <bool BF16, bool P16, bool F16QK, bool FULL>
+template <bool BF16, bool P16, bool F16QK, bool FULL, bool DIFF = false>
 int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
                 const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
 #define HEPT_ATTN_CASE(K)                                                                                    \
@@ -718,10 +778,10 @@ int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const
         constexpr size_t lds = (size_t)2 * 32 * K * 32 * (BF16 ? 2 : 4) + 32 * K * 8;                        \
         if (lds > 65536) {                                                                                   \
             static LdsRaised raised;                                                                         \
-            if (hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16, F16QK, FULL>), lds)) \
+            if (hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_kernel<K, BF16, P16, F16QK, FULL, DIFF>), lds)) \
                 return HEPT_ERR_LAUNCH;                                                                      \
         }                                                                                                    \
-        hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16, F16QK, FULL>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,     \
+        hipLaunchKernelGGL((block_attn_kernel<K, BF16, P16, F16QK, FULL, DIFF>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos, \
                            kpos, part, N, H, D, B, nb, hr, pa);                                                    \
         break;                                                                                               \
     }
@@ -741,12 +801,12 @@ int launch_attn_full(int nkt, dim3 grid, hipStream_t st, const char* qhat, const
     return hept_launch_status();
 }
 
-template <bool BF16, bool P16, bool F16QK>
+template <bool BF16, bool P16, bool F16QK, bool DIFF = false>
 int launch_attn(int nkt, dim3 grid, hipStream_t st, const char* qhat, const char* kvhat, const int* qpos,
                 const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
     if (B == 32 * nkt)
-        return launch_attn_full<BF16, P16, F16QK, true>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr, pa);
-    return launch_attn_full<BF16, P16, F16QK, false>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr, pa);
+        return launch_attn_full<BF16, P16, F16QK, true, DIFF>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr, pa);
+    return launch_attn_full<BF16, P16, F16QK, false, DIFF>(nkt, grid, st, qhat, kvhat, qpos, kpos, part, N, H, D, B, nb, hr, pa);
 }
 
 }  // namespace
@@ -802,6 +862,8 @@ int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, co
     }
     if (precision == HEPT_PREC_F32_MFMA)
         return launch_attn<false, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
+    if (precision == HEPT_PREC_F32_DIFF)
+        return launch_attn<false, false, false, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
     return HEPT_ERR_SHAPE;
 }
 }  // namespace

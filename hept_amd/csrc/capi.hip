@@ -26,7 +26,7 @@ struct Workspace {
 inline int chunk_tables(int Tl) { return Tl < HEPT_MAX_TABLES ? Tl : HEPT_MAX_TABLES; }
 
 Workspace carve(void* base, int N, int H, int C, int Tl, int precision) {
-    const size_t esz = (precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA) ? 4 : 2;
+    const size_t esz = (precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA || precision == HEPT_PREC_F32_DIFF) ? 4 : 2;
     const int Tc = chunk_tables(Tl);
     char* p = reinterpret_cast<char*>(base);
     size_t off = 0;
@@ -124,7 +124,7 @@ int run_begin(const float* q, const float* k, const float* v, const float* coord
     // 16-bit rows the bucket sort is ~12 us of its own work against ~20 us of riders -- the row builder keeps its v
     // role there (tracking-60k, T = 1: 111.0 -> 104.7 us per forward; two tables and more, and f32 rows at any count,
     // are faster with riders: profiles/r04_experiments.txt)
-    const bool f32_rows = precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA;
+    const bool f32_rows = precision == HEPT_PREC_F32 || precision == HEPT_PREC_F32_MFMA || precision == HEPT_PREC_F32_DIFF;
     // (HEPT_FORCE_ROW_RIDERS=1: riders at any table count -- A/B measurements; read once)
     static const bool force_ride = [] { const char* e = getenv("HEPT_FORCE_ROW_RIDERS"); return e && *e && *e != '0'; }();
     // f32 rows, round 5: nobody builds the v half at all when the caller of run_begin runs the block attention itself
@@ -192,7 +192,7 @@ void hept_prof_mark_sort_mid(void* stream) {
 extern "C" int hept_abi_version(void) { return 20; }
 
 extern "C" int hept_part_precision(int precision, int D) {
-    return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
+    return (precision != HEPT_PREC_F32 && precision != HEPT_PREC_F32_MFMA && precision != HEPT_PREC_F32_DIFF && D == 24) ? HEPT_PREC_BF16 : HEPT_PREC_F32;
 }
 
 extern "C" int hept_check_shape(int N, int H, int D, int C, int Tl, int B) {

@@ -794,7 +794,7 @@ int hept_prep_hash_rpe(const float* q, const float* k, const float* v, const flo
         return HEPT_ERR_ARG;
     if (H < 1 || H > 16 || D < 1 || D > 28 || C < 1 || D + C > 30) return HEPT_ERR_SHAPE;
     if (N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
-    if (precision == HEPT_PREC_F32_MFMA) precision = HEPT_PREC_F32;  // same f32 tile rows, another block_attn kernel
+    if (precision == HEPT_PREC_F32_MFMA || precision == HEPT_PREC_F32_DIFF) precision = HEPT_PREC_F32;  // same f32 tile rows, another block_attn kernel
     if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16 && precision != HEPT_PREC_MIXED16)
         return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -835,7 +835,7 @@ int hept_prep_hash_fused_rpe(const float* x, const float* norm_w, const float* n
         !qproj || !kproj || !minmax)
         return HEPT_ERR_ARG;
     if (H != 8 || D != 24 || N < 1 || Tl < 1 || Tl > HEPT_MAX_TABLES || t0 < 0 || t0 + Tl > T) return HEPT_ERR_SHAPE;
-    if (precision == HEPT_PREC_F32_MFMA) precision = HEPT_PREC_F32;  // same f32 tile rows, another block_attn kernel
+    if (precision == HEPT_PREC_F32_MFMA || precision == HEPT_PREC_F32_DIFF) precision = HEPT_PREC_F32;  // same f32 tile rows, another block_attn kernel
     if (precision != HEPT_PREC_F32 && precision != HEPT_PREC_BF16 && precision != HEPT_PREC_MIXED16)
         return HEPT_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;

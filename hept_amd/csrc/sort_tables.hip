@@ -1397,7 +1397,7 @@ RowsJob rows_job(const HeptRowsJob* r) {
     jb.raw_size = r->raw_size;
     jb.H = r->H;
     jb.D4 = r->D / 4;
-    jb.f32 = (r->precision == HEPT_PREC_F32 || r->precision == HEPT_PREC_F32_MFMA) ? 1 : 0;
+    jb.f32 = (r->precision == HEPT_PREC_F32 || r->precision == HEPT_PREC_F32_MFMA || r->precision == HEPT_PREC_F32_DIFF) ? 1 : 0;
     static const int vy = [] { const char* e = getenv("HEPT_ROW_RIDERS"); const int n = e ? atoi(e) : 0; return n > 0 && n <= 64 ? n : HEPT_ROWS_RIDERS; }();
     jb.vy = vy;   // (HEPT_ROW_RIDERS=<grid rows>: tuning; read once)
     return jb;

@@ -16,6 +16,8 @@ checkpoints carry) and call ``forward`` with that variant's kwargs — ``raw_siz
 
 Two keyword-only extensions: ``precision`` ("fp32" reference numerics: f32 rows, tile products as split-bf16
 MFMAs accurate to f32 round-off / "fp32_mfma" the same on the native f32 MFMA, slower, kept as ground truth /
+"fp32_diff" = "fp32_mfma" with the coordinate part of the logit as explicit differences: the mode for a trained
+``w_rpe`` on un-normalised coordinates, where the reference's own fp32 logits are rounding noise /
 "bf16" MFMA tiles / "mixed16" = fp16 q̂,k̂ tiles with bf16 weights and values) and ``process_group`` (shard the ``n_hashes`` tables over
 the ranks of a ``torch.distributed`` group).
 
@@ -114,7 +116,7 @@ class HEPTAttention(nn.Module):
             # lands here because the parameters require grad: with fp32 tiles on one GPU it simply takes the autograd
             # path (same values); with 16-bit tiles or table sharding an eval-mode call whose inputs carry no
             # gradient is served by the inference path instead, as the reference would serve it
-            light = self.precision in ("fp32", "fp32_mfma") and self.sharding is None
+            light = self.precision in ("fp32", "fp32_mfma", "fp32_diff") and self.sharding is None
             if light or self.training or any(t.requires_grad for t in (query, key, value)):
                 return self._forward_train(query, key, value, **kwargs)
             if not self._warned_eval_grad:

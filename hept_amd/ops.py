@@ -12,7 +12,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_F32, PREC_F32_MFMA, PREC_MIXED16
+from ._lib import PREC_BF16, PREC_F32, PREC_F32_DIFF, PREC_F32_MFMA, PREC_MIXED16
 
 __all__ = [
     "precision_code", "rpe_scale", "prep_hash", "sort_tables", "block_attn", "reduce_tables", "combine_out",
@@ -25,7 +25,7 @@ __all__ = [
 
 
 def precision_code(precision) -> int:
-    if isinstance(precision, int) and not isinstance(precision, bool) and precision in (PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA):
+    if isinstance(precision, int) and not isinstance(precision, bool) and precision in (PREC_F32, PREC_BF16, PREC_MIXED16, PREC_F32_MFMA, PREC_F32_DIFF):
         return precision
     if precision == "mixed16":
         return PREC_MIXED16
@@ -33,9 +33,11 @@ def precision_code(precision) -> int:
         return PREC_F32
     if precision == "fp32_mfma":
         return PREC_F32_MFMA
+    if precision == "fp32_diff":
+        return PREC_F32_DIFF
     if precision == "bf16" or precision is torch.bfloat16:
         return PREC_BF16
-    raise ValueError(f"precision must be 'fp32', 'bf16', 'mixed16' or 'fp32_mfma', got {precision!r}")
+    raise ValueError(f"precision must be 'fp32', 'bf16', 'mixed16', 'fp32_mfma' or 'fp32_diff', got {precision!r}")
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -148,7 +150,7 @@ def prep_hash(q, k, v, coords, sqrt_w, alpha, codes, precision="fp32", t0: int =
     prec = precision_code(precision)
     # dtype tag of the row buffers: bf16 / f16 (mixed16: q^,k^ halves are fp16, the v half of kvhat is bf16) / f32
     tile = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16,
-            PREC_F32_MFMA: torch.float32}[prec]
+            PREC_F32_MFMA: torch.float32, PREC_F32_DIFF: torch.float32}[prec]
     dev = q.device
     if rows is not None:
         qhat, kvhat = rows
@@ -228,13 +230,14 @@ def segmented_argsort(keys: torch.Tensor, lens: Optional[torch.Tensor] = None) -
 def block_attn(qhat, kvhat, qpos, kpos, head_dim: int, block_size: int, f32_mfma: bool = False) -> torch.Tensor:
     """Per-table partial rows (Tl, N, H, row).  fp32 tiles: row = 32 f32 (numer in [:D], denom (+1e-20) at [D]);
     bf16 tiles with D == 24: packed row = 16 int32 dwords (24 bf16 numer | f32 denom | 0); see ``unpack_part``.
-    ``f32_mfma`` runs f32 tiles on the native f32 MFMA instead of the split-bf16 products."""
+    ``f32_mfma`` runs f32 tiles on the native f32 MFMA instead of the split-bf16 products; ``f32_mfma="diff"`` the
+    difference form of the coordinate columns on top of that (``precision="fp32_diff"``)."""
     lib = _lib.load()
     h, n, _ = qhat.shape
     tl = qpos.shape[0]
     prec = {torch.float32: PREC_F32, torch.bfloat16: PREC_BF16, torch.float16: PREC_MIXED16}[qhat.dtype]
     if f32_mfma and prec == PREC_F32:
-        prec = PREC_F32_MFMA
+        prec = PREC_F32_DIFF if f32_mfma == "diff" else PREC_F32_MFMA
     packed = lib.hept_part_precision(prec, head_dim) == PREC_BF16
     qpos = qpos.to(torch.int32).contiguous()
     kpos = kpos.to(torch.int32).contiguous()
@@ -519,7 +522,7 @@ def prep_hash_fused(x, norm_w, norm_b, eps, w_q, w_k, w_v, coords, sqrt_w, alpha
     tl = t - t0 if tl is None else tl
     prec = precision_code(precision)
     dt = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_MIXED16: torch.float16,
-            PREC_F32_MFMA: torch.float32}[prec]
+            PREC_F32_MFMA: torch.float32, PREC_F32_DIFF: torch.float32}[prec]
     dev = x.device
     if rows is not None:   # see prep_hash
         qhat, kvhat = rows

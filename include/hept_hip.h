@@ -59,6 +59,12 @@ extern "C" {
 #define HEPT_PREC_F32_MFMA 3 /* f32 tiles on v_mfma_f32_32x32x2_f32 (the exact f32 fma chain); same storage and row
                                 formats as HEPT_PREC_F32, ~2x slower -- kept as the in-library ground truth */
 
+#define HEPT_PREC_F32_DIFF 4 /* as HEPT_PREC_F32_MFMA, but the coordinate part of the logit (every row column from D on) is
+                                formed as -(q^_c - k^_c)^2 / 2 from the difference of the stored values instead of
+                                q^.k^ - |q^|^2/2 - |k^|^2/2: no cancellation when sqrt_w . coords is large (a trained
+                                w_rpe on un-normalised coordinates: terms of ~3e8 whose f32 sum is noise).  The mode for
+                                such inputs; mathematically the same operator (example/hept.py:8-12) */
+
 #define HEPT_ROW 32          /* padded row width (elements) of qhat / k / v / part rows */
 #define HEPT_MAX_TABLES 8    /* tables per hept_prep_hash / hept_sort_tables call; the whole-operator entry points
                                 take any number of tables and walk them in chunks of this size */

@@ -48,7 +48,8 @@ def _staged(g, inp, precision, qpos=None, kpos=None):
     ph = ops.prep_hash(g["q"], g["k"], g["v"], g["coords"], sw, g["alpha"], g["combined_shifts"], precision)
     if qpos is None:
         qpos, kpos = ops.sort_tables(ph["qproj"], ph["kproj"], g["combined_shifts"], ph["minmax"])
-    part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, inp["block_size"])
+    part = ops.block_attn(ph["qhat"], ph["kvhat"], qpos, kpos, d, inp["block_size"],
+                          f32_mfma={"fp32_mfma": True, "fp32_diff": "diff"}.get(precision, False))
     out = ops.combine_out(part, d, g["out_weight"], g["out_bias"])
     return dict(sqrt_w=sw, part=part, out=out, qpos=qpos, kpos=kpos, **ph)
 
@@ -518,7 +519,8 @@ G7_MIN_ROWS_AT_G3_TOL = 0.7   # measured 0.80 (printed below); see DESIGN.md sec
 # inside the G3 tolerance (median row error 1.6e-4, worst 0.133); the HIP fp32 output has to do as well, up to this slack
 G7_FP64_ROWS_SLACK = 0.02
 G7_FP64_FACTOR = 1.5
-G7_FP64_FAR_ROWS = 20     # 0.33 % of the rows (measured 8)
+G7_FP64_FAR_ROWS = 10     # measured 8 of 6016 (the reference: 0); precision="fp32_diff" below: 0
+G7_FP64_MEAN_X = 16.0     # mean row error of the fp32 mode over the reference's: measured 13.8 (the far rows carry it)
 
 
 def test_unrescaled_checkpoint_fp32_is_as_close_to_float64_as_the_reference(gpu_device):
@@ -554,6 +556,50 @@ def test_unrescaled_checkpoint_fp32_is_as_close_to_float64_as_the_reference(gpu_
     far = int((r_hip > 0.5).sum())
     print(f"g7 vs float64: rows off by more than 0.5: HIP {far}, reference fp32 {int((r_ref > 0.5).sum())}")
     assert far <= G7_FP64_FAR_ROWS
+    # the MEAN is asserted too (round 6): it is 13.8x the reference's, all of it those far rows -- which is why
+    # precision="fp32_diff" exists (next test) and is the mode DESIGN.md section 4 names for such inputs
+    assert float(r_hip.mean()) <= G7_FP64_MEAN_X * float(r_ref.mean())
+
+
+def test_unrescaled_checkpoint_difference_form_is_closer_to_float64_than_the_reference(gpu_device):
+    """precision="fp32_diff" (round 6): the coordinate part of every logit as -(q^_c - k^_c)^2 / 2 from the stored values
+    instead of q^.k^ - |q^|^2/2 - |k^|^2/2 (example/hept.py:8-12) -- the same operator without the cancellation of 3e8-sized
+    terms.  On the shipped layer-0 scales with raw coordinates it has to beat the reference's OWN fp32 evaluation against
+    the float64 yardstick on every count: more rows inside the G3 tolerance, smaller median, mean and worst row error,
+    and no row far off."""
+    inp, fx = cases.load_case("g7_ckpt_rawcoords")
+    g = _gpu(inp, gpu_device)
+    qp = torch.from_numpy(fx["q_positions"].astype(np.int32)).to(gpu_device)
+    kp = torch.from_numpy(fx["k_positions"].astype(np.int32)).to(gpu_device)
+    got = _staged(g, inp, "fp32_diff", qp, kp)["out"].cpu().double()
+    ref32, ref64 = torch.from_numpy(fx["out"]).double(), torch.from_numpy(fx["out_fp64"])
+    tol = ATOL["g3_ckpt6k"] + 1e-4 * ref64.abs()
+    e_hip, e_ref = (got - ref64).abs(), (ref32 - ref64).abs()
+    rows_hip, rows_ref = float((e_hip <= tol).all(1).float().mean()), float((e_ref <= tol).all(1).float().mean())
+    r_hip, r_ref = e_hip.amax(1), e_ref.amax(1)
+    print(f"g7 fp32_diff vs float64: rows within the G3 tolerance {rows_hip:.4f} (reference fp32 {rows_ref:.4f}); median "
+          f"{float(r_hip.median()):.3e} / {float(r_ref.median()):.3e}; mean {float(r_hip.mean()):.3e} / {float(r_ref.mean()):.3e}; "
+          f"max {float(r_hip.max()):.3e} / {float(r_ref.max()):.3e}; rows off by more than 0.5: {int((r_hip > 0.5).sum())}")
+    assert rows_hip >= rows_ref
+    assert float(r_hip.median()) <= float(r_ref.median())
+    assert float(r_hip.mean()) <= float(r_ref.mean())
+    assert float(r_hip.max()) <= float(r_ref.max())
+    assert int((r_hip > 0.5).sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["g1_rand512", "g3_ckpt6k", "g4_pileup", "g6_block100"])
+def test_difference_form_matches_the_reference_where_it_is_well_conditioned(name, gpu_device):
+    """The same mode on the ordinary golden cases (reference permutations injected): every element of the reference's
+    output at the fp32 tolerance -- the difference form changes how a logit is summed, not what it is."""
+    inp, fx = cases.load_case(name)
+    g = _gpu(inp, gpu_device)
+    qp = torch.from_numpy(fx["q_positions"].astype(np.int32)).to(gpu_device)
+    kp = torch.from_numpy(fx["k_positions"].astype(np.int32)).to(gpu_device)
+    got = _staged(g, inp, "fp32_diff", qp, kp)["out"].cpu()
+    torch.testing.assert_close(got, torch.from_numpy(fx["out"]), rtol=1e-4, atol=ATOL.get(name, 1e-5))
+    # ... and through the module (its own sort): the one-call operator runs the same kernel
+    out = _forward(g, inp, "fp32_diff")
+    assert bool(torch.isfinite(out).all()) and _rows_ok(out.cpu(), torch.from_numpy(fx["out"]), ATOL.get(name, 1e-5), 1e-4) >= 0.99
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "mixed16"])
