@@ -430,7 +430,10 @@ void block_attn_kernel(const char* __restrict__ qhat,
         }
     }
     // (direct mode: this rank's row flags are raised by the next kernel of the stream, p2p_dev.h raise_flags)
-    if (pa.direct) drain_remote_stores();
+    if (pa.direct) {
+        drain_remote_stores();
+        if (pa.counter) signal_when_all_done(pa.counter, pa.peers, pa.world, pa.flag_idx, pa.epoch, gridDim.x - pa.push_wgs);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -735,7 +738,10 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
         }
     }
 #endif
-    if (pa.direct) drain_remote_stores();   // see block_attn_kernel
+    if (pa.direct) {   // see block_attn_kernel
+        drain_remote_stores();
+        if (pa.counter) signal_when_all_done(pa.counter, pa.peers, pa.world, pa.flag_idx, pa.epoch, gridDim.x - pa.push_wgs);
+    }
 }
 
 template <bool FULL, int VP>

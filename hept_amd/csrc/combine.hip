@@ -157,7 +157,8 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
     float* stage_s_end = ffn_s + (FFN ? FFN_WFLOATS + CMB_WAVES * 32 * FFN_PITCH : 0);
     if constexpr (PUSH) {
         // the launches that stored this rank's rows into the owners' buffers have ended: announce them (raise_flags)
-        if (blockIdx.x < RAISE_WGS) raise_flags(px.peers, px.world, px.wait_groups, px.me, HEPT_MAX_RANKS_DEV, px.epoch);
+        if (px.consumer_raises && blockIdx.x < RAISE_WGS)
+            raise_flags(px.peers, px.world, px.wait_groups, px.me, HEPT_MAX_RANKS_DEV, px.epoch);
         if (tid < px.wait_groups * px.world) {
             const int g = tid / px.world, src = tid - g * px.world;
             wait_flag(flag_word(px.local, g * HEPT_MAX_RANKS_DEV + src), px.epoch, px.status, 1u, px.timeout);
@@ -488,7 +489,10 @@ __global__ __launch_bounds__(CMB_THREADS) void combine_out_kernel(const float* _
         if constexpr (SPLIT) __syncthreads();
     }
     // (PUSH: this rank's output flag is raised by the gather kernel that follows, p2p.hip)
-    if constexpr (PUSH) drain_remote_stores();
+    if constexpr (PUSH) {
+        drain_remote_stores();
+        if (px.out_counter) signal_when_all_done(px.out_counter, px.peers, px.world, OUT_FLAG_WORD + px.me, px.epoch, gridDim.x);
+    }
 }
 
 // 16 consecutive columns [16*hh, 16*hh+16) of one partial row, widened to fp32 (reduce_tables)

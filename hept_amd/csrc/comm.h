@@ -25,7 +25,8 @@ struct hept_comm {
     char* p2p_peer[HEPT_MAX_RANKS] = {};  // every rank's buffer as mapped here (own rank: p2p_local)
     bool p2p_open = false;
     char** d_peer = nullptr;     // device copy of p2p_peer
-    unsigned int* d_state = nullptr;  // device words: [0..8] unused since round 5 (completion counters of rounds 2-4), [16] status,
+    unsigned int* d_state = nullptr;  // device words: [0], [1] completion counters of the row / output producers (used with
+                                      // HEPT_P2P_PRODUCER_SIGNAL=1 only: p2p.hip producer_signal), [16] status,
                                       // [18, 19] device address of h_status (p2p_dev.h: HEPT_STATE_*)
     unsigned int* h_status = nullptr; // host-mapped copy of the status word: a kernel whose wait timed out writes it
     bool broken = false;              // a step failed on the host after it had taken its epoch: the ranks' epochs may

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void wait_rows_kernel(char* local, char* const
                                                         unsigned int epoch, unsigned int* status,
                                                         unsigned long long timeout) {
     const int i = threadIdx.x;
-    if (peers) raise_flags(peers, world, head_groups, me, HEPT_MAX_RANKS, epoch);
+    if (peers) raise_flags(peers, world, head_groups, me, HEPT_MAX_RANKS, epoch);   // (null: the producers signalled)
     if (i < head_groups * world) {
         const int g = i / world, s = i - g * world;
         wait_flag(flag_word(local, g * HEPT_MAX_RANKS + s), epoch, status, 1u, timeout);
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void wait_rows_kernel(char* local, char* const
 // (a slice computed after a timed-out wait goes out as NaN, see combine_out_kernel<PUSH>)
 // (the output flag is raised by the gather kernel that follows)
 __global__ __launch_bounds__(256) void push_out_kernel(char* const* peers, int world, int me, size_t slice_off,
-                                                       size_t slice_bytes, const unsigned int* status) {
+                                                       size_t slice_bytes, const unsigned int* status,
+                                                       unsigned int* counter, unsigned int epoch) {
     const u32x4* src = reinterpret_cast<const u32x4*>(peers[me] + slice_off);
     const size_t n16 = slice_bytes / 16;
     const bool poisoned = status_bad(status);
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void push_out_kernel(char* const* peers, int w
             if (s != me) store16_system(peers[s] + slice_off + i * 16, v);
     }
     drain_remote_stores();
+    if (counter) signal_when_all_done(counter, peers, world, OUT_FLAG_WORD + me, epoch, gridDim.x);
 }
 
 // `bytes` = the whole (n_pad, D) output, `valid_bytes` = its first N rows: the padding rows are written as zeros (the
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(256) void wait_copy_out_kernel(char* local, int wor
                                                             unsigned int* status, unsigned long long timeout,
                                                             size_t skip_lo, size_t skip_hi, char* const* peers, int me) {
     // this rank's slice has been stored into every rank's output region by the kernel in front of this one
-    if (blockIdx.x < RAISE_WGS) raise_flags(peers, world, 1, OUT_FLAG_WORD + me, 0, epoch);
+    // (peers null: that kernel raised the flag itself, HEPT_P2P_PRODUCER_SIGNAL)
+    if (peers && blockIdx.x < RAISE_WGS) raise_flags(peers, world, 1, OUT_FLAG_WORD + me, 0, epoch);
     if (threadIdx.x < world) wait_flag(flag_word(local, OUT_FLAG_WORD + threadIdx.x), epoch, status, 2u, timeout);
     __syncthreads();
     const bool bad = status_bad(status);
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void wait_copy_out_kernel(char* local, int wor
 __global__ __launch_bounds__(256) void wait_out_kernel(char* local, int world, unsigned int epoch, size_t out_off,
                                                        size_t valid_bytes, unsigned int* status,
                                                        unsigned long long timeout, char* const* peers, int me) {
-    raise_flags(peers, world, 1, OUT_FLAG_WORD + me, 0, epoch);
+    if (peers) raise_flags(peers, world, 1, OUT_FLAG_WORD + me, 0, epoch);
     if (threadIdx.x < world) wait_flag(flag_word(local, OUT_FLAG_WORD + threadIdx.x), epoch, status, 2u, timeout);
     __syncthreads();
     if (!status_bad(status)) return;
@@ -112,6 +115,15 @@ __global__ __launch_bounds__(256) void wait_out_kernel(char* local, int world, u
 #define HEPT_COPY_OUT_WGS 256
 #endif
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+// HEPT_P2P_PRODUCER_SIGNAL=1: the protocol of rounds 2-4 (p2p_dev.h signal_when_all_done) instead of "a kernel boundary is
+// the completion signal" -- an A/B switch and a fallback for a stack on which a wave's stores to a peer GPU are not
+// acknowledged before the wave retires.  Must be set on EVERY rank (it decides who raises the flags).
+inline bool producer_signal() {
+    static const bool on = [] { const char* e = getenv("HEPT_P2P_PRODUCER_SIGNAL"); return e && *e && *e != '0'; }();
+    return on;
+}
+// completion counters in hept_comm::d_state: [0] row producers of a launch, [1] output producers
+constexpr int STATE_ROW_COUNTER = 0, STATE_OUT_COUNTER = 1;
 constexpr int CMB_WAIT_MAX = 256;  // threads of the combine that poll one arrival flag each
 
 }  // namespace
@@ -303,6 +315,7 @@ int hept_p2p_push_args(hept_comm* c, const float* part, int part_precision, int 
     a.flag_idx = g * HEPT_MAX_RANKS + c->rank;
     a.push_wgs = push_wgs;
     a.direct = 0;
+    a.counter = producer_signal() ? c->d_state + STATE_ROW_COUNTER : nullptr;
     a.self = mirror ? c->p2p_self : c->p2p_local;
     *out = a;
     return HEPT_OK;
@@ -336,7 +349,8 @@ int hept_p2p_reduce_push(hept_comm* c, const float* part, int part_precision, in
 
 int hept_p2p_wait_rows(hept_comm* c, int head_groups, hipStream_t st) {
     if (!c || !c->p2p_open || head_groups * c->world > 256) return HEPT_ERR_ARG;
-    hipLaunchKernelGGL(wait_rows_kernel, dim3(1), dim3(256), 0, st, c->p2p_local, c->d_peer, c->rank, head_groups, c->world,
+    hipLaunchKernelGGL(wait_rows_kernel, dim3(1), dim3(256), 0, st, c->p2p_local,
+                       producer_signal() ? (char* const*)nullptr : (char* const*)c->d_peer, c->rank, head_groups, c->world,
                        c->epoch, c->d_state + HEPT_STATE_STATUS, c->timeout_ticks);
     return hept_launch_status();
 }
@@ -348,7 +362,7 @@ int hept_p2p_push_out(hept_comm* c, int per, int D, const P2pLayout& lay, hipStr
     const size_t blocks = (slice_bytes / 16 + 255) / 256;
     hipLaunchKernelGGL(push_out_kernel, dim3((unsigned)(blocks < 512 ? (blocks ? blocks : 1) : 512)), dim3(256), 0, st,
                        c->d_peer, c->world, c->rank, lay.out_off + (size_t)c->rank * slice_bytes, slice_bytes,
-                       c->d_state + HEPT_STATE_STATUS);
+                       c->d_state + HEPT_STATE_STATUS, producer_signal() ? c->d_state + STATE_OUT_COUNTER : nullptr, c->epoch);
     return hept_launch_status();
 }
 
@@ -371,6 +385,8 @@ int hept_p2p_combine_push(hept_comm* c, int head_groups, int per, int cnt, int H
     px.status = c->d_state + HEPT_STATE_STATUS;
     px.timeout = c->timeout_ticks;
     px.wait_groups = head_groups;
+    px.consumer_raises = producer_signal() ? 0 : 1;
+    px.out_counter = producer_signal() ? c->d_state + STATE_OUT_COUNTER : nullptr;
     px.slice_off = lay.out_off + (size_t)c->rank * per * 24 * 4;
     px.self_rows = reinterpret_cast<const float*>(c->p2p_self + lay.recv_off);
     px.out_local = reinterpret_cast<char*>(out_local);
@@ -385,7 +401,8 @@ int hept_p2p_wait_out(hept_comm* c, int N, int D, const P2pLayout& lay, hipStrea
     if (valid % 16 != 0) return HEPT_ERR_SHAPE;
     // (every workgroup polls the same few flags: the extra ones are there for the NaN fill of the failure path)
     hipLaunchKernelGGL(wait_out_kernel, dim3(16), dim3(256), 0, st, c->p2p_local, c->world, c->epoch, lay.out_off, valid,
-                       c->d_state + HEPT_STATE_STATUS, c->timeout_ticks, c->d_peer, c->rank);
+                       c->d_state + HEPT_STATE_STATUS, c->timeout_ticks,
+                       producer_signal() ? (char* const*)nullptr : (char* const*)c->d_peer, c->rank);
     return hept_launch_status();
 }
 
@@ -426,6 +443,6 @@ int hept_p2p_wait_copy_out(hept_comm* c, int n_pad, int N, int D, const P2pLayou
     const unsigned grid = (unsigned)(blocks < max_wgs ? (blocks ? blocks : 1) : max_wgs);
     hipLaunchKernelGGL(wait_copy_out_kernel, dim3(grid), dim3(256), 0,
                        st, c->p2p_local, c->world, c->epoch, lay.out_off, bytes, valid, dst, c->d_state + HEPT_STATE_STATUS,
-                       c->timeout_ticks, lo, hi, c->d_peer, c->rank);
+                       c->timeout_ticks, lo, hi, producer_signal() ? (char* const*)nullptr : (char* const*)c->d_peer, c->rank);
     return hept_launch_status();
 }

@@ -15,6 +15,10 @@ struct P2pDev {
     unsigned long long timeout;  // bound of a wait, in wall_clock64 ticks
     int wait_groups;             // flags to wait for before reading received rows: wait_groups * world
     size_t slice_off;            // bytes from a buffer's start to this rank's slice of the gathered output
+    // HEPT_P2P_PRODUCER_SIGNAL=1 (A/B and fallback, see signal_when_all_done): the producers raise the flags themselves;
+    // the kernels that wait must then NOT raise them at their start.  out_counter: the combine's completion counter.
+    int consumer_raises;         // 1: the default protocol (a kernel boundary is the completion signal)
+    unsigned int* out_counter;   // non-null: the fused combine counts its workgroups in and raises the output flag itself
     const float* self_rows;      // the rows this rank sent to itself: ordinary device memory, laid out like the receive region
     char* out_local;             // the caller's (n_pad, D) output, or null (view mode): this rank's own slice goes there
     size_t out_base;             // bytes from a buffer's start to row 0 of the gathered output
@@ -38,6 +42,9 @@ struct PushArgs {
     // owns the point (direct_row below; `part`, `Tl`, `push_wgs` are unused).  No extra pass over the rows, no
     // separate push: only the drain of the last stores is exposed.
     int direct;
+    // non-null (HEPT_P2P_PRODUCER_SIGNAL=1): the producing workgroups count themselves in here and the last one raises
+    // flag_idx = epoch in every rank's buffer after a system-scope fence (the protocol of rounds 2-4)
+    unsigned int* counter;
     // Rows whose owner is THIS rank never leave the GPU: they go to an ordinary (cached) mirror of the exchange buffer
     // (same offsets) instead of the uncached buffer the peers store into -- the combine reads its own "table" there.
     char* self;
@@ -122,6 +129,26 @@ __device__ __forceinline__ void raise_flags(char* const* peers, int world, int n
 }
 
 
+// The protocol of rounds 2-4, kept as an A/B and a fallback (HEPT_P2P_PRODUCER_SIGNAL=1): nothing is inferred
+// from a kernel boundary.  Every producing wave waits for the acknowledgement of its own stores, the workgroup meets at
+// a barrier and counts itself in with a device-scope atomic; the workgroup that completes the count resets the counter,
+// issues a system-scope fence and raises `flag_idx` = epoch in every rank's buffer.  Costs the producers their early
+// retirement (one-table block attention 33 -> 57 us on the proxy), which is why it is not the default.
+__device__ __forceinline__ void signal_when_all_done(unsigned int* counter, char* const* peers, int world, int flag_idx,
+                                                     unsigned int epoch, unsigned int n_workgroups) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == n_workgroups - 1) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            for (int s = 0; s < world; ++s)
+                __hip_atomic_store(flag_word(peers[s], flag_idx), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // direct mode: address of the partial row of point n, head h0 + hl, in the owner's receive buffer (same slot as
 // reduce_push_body's: recv[g][me][n - dest * per][hl]); `remote` = the owner is another rank (system-scope stores)
 __device__ __forceinline__ char* direct_row(const PushArgs& a, int n, int hl, int rowb, bool& remote) {
@@ -202,8 +229,10 @@ __device__ __forceinline__ void reduce_push_body(const PushArgs& a, int wg_index
         if (dest == a.me) *reinterpret_cast<u32x4*>(row + pc * 16) = v;
         else store16_system(row + pc * 16, v);
     }
-    // (no signal: the flags of every head group are raised by the kernel that waits for the rows, see raise_flags)
+    // (no signal: the flags of every head group are raised by the kernel that waits for the rows, see raise_flags --
+    //  unless the producers have been asked to signal themselves)
     drain_remote_stores();
+    if (a.counter) signal_when_all_done(a.counter, a.peers, a.world, a.flag_idx, a.epoch, (unsigned int)a.push_wgs);
 }
 
 }  // namespace

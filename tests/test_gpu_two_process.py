@@ -183,6 +183,57 @@ def test_eight_ranks_one_table_each_match_the_unsharded_operator(precision, grou
     torch.testing.assert_close(ret[0][0], plain, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("world,precision,groups", [(8, "bf16", None), (8, "fp32", 2), (3, "bf16", 2)])
+def test_producer_signal_fallback_of_the_one_sided_exchange(world, precision, groups, gpu_device, monkeypatch):
+    """HEPT_P2P_PRODUCER_SIGNAL=1: the protocol of rounds 2-4 -- every producing workgroup drains its
+    stores and counts itself in, the last one raises the flags after a system-scope fence; the waiting kernels raise
+    nothing -- kept as an A/B and a fallback beside "a kernel boundary is the completion signal".  Same outputs as the
+    plain operator, on the direct-scatter path (one table per rank) with one and several head groups."""
+    monkeypatch.setenv("HEPT_P2P_PRODUCER_SIGNAL", "1")   # inherited by the spawned ranks; read once per process
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_synthetic_worker, args=(world, port, precision, "p2p", ret, groups, False), nprocs=world, join=True)
+    assert all(torch.equal(ret[0][0], ret[r][0]) for r in range(1, world)) and "one-sided" in ret[0][1]
+    from hept_amd import ops
+    from hept_amd.synthetic import make_inputs
+
+    inp = make_inputs(_SIZES, block_size=128, n_hashes=world, seed=5, cluster_size=8)
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    plain = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
+                        g["out_weight"], g["out_bias"], block_size=128, w_per_dist=10, precision=precision).cpu()
+    torch.testing.assert_close(ret[0][0], plain, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_producer_signal_fallback_with_several_tables_per_rank(precision, gpu_device, monkeypatch):
+    """... and on the carried-push path (two ranks, the tables of g6 split between them: the table sum + push of a head
+    group rides in the next group's block-attention launch and signals from there)."""
+    monkeypatch.setenv("HEPT_P2P_PRODUCER_SIGNAL", "1")
+    name, world = "g6_block100", 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, name, precision, "all_to_all", ret), nprocs=world, join=True)
+    assert torch.equal(ret[0], ret[1])
+    from hept_amd import ops
+
+    inp, _ = cases.load_case(name)
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    plain = ops.forward(g["q"], g["k"], g["v"], g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
+                        g["out_weight"], g["out_bias"], block_size=inp["block_size"], w_per_dist=10,
+                        precision=precision).cpu()
+    if precision != "fp32":
+        err = (ret[0] - plain).abs().amax(-1)
+        assert bool((err <= 4e-3 * (plain.abs().amax(-1) + 1e-2)).all())
+    else:
+        torch.testing.assert_close(ret[0], plain, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("world,mode,precision", [(2, "all_reduce", "fp32"), (2, "all_reduce", "bf16"),
                                                   (2, "all_to_all", "fp32"), (2, "all_to_all", "bf16"),
                                                   (3, "all_to_all", "bf16"), (3, "all_to_all", "mixed16")])
