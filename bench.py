@@ -143,7 +143,7 @@ SMALL_SORT_MAX = 6144      # csrc/sort_tables.hip SMALL_CAP: clouds up to this s
 RIDERS_MAX = 131072        # ... and up to this size the bucket-sort launch can carry the v rows (hept_sort_carries_rows)
 
 
-def step_kernels(n, h, d, c, t, precision):
+def step_kernels(n, h, d, c, t, precision, block_size=128):
     """Algorithmic bytes of every launch of one hept_forward: what each kernel has to read and
     write once, whatever the caches do.  Returns [(stage key, kernel name, bytes)] in launch order; stage keys are those of
     ops.profile_read()."""
@@ -151,7 +151,12 @@ def step_kernels(n, h, d, c, t, precision):
     row = 32 * s                                              # one q^ / k^ / v row
     keys = 2 * t * h * n                                      # sort keys: q and k segments
     v_rows = n * h * d * 4 + n * h * row                      # v in, v halves of the kvhat rows out
-    riders = (t >= 2 or precision == "fp32") and SMALL_SORT_MAX < n <= RIDERS_MAX   # csrc/capi.hip run_begin
+    # csrc/capi.hip run_begin: f32 rows above block 128 read the values in place (direct_v_pays): nobody builds v rows
+    direct_v = precision == "fp32" and block_size > 128 and d % 4 == 0 and not os.environ.get("HEPT_NO_DIRECT_V")
+    riders = ((t >= 2 or precision == "fp32") and SMALL_SORT_MAX < n <= RIDERS_MAX and not direct_v
+              and not os.environ.get("HEPT_NO_ROW_RIDERS")) or (os.environ.get("HEPT_FORCE_ROW_RIDERS") and not direct_v)
+    if direct_v:
+        v_rows = 0
     prep = 2 * n * h * d * 4 + 2 * n * c * 4 + t * h * n * 8 // 8 + 2 * n * h * row + keys * 4
     packed = precision != "fp32" and d == 24
     combine = t * n * h * (64 if packed else 128) + n * d * 4

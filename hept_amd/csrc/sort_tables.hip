@@ -97,8 +97,8 @@ struct RegionArgs {
     int segs;
 };
 constexpr int REGION_MAX_N = 131072;   // = NTOP * BKT_CAP_SMALL / 2: the range of the small-tile bucket kernel
-constexpr unsigned int region_cap(int N) {   // >= 8x the average bucket, a power of two, >= 2048
-    unsigned int c = 2048;
+constexpr unsigned int region_cap(int N) {   // >= 8x the average bucket, a power of two, >= 1024 = 2 x the lean path's bucket
+    unsigned int c = 1024;   // (round 5's floor of 2048 gave an 8k-point cloud 214 MB of regions: ADVICE round 5)
     while ((size_t)c * 32 < (size_t)N) c <<= 1;
     return c;
 }

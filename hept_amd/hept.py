@@ -126,6 +126,10 @@ class HEPTAttention(nn.Module):
                               f"precision={self.precision!r}/table sharding runs the inference path (no parameter "
                               "gradients); call under torch.no_grad() or .train() to be explicit", stacklevel=2)
                 self._warned_eval_grad = True
+        if self.sharding is not None and self.sharding.out_view and torch.is_grad_enabled():
+            # a view of the exchange buffer is overwritten by the second next call: autograd must never save it
+            raise RuntimeError("TableSharding(out_view=True) hands out views of the exchange buffer that later calls "
+                               "overwrite: call the module under torch.no_grad()")
         coords = kwargs["coords"]
         src = "combined_shifts" not in kwargs  # the src variant's kwargs: raw_size, regions_h, region_indices
         w_rpe_weight = kwargs["w_rpe"].weight
@@ -192,7 +196,8 @@ class HEPTAttention(nn.Module):
                 return ops.forward_sharded(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
                                            self.e2lsh.alpha, self.out_linear.weight, self.out_linear.bias, comm=comm,
                                            world=sh.world, t0=t0, tl=tl, head_groups=sh.groups_for(h), workspace=ws,
-                                           xbuf=xbuf, one_sided=one_sided, geo=geo, out_view=sh.out_view, **common)
+                                           xbuf=xbuf, one_sided=one_sided, geo=geo, out_view=sh.out_view, view_owner=sh,
+                                           **common)
             # the same pipeline driven from Python over torch.distributed (gloo in the tests; fallback)
             dims = ops.partial_begin(q2, k2, v2, coords, None if src else kwargs["combined_shifts"], w_rpe_weight,
                                      self.e2lsh.alpha, t0=t0, tl=tl, workspace=ws, geo=geo, **common)

@@ -681,7 +681,7 @@ def combine_groups(part: torch.Tensor, head_dim: int, out_weight, out_bias, n0: 
 def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out_bias, *, comm: int, world: int,
                     block_size: int, w_per_dist: int, t0: int, tl: int, head_groups: int, precision="fp32",
                     workspace: torch.Tensor, xbuf: Optional[torch.Tensor] = None, one_sided: bool = False,
-                    geo=None, out_view: bool = False) -> torch.Tensor:
+                    geo=None, out_view: bool = False, view_owner=None) -> torch.Tensor:
     """Table-sharded operator in one C call (``hept_forward_sharded``): this rank's tables [t0, t0+tl), the RCCL
     exchange pipelined by head groups on the communicator's side stream, combine of this rank's points and the
     all-gather; returns the full (N, D) output.  ``comm`` is a ``hept_comm*`` (see ``hept_amd.sharding``);
@@ -724,7 +724,7 @@ def forward_sharded(q, k, v, coords, codes, w_rpe_weight, alpha, out_weight, out
 
         ptr = ctypes.c_void_p()
         _lib.check(lib.hept_comm_out_view(comm, ctypes.byref(ptr)), "hept_comm_out_view")
-        return torch.as_tensor(_DeviceRows(ptr.value, n, d), device=q.device)
+        return torch.as_tensor(_DeviceRows(ptr.value, n, d, view_owner), device=q.device)
     return out_full[:n]
 
 
@@ -732,9 +732,18 @@ class _DeviceRows:
     """(n, d) f32 rows at a device address owned by the C library (the exchange buffer of a communicator), for
     ``torch.as_tensor`` (zero-copy through ``__cuda_array_interface__``)"""
 
-    def __init__(self, ptr: int, n: int, d: int):
+    def __init__(self, ptr: int, n: int, d: int, owner=None):
         self.__cuda_array_interface__ = {"shape": (n, d), "typestr": "<f4", "data": (ptr, False), "version": 2,
                                          "strides": None}
+        # the tensor made from this object keeps it alive, and with it the owner of the memory (the TableSharding whose
+        # communicator holds the exchange buffer): the buffer cannot be unmapped under a live view (ADVICE round 5)
+        self.owner = owner
+        if owner is not None:
+            owner._live_views = getattr(owner, "_live_views", 0) + 1
+
+    def __del__(self):
+        if self.owner is not None:
+            self.owner._live_views = max(0, getattr(self.owner, "_live_views", 1) - 1)
 
 
 # ---- the dense tail of the Attn block's training step (csrc/block_train.hip; rows of 24 floats)

@@ -288,6 +288,10 @@ class TableSharding:
         return self._xbuf
 
     def close(self) -> None:
+        if getattr(self, "_live_views", 0) > 0 and self._native:
+            # (every live view holds a reference to this object, so __del__ cannot get here with views alive)
+            raise RuntimeError(f"TableSharding.close(): {self._live_views} view(s) of the gathered output (out_view=True) "
+                               "are still alive; drop them first -- the exchange buffer they point into would be unmapped")
         if self._native:
             from . import _lib
 

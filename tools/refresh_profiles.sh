@@ -8,21 +8,12 @@ rm -rf $O; mkdir -p $O
 # ---- PMC passes first: bench.py copies roofline.traffic / mfma_busy_frac from profiles/attn_traffic.json only when the
 #      record carries the digest of THIS tree's block-attention sources and the kernel template this run launches
 cd $R
-bash tools/pmc.sh bf16r > /dev/null 2>&1
-bash tools/pmc.sh fp32r --precision fp32 > /dev/null 2>&1
-python3 tools/pmc_summary.py gpurun_out/pmc_bf16r > $O/pmc_bf16.txt 2>&1
-python3 tools/pmc_summary.py gpurun_out/pmc_fp32r > $O/pmc_fp32.txt 2>&1
-bash tools/pmc_shapes.sh > /dev/null 2>&1     # block 256 (pileup), block 100, the batched tracking-6k clouds: both precisions
-python3 tools/make_traffic.py $O/attn_traffic.json gpurun_out/pmc_bf16r gpurun_out/pmc_fp32r gpurun_out/pmcs_* > $O/attn_traffic_summary.txt 2>&1
+bash tools/pmc_all.sh > $O/pmc_all.log 2>&1     # every record of bench.py's line, both precisions: gpurun_out/pmca_<key>_<precision>/
+cp gpurun_out/attn_traffic.json $O/attn_traffic.json
+cp gpurun_out/attn_traffic_summary.txt $O/attn_traffic_summary.txt
+cp gpurun_out/pmc_c3_bf16.txt $O/pmc_bf16.txt
+cp gpurun_out/pmc_c3_fp32.txt $O/pmc_fp32.txt
 cp $O/attn_traffic.json profiles/attn_traffic.json
-python3 - <<'PY' > $O/traffic_check.txt 2>&1
-import bench
-for prec, bs in (("bf16", 128), ("fp32", 128), ("bf16", 256), ("fp32", 256), ("bf16", 100), ("fp32", 100)):
-    ent, src = bench.pmc_record(prec, bs)
-    print(prec, bs, "traffic", ent and ent["traffic"], "mfma_busy", ent and ent["mfma_busy_frac"], "valu_issue", ent and ent["valu_issue_frac"], "refused:", src.get("refused"))
-    assert ent is not None, src
-PY
-cat $O/traffic_check.txt
 cd /tmp
 for prec in fp32 bf16; do
   # kernel durations from the profiled run; the JSON line from an un-profiled run of the same command (the tracer
