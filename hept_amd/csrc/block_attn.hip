@@ -479,7 +479,10 @@ constexpr int split_ck(int nkt) { return nkt == 8 ? HEPT_SPLIT_CK8 : (nkt == 4 ?
 #ifndef HEPT_SPLIT_PP
 #define HEPT_SPLIT_PP 2
 #endif
-template <int NKT, bool FULL, int VP>
+// DIFF (HEPT_PREC_F32_DIFF at D = 24): the difference form of block_attn_kernel<.., DIFF> on this kernel -- the 24 feature
+// columns through the six-term split products, the columns from 24 on as -(q^_c - k^_c)^2 / 2 from the stored f32 values
+// (the keys' six coordinate columns in a side array of the staged chunk, the feature-only norms formed while staging).
+template <int NKT, bool FULL, int VP, bool DIFF = false>
 __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float* __restrict__ qhat,
                                                                     const float* __restrict__ kvhat,
                                                                     const int* __restrict__ qpos,
@@ -499,6 +502,7 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_s = smem;                   // 3 planes [CK][32 bf16], 16-B chunks XOR-swizzled
     char* v_s = smem + 3 * CK * PROW;   // VP planes [CK][32 bf16], read transposed
+    float* kc_s = reinterpret_cast<float*>(smem + (3 + VP) * CK * PROW);   // DIFF: [CK][8] columns 24 .. 29 of the chunk's keys, f32
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hh = lane >> 5, li = lane & 31;
     const int bid = (int)blockIdx.x - pa.push_wgs;
@@ -557,6 +561,27 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
             if (ci >= CK * 8) break;
             const int row = ci >> 3, c = ci & 7;
             u32x4 ph, pm, pl;
+            if constexpr (DIFF) {
+                // the eight items of a key are eight consecutive lanes: items 0 .. 2 hold its 24 feature columns, item 3
+                // columns 24 .. 31.  Feature norm: three partial sums meet in item 3's lane (DPP row_shr); its six
+                // coordinate columns go to the side array and leave the product, column 31 takes -|k_feat|^2 / 2
+                float sq = 0.f;
+                if (c < 3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sq = fmaf(pre[it][j], pre[it][j], sq);
+                }
+                const int sqi = __builtin_bit_cast(int, sq);
+                const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, sqi, 0x111, 0xF, 0xF, true));
+                const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, sqi, 0x112, 0xF, 0xF, true));
+                const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, sqi, 0x113, 0xF, 0xF, true));
+                if (c == 3) {
+                    *reinterpret_cast<f32x4*>(kc_s + row * 8) = f32x4{pre[it][0], pre[it][1], pre[it][2], pre[it][3]};
+                    *reinterpret_cast<f32x4*>(kc_s + row * 8 + 4) = f32x4{pre[it][4], pre[it][5], 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) pre[it][j] = 0.f;
+                    pre[it][7] = -0.5f * ((s3 + s2) + s1);
+                }
+            }
             if (c < 4) {
                 split3_bf16(pre[it], ph, pm, pl);
                 const int off = row * PROW + ((c ^ ((row >> 2) & 3)) * 16);
@@ -582,16 +607,41 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     const int qsrc = qp[qvalid ? qi : 0];
     const float* qrow = qbase + (size_t)qsrc * 32;
     u32x4 qh[2], qm[2], ql[2];
+    float qc[DIFF ? 6 : 1];   // DIFF: this query's columns 24 .. 29 (both lane halves: the logits of a query live in both)
+    {
+        float av[2][8];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hh);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hh + 4);
-        float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        if (s == 1 && hh == 1) {  // the norms ride in the product: q^[30] = -|q|^2/2 meets k^[30] = 1, q^[31] = 1
-            a[6] = a[7];          // meets k^[31] = -|k|^2/2 (columns E..30 of the stored rows are zero, E <= 30)
-            a[7] = 1.f;
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hh);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hh + 4);
+            av[s][0] = a0[0]; av[s][1] = a0[1]; av[s][2] = a0[2]; av[s][3] = a0[3];
+            av[s][4] = a1[0]; av[s][5] = a1[1]; av[s][6] = a1[2]; av[s][7] = a1[3];
         }
-        split3_bf16(a, qh[s], qm[s], ql[s]);
+        if constexpr (DIFF) {
+            // lane half 0 holds columns 0 .. 7 and 16 .. 23, half 1 columns 8 .. 15 and 24 .. 31: the feature norm is the sum
+            // of both halves' squares, the coordinates come from half 1
+            float fn = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fn = fmaf(av[0][j], av[0][j], fn);
+            if (hh == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fn = fmaf(av[1][j], av[1][j], fn);
+            }
+            fn += __shfl_xor(fn, 32);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) qc[c] = __shfl(av[1][c], li + 32);
+            if (hh == 1) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) av[1][j] = 0.f;
+                av[1][6] = -0.5f * fn;   // meets k^[30] = 1
+                av[1][7] = 1.f;          // meets k^[31] = -|k_feat|^2 / 2
+            }
+        } else if (hh == 1) {  // the norms ride in the product: q^[30] = -|q|^2/2 meets k^[30] = 1, q^[31] = 1
+            av[1][6] = av[1][7];   // meets k^[31] = -|k|^2/2 (columns E..30 of the stored rows are zero, E <= 30)
+            av[1][7] = 1.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) split3_bf16(av[s], qh[s], qm[s], ql[s]);
     }
 
     f32x16 z;
@@ -643,7 +693,20 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
             const int kt = ch * TPC + kl;
             if (kt >= NKT) break;
             if (!FULL && kt * 32 >= B) break;  // uniform
-            const f32x16 x = xs[kg];
+            f32x16 x = xs[kg];
+            if constexpr (DIFF) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* kc = kc_s + (kl * 32 + hept_acc_row(r, hh)) * 8;   // (a broadcast: one key per lane half)
+                    const f32x4 k0 = *reinterpret_cast<const f32x4*>(kc), k1 = *reinterpret_cast<const f32x4*>(kc + 4);
+                    float d0 = qc[0] - k0[0], d1 = qc[1] - k0[1], d2 = qc[2] - k0[2], d3 = qc[3] - k0[3];
+                    float d4 = qc[4] - k1[0], d5 = qc[5] - k1[1];
+                    float dsq = d0 * d0;
+                    dsq = fmaf(d1, d1, dsq); dsq = fmaf(d2, d2, dsq); dsq = fmaf(d3, d3, dsq);
+                    dsq = fmaf(d4, d4, dsq); dsq = fmaf(d5, d5, dsq);
+                    x[r] = fmaf(-0.5f, dsq, x[r]);
+                }
+            }
 
             float pr[16];
             exp_clamped(x, pr);
@@ -744,19 +807,20 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     }
 }
 
-template <bool FULL, int VP>
+template <bool FULL, int VP, bool DIFF = false>
 int launch_attn_split(int nkt, dim3 grid, hipStream_t st, const float* qhat, const float* kvhat, const int* qpos,
                       const int* kpos, float* part, int N, int H, int D, int B, int nb, HeadRange hr, PushArgs pa) {
 #define HEPT_SPLIT_CASE(K)                                                                                       \
     case K: {                                                                                                    \
         /* the planes, or the epilogue's 4 KiB per wave where that is more (B = 224: 7 waves) */                  \
-        constexpr size_t lds = (size_t)(3 + VP) * split_ck(K) * 64 > (size_t)K * 4096 ? (size_t)(3 + VP) * split_ck(K) * 64 : (size_t)K * 4096; \
+        constexpr size_t lds0 = (size_t)(3 + VP) * split_ck(K) * 64 + (DIFF ? (size_t)split_ck(K) * 32 : 0);        \
+        constexpr size_t lds = lds0 > (size_t)K * 4096 ? lds0 : (size_t)K * 4096;                                \
         if (lds > 65536) {                                                                                       \
             static LdsRaised raised;                                                                             \
-            if (hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_split_kernel<K, FULL, VP>), lds))   \
+            if (hept_raise_lds(raised, reinterpret_cast<const void*>(&block_attn_split_kernel<K, FULL, VP, DIFF>), lds)) \
                 return HEPT_ERR_LAUNCH;                                                                          \
         }                                                                                                        \
-        hipLaunchKernelGGL((block_attn_split_kernel<K, FULL, VP>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos,   \
+        hipLaunchKernelGGL((block_attn_split_kernel<K, FULL, VP, DIFF>), grid, dim3(64 * K), lds, st, qhat, kvhat, qpos, \
                            kpos, part, N, H, D, B, nb, hr, pa);                                                        \
         break;                                                                                                   \
     }
@@ -868,8 +932,19 @@ int block_attn_impl(const void* qhat, const void* kvhat, const int32_t* qpos, co
     }
     if (precision == HEPT_PREC_F32_MFMA)
         return launch_attn<false, false, false>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
-    if (precision == HEPT_PREC_F32_DIFF)
+    if (precision == HEPT_PREC_F32_DIFF) {
+        // D = 24 (every shipped shape): the difference form on the split-bf16 kernel (1.3x the "fp32" time instead of 2x);
+        // other head dimensions: on the f32-MFMA kernel (HEPT_DIFF_MFMA=1: that kernel at D = 24 too, for A/B)
+        const char* e = getenv("HEPT_DIFF_MFMA");   // (read on every call: the parity tests switch it inside one process)
+        const bool mfma = e && *e && *e != '0';
+        if (D == 24 && !mfma) {
+            const float* qf = (const float*)qhat;
+            const float* kf = (const float*)kvhat;
+            if (B == 32 * nkt) return launch_attn_split<true, 3, true>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr, pa);
+            return launch_attn_split<false, 3, true>(nkt, grid, st, qf, kf, qpos, kpos, part, N, H, D, B, nb, hr, pa);
+        }
         return launch_attn<false, false, false, true>(nkt, grid, st, qh, kv, qpos, kpos, part, N, H, D, B, nb, hr, pa);
+    }
     return HEPT_ERR_SHAPE;
 }
 }  // namespace

@@ -561,12 +561,16 @@ def test_unrescaled_checkpoint_fp32_is_as_close_to_float64_as_the_reference(gpu_
     assert float(r_hip.mean()) <= G7_FP64_MEAN_X * float(r_ref.mean())
 
 
-def test_unrescaled_checkpoint_difference_form_is_closer_to_float64_than_the_reference(gpu_device):
+@pytest.mark.parametrize("kernel", ["split", "mfma"])
+def test_unrescaled_checkpoint_difference_form_is_closer_to_float64_than_the_reference(kernel, gpu_device, monkeypatch):
     """precision="fp32_diff" (round 6): the coordinate part of every logit as -(q^_c - k^_c)^2 / 2 from the stored values
     instead of q^.k^ - |q^|^2/2 - |k^|^2/2 (example/hept.py:8-12) -- the same operator without the cancellation of 3e8-sized
     terms.  On the shipped layer-0 scales with raw coordinates it has to beat the reference's OWN fp32 evaluation against
     the float64 yardstick on every count: more rows inside the G3 tolerance, smaller median, mean and worst row error,
     and no row far off."""
+    # two kernels carry the mode: the split-bf16 kernel (D = 24: features through six-term bf16 products) and the f32-MFMA
+    # kernel (any D; HEPT_DIFF_MFMA=1 selects it at D = 24 as well)
+    monkeypatch.setenv("HEPT_DIFF_MFMA", "1" if kernel == "mfma" else "0")
     inp, fx = cases.load_case("g7_ckpt_rawcoords")
     g = _gpu(inp, gpu_device)
     qp = torch.from_numpy(fx["q_positions"].astype(np.int32)).to(gpu_device)
@@ -577,7 +581,7 @@ def test_unrescaled_checkpoint_difference_form_is_closer_to_float64_than_the_ref
     e_hip, e_ref = (got - ref64).abs(), (ref32 - ref64).abs()
     rows_hip, rows_ref = float((e_hip <= tol).all(1).float().mean()), float((e_ref <= tol).all(1).float().mean())
     r_hip, r_ref = e_hip.amax(1), e_ref.amax(1)
-    print(f"g7 fp32_diff vs float64: rows within the G3 tolerance {rows_hip:.4f} (reference fp32 {rows_ref:.4f}); median "
+    print(f"g7 fp32_diff ({kernel}) vs float64: rows within the G3 tolerance {rows_hip:.4f} (reference fp32 {rows_ref:.4f}); median "
           f"{float(r_hip.median()):.3e} / {float(r_ref.median()):.3e}; mean {float(r_hip.mean()):.3e} / {float(r_ref.mean()):.3e}; "
           f"max {float(r_hip.max()):.3e} / {float(r_ref.max()):.3e}; rows off by more than 0.5: {int((r_hip > 0.5).sum())}")
     assert rows_hip >= rows_ref
@@ -587,10 +591,12 @@ def test_unrescaled_checkpoint_difference_form_is_closer_to_float64_than_the_ref
     assert int((r_hip > 0.5).sum()) == 0
 
 
+@pytest.mark.parametrize("kernel", ["split", "mfma"])
 @pytest.mark.parametrize("name", ["g1_rand512", "g3_ckpt6k", "g4_pileup", "g6_block100"])
-def test_difference_form_matches_the_reference_where_it_is_well_conditioned(name, gpu_device):
+def test_difference_form_matches_the_reference_where_it_is_well_conditioned(name, kernel, gpu_device, monkeypatch):
     """The same mode on the ordinary golden cases (reference permutations injected): every element of the reference's
     output at the fp32 tolerance -- the difference form changes how a logit is summed, not what it is."""
+    monkeypatch.setenv("HEPT_DIFF_MFMA", "1" if kernel == "mfma" else "0")
     inp, fx = cases.load_case(name)
     g = _gpu(inp, gpu_device)
     qp = torch.from_numpy(fx["q_positions"].astype(np.int32)).to(gpu_device)
