@@ -1,5 +1,5 @@
-"""A dozen forwards of one named workload (for PMC passes of the block-attention kernel of shapes other than the
-headline's: tools/pmc_shapes.sh).  python tools/attn_shape_run.py <workload> <precision> [block size]"""
+"""A dozen forwards of one named workload (for the PMC passes of the block-attention kernel, one per record of bench.py's
+line: tools/pmc_all.sh).  python tools/attn_shape_run.py <workload> <precision> [block size]"""
 import os
 import sys
 
