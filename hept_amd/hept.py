@@ -86,6 +86,8 @@ class HEPTAttention(nn.Module):
             TableSharding(self.n_hashes, process_group) if process_group is not None else None
         )
         self._workspace: Optional[torch.Tensor] = None
+        self._ws_stream = None            # stream of the last forward that used the workspace (see _scratch)
+        self._busy = False                # a forward of this instance is being issued (two host threads at once: refused)
         self._warned_eval_grad = False
 
     def _scratch(self, nbytes: int, device) -> torch.Tensor:
@@ -93,6 +95,14 @@ class HEPTAttention(nn.Module):
         if ws is None or ws.numel() < nbytes or ws.device != device:
             ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
             self._workspace = ws
+        # One workspace per module: a forward issued on ANOTHER stream than the one before it would overwrite rows the
+        # earlier forward may still be reading.  Enforced, not only documented (round 6): the new stream waits for the
+        # stream of the call before it -- one event wait when the stream changes, nothing when it does not.
+        cur = torch.cuda.current_stream(device)
+        last = self._ws_stream
+        if last is not None and last != cur:
+            cur.wait_stream(last)
+        self._ws_stream = cur
         return ws
 
     def reserve(self, n_points: int, n_coords: int, device) -> None:
@@ -107,6 +117,16 @@ class HEPTAttention(nn.Module):
                                           self.block_size, self.precision), device)
 
     def forward(self, query, key, value, **kwargs):
+        if self._busy:   # (a flag, not a lock: the point is to refuse a second host thread, not to queue it)
+            raise RuntimeError("hept_amd.HEPTAttention: this instance is being called from two threads at once; it owns "
+                               "one workspace -- use one instance per thread")
+        self._busy = True
+        try:
+            return self._forward_impl(query, key, value, **kwargs)
+        finally:
+            self._busy = False
+
+    def _forward_impl(self, query, key, value, **kwargs):
         if not query.is_cuda:
             raise RuntimeError("hept_amd.HEPTAttention needs GPU tensors: there is no CPU fallback")
         if torch.is_grad_enabled() and any(

@@ -313,3 +313,31 @@ def test_combine_without_the_staged_rows_gives_the_same_bits(gpu_device):
         assert run.returncode == 0, run.stderr[-2000:]
         outs.append([ln for ln in run.stdout.splitlines() if ln.startswith(("fp32", "bf16"))])
     assert len(outs[0]) == 2 and outs[0] == outs[1] and all(ln.endswith("True") for ln in outs[0]), outs
+
+
+def test_two_streams_share_one_module_safely(gpu_device):
+    """One module owns one workspace.  Round 6 enforces what round 5 only documented: a forward issued on another stream
+    than the one before it waits for that stream (one event wait), so alternating streams cannot overwrite rows an earlier
+    forward is still reading -- every result equals the single-stream one."""
+    from hept_amd import HEPTAttention
+    from hept_amd.synthetic import make_inputs
+
+    inp = make_inputs([3000, 1500], block_size=128, n_hashes=3, seed=3, cluster_size=8)
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    m = HEPTAttention(30, h_dim=24, num_heads=8, block_size=128, n_hashes=3, num_w_per_dist=10, precision="bf16")
+    m.load_state_dict({"out_linear.weight": inp["out_weight"], "out_linear.bias": inp["out_bias"], "e2lsh.alpha": inp["alpha"]})
+    m = m.to(gpu_device).eval()
+    w_rpe = torch.nn.Linear(50, 192).to(gpu_device)
+    with torch.no_grad():
+        w_rpe.weight.copy_(g["w_rpe_weight"])
+        kw = dict(w_rpe=w_rpe, coords=g["coords"], combined_shifts=g["combined_shifts"])
+        ref = [m(g["q"] * (1.0 + 0.1 * i), g["k"], g["v"], **kw).clone() for i in range(6)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=gpu_device) for _ in range(2)]
+        outs = []
+        for i in range(6):
+            with torch.cuda.stream(streams[i % 2]):
+                outs.append(m(g["q"] * (1.0 + 0.1 * i), g["k"], g["v"], **kw))
+        torch.cuda.synchronize()
+    for a, b in zip(outs, ref):
+        assert torch.equal(a, b)
