@@ -255,7 +255,7 @@ def launched_kernel(precision, block_size=128, head_dim=24):
     """The template instance hept_block_attn launches for this workload (csrc/block_attn.hip: block_attn_impl)"""
     nkt, full = (block_size + 31) // 32, "true" if block_size % 32 == 0 else "false"
     if precision == "fp32":
-        return f"block_attn_split_kernel<{nkt},{full},3>"
+        return f"block_attn_split_kernel<{nkt},{full},3,false>"
     p16 = "true" if head_dim == 24 else "false"
     return f"block_attn_kernel<{nkt},true,{p16},{'true' if precision == 'mixed16' else 'false'},{full},false>"
 
@@ -714,7 +714,10 @@ def worker(args) -> int:
                 c4_tune = {}
                 if multi:
                     c4_tune = tune_record(settle(attn4, step4))
-                el, ams, nrec = measure(step4, sub_steps, sub_warm, launches_per_step(attn4))
+                if multi:
+                    el, ams, nrec = measure(step4, sub_steps, sub_warm, launches_per_step(attn4))
+                else:   # (one process: a median of three regions, like every other sub-record)
+                    el, ams, nrec = measure_median(step4, sub_steps, sub_warm)
                 if multi:
                     attn4.sharding.check()
                 sub["c4"] = {"workload": f"{WORKLOAD}, n_hashes={world} sharded 1 per GPU over {world} GPU(s)",

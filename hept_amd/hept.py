@@ -86,7 +86,7 @@ class HEPTAttention(nn.Module):
             TableSharding(self.n_hashes, process_group) if process_group is not None else None
         )
         self._workspace: Optional[torch.Tensor] = None
-        self._ws_stream = None            # stream of the last forward that used the workspace (see _scratch)
+        self._ws_stream_ptr = None        # stream of the last forward that used the workspace (see _scratch)
         self._busy = False                # a forward of this instance is being issued (two host threads at once: refused)
         self._warned_eval_grad = False
 
@@ -98,11 +98,11 @@ class HEPTAttention(nn.Module):
         # One workspace per module: a forward issued on ANOTHER stream than the one before it would overwrite rows the
         # earlier forward may still be reading.  Enforced, not only documented (round 6): the new stream waits for the
         # stream of the call before it -- one event wait when the stream changes, nothing when it does not.
-        cur = torch.cuda.current_stream(device)
-        last = self._ws_stream
-        if last is not None and last != cur:
-            cur.wait_stream(last)
-        self._ws_stream = cur
+        ptr = ops.current_stream_ptr(device)     # the raw hipStream_t (one C call; no Stream object on the common path)
+        last = self._ws_stream_ptr
+        if last is not None and last != ptr:
+            torch.cuda.current_stream(device).wait_stream(torch.cuda.ExternalStream(last, device=device))
+        self._ws_stream_ptr = ptr                # (also handed to the C call: one stream lookup per forward, not two)
         return ws
 
     def reserve(self, n_points: int, n_coords: int, device) -> None:
@@ -122,11 +122,11 @@ class HEPTAttention(nn.Module):
                                "one workspace -- use one instance per thread")
         self._busy = True
         try:
-            return self._forward_impl(query, key, value, **kwargs)
+            return self._forward_impl(query, key, value, kwargs)
         finally:
             self._busy = False
 
-    def _forward_impl(self, query, key, value, **kwargs):
+    def _forward_impl(self, query, key, value, kwargs):
         if not query.is_cuda:
             raise RuntimeError("hept_amd.HEPTAttention needs GPU tensors: there is no CPU fallback")
         if torch.is_grad_enabled() and any(
@@ -189,7 +189,7 @@ class HEPTAttention(nn.Module):
                 else:
                     out = ops.forward(q2, k2, v2, coords.float(), kwargs["combined_shifts"], w_rpe_weight,
                                       self.e2lsh.alpha, self.out_linear.weight, self.out_linear.bias, workspace=ws,
-                                      **common)
+                                      stream=self._ws_stream_ptr, **common)
             else:
                 out = self._forward_sharded(q2, k2, v2, coords.float(), w_rpe_weight, src, kwargs, common)
         return out if query.dtype is torch.float32 else out.to(query.dtype)

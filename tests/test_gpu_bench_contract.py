@@ -94,7 +94,9 @@ def test_bench_line(precision, dtype, gpu_device):
     src = r["traffic_source"]
     assert src["kernel_launched"].startswith("block_attn_split_kernel<4" if precision == "fp32" else "block_attn_kernel<4")
     if r["traffic"] is None:
-        assert "refused" in src
+        # refused for a reason that is not this test's business (a stale digest on a tree under development) -- but never
+        # because bench.py and the library disagree about the NAME of the kernel that ran (round 6 shipped that twice)
+        assert "refused" in src and "no PMC pass" not in src["refused"], src
     else:
         assert "refused" not in src and src["kernel_launched"] in src["kernel_measured"].replace(" ", "")
         assert src["workload_key"] == f"c3/{precision}"
