@@ -341,3 +341,31 @@ def test_two_streams_share_one_module_safely(gpu_device):
         torch.cuda.synchronize()
     for a, b in zip(outs, ref):
         assert torch.equal(a, b)
+
+
+def test_the_launch_order_of_the_block_attention_does_not_change_the_output(gpu_device):
+    """Round 6 runs the tables of a block side by side (csrc/block_attn.hip: HeadRange::tl) instead of table-major.  The map
+    only decides WHEN a (table, head, block) runs: the output of the round-5 map (HEPT_ATTN_TABLE_MAJOR=1, read once per
+    process -- hence the child process) is bit-identical, in every precision."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, torch; sys.path.insert(0, %r)\n"
+        "from hept_amd import ops\n"
+        "from hept_amd.synthetic import make_inputs\n"
+        "inp = make_inputs([9000, 4000], block_size=128, n_hashes=3, seed=4, cluster_size=8)\n"
+        "g = {k: v.cuda() for k, v in inp.items() if torch.is_tensor(v)}\n"
+        "for p in ('fp32', 'bf16', 'mixed16'):\n"
+        "    o = ops.forward(g['q'], g['k'], g['v'], g['coords'], g['combined_shifts'], g['w_rpe_weight'], g['alpha'],\n"
+        "                    g['out_weight'], g['out_bias'], block_size=128, w_per_dist=10, precision=p)\n"
+        "    print(p, hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest())\n" % root)
+    outs = []
+    for extra in ({}, {"HEPT_ATTN_TABLE_MAJOR": "1"}):
+        run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **extra), timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs.append([ln for ln in run.stdout.splitlines() if ln.split() and ln.split()[0] in ("fp32", "bf16", "mixed16")])
+    assert len(outs[0]) == 3 and outs[0] == outs[1], outs
