@@ -33,30 +33,17 @@
 
 namespace {
 
-// Cache policy of the partial-row stores (A/B switch)
+// Cache policy of the packed partial rows: 1 = non-temporal (they are written once and read by the
+// combine only: as plain stores they push the gathered rows out of the L2), 0 = plain (A/B).  The f32 rows stay plain:
+// the f32 combine lives on what the caches still hold of them.
 #ifndef HEPT_ATTN_STORE
 #define HEPT_ATTN_STORE 1
 #endif
 __device__ __forceinline__ void store16_rows(unsigned int* dst, const u32x4& v) {
 #if HEPT_ATTN_STORE == 1
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
-#elif HEPT_ATTN_STORE == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-#elif HEPT_ATTN_STORE == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-#elif HEPT_ATTN_STORE == 4
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
-#elif HEPT_ATTN_STORE == 5
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(dst), "v"(v) : "memory");
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));   // (sc1 / sc0 sc1 stores gain nothing: r06_experiments.txt)
 #else
     *reinterpret_cast<u32x4*>(dst) = v;
-#endif
-}
-__device__ __forceinline__ void store4_rows(float* dst, float v) {
-#ifdef HEPT_ATTN_STORE32_NT
-    __builtin_nontemporal_store(v, dst);
-#else
-    *dst = v;
 #endif
 }
 
@@ -126,22 +113,14 @@ void block_attn_kernel(const char* __restrict__ qhat,
     // ---- this wave's 32 query rows: HBM -> registers (B-operand layout), norm from the row tail
     const int qi = w * 32 + li;
     const bool qvalid = FULL || qi < B;
-#ifdef HEPT_ATTN_NT_IDX
-    const int qsrc = __builtin_nontemporal_load(qp + (qvalid ? qi : 0));
-#else
     const int qsrc = qp[qvalid ? qi : 0];
-#endif
     if (hh == 0) qidx_s[qi] = qvalid ? qsrc : -1;
     const char* qrow = qbase + (size_t)qsrc * QROW;
     float qn = *reinterpret_cast<const float*>(qrow + QROW - 4);
     u32x4 qraw[BF16 ? 2 : 4];
 #pragma unroll
     for (int s = 0; s < (BF16 ? 2 : 4); ++s)
-#ifdef HEPT_ATTN_NT_Q
-        qraw[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qrow + (BF16 ? (s * 32 + hh * 16) : (hh * 64 + s * 16))));
-#else
         qraw[s] = *reinterpret_cast<const u32x4*>(qrow + (BF16 ? (s * 32 + hh * 16) : (hh * 64 + s * 16)));
-#endif
     if (hh == 1) qraw[BF16 ? 1 : 3][3] = 0u;  // the norm slot is not a feature
     if constexpr (DIFF) {
         static_assert(!BF16, "the difference form runs on f32 rows");
@@ -167,16 +146,8 @@ void block_attn_kernel(const char* __restrict__ qhat,
         const int key = ci / CPR, c = ci % CPR;
         u32x4 val = {0u, 0u, 0u, 0u};
         if (FULL || key < B) {  // FULL: B == 32 * NKT, no ragged tile -> no masking code at all
-#ifdef HEPT_ATTN_NT_IDX
-            const int src = __builtin_nontemporal_load(kp + key);
-#else
-            const int src = kp[key];
-#endif
-#ifdef HEPT_ATTN_NT_KV
-            val = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kvbase + (size_t)src * KVROW + c * 16));
-#else
+            const int src = kp[key];   // (the gathers and the positions WANT the caches: nt loads are slower, r06_experiments.txt)
             val = *reinterpret_cast<const u32x4*>(kvbase + (size_t)src * KVROW + c * 16);
-#endif
         }
         if (c < CH) {
             if (c == CH - 1) {
@@ -214,11 +185,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
         const int key = kt * 32 + li;
         f32x16 x;
 #pragma unroll
-#ifdef HEPT_ABL_NOINIT
-        for (int r = 0; r < 16; ++r) x[r] = qn;
-#else
         for (int r = 0; r < 16; ++r) x[r] = qn + kn_s[kt * 32 + hept_acc_row(r, hh)];
-#endif
 
         if constexpr (BF16) {
 #pragma unroll
@@ -269,12 +236,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
         // exp(min(x, 0)) written as min(exp(x), 1): identical value for every x (exp is monotone, exp(0) = 1),
         // and v_min on the v_exp result needs no NaN-canonicalising v_max in front of it
         float pr[16];
-#ifdef HEPT_ABL_NOEXP
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pr[r] = x[r];
-#else
         exp_clamped(x, pr);
-#endif
         if (!FULL && (kt + 1) * 32 > B) {  // ragged last tile (B not a multiple of 32): padded keys carry no weight
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -310,20 +272,15 @@ void block_attn_kernel(const char* __restrict__ qhat,
     }
 
     if constexpr (P16) {
-        // ---- scatter, 64-B rows [24 bf16 numer | f32 denom | 0]: even lane 2i packs columns (2i, 2i+1) -> dword i
-        //      (i < 12), lane 24 holds the denominator (dword 12), lanes 26..30 the zero padding.  The wave's 32 x 16
-        //      dword tile passes through LDS (the K^ / V tiles are dead after the loop; 16-B pieces XOR-swizzled by the
-        //      row so that the two lane halves -- rows r and r + 4, 64 dwords apart -- land on different banks), so that
-        //      a lane stores a 16-B piece and four lanes a whole 64-B row: two store instructions per wave instead of
-        //      sixteen 4-byte ones, and the form the xGMI links want when the row belongs to another rank (direct mode).
-#ifndef HEPT_ATTN_DWORD_SCATTER
+        // ---- scatter, 64-B rows [24 bf16 numer | f32 denom | 0].  The wave's 32 x 32 accumulator tile goes to LDS as it
+        //      stands (the K^ / V tiles are dead after the loop: f32, one ds_write_b32 per register at an immediate offset),
+        //      and the lane that stores piece pc of row `row` reads its eight values back (two ds_read_b128) and packs them
+        //      there: a lane stores a 16-B piece, four lanes a whole 64-B row -- two store instructions per wave, and the
+        //      form the xGMI links want when the row belongs to another rank (direct mode).  (Round 5 packed every register
+        //      where it lay: a DPP move, a conversion, two selects and a swizzled address per register -- 16 x 6 vector
+        //      instructions of a kernel that issues one in 57 % of its cycles: 56.2 -> 51.8 us.)  Word i = pack(column 2i,
+        //      column 2i + 1): the same values and rounding as ever.
         __syncthreads();   // every wave is done reading k_s / v_s
-#if !defined(HEPT_ATTN_EPI_DPP)
-        // round 6: the wave's 32 x 32 accumulator tile goes to LDS as it stands (f32, one ds_write_b32 per register at an
-        // immediate offset: no address arithmetic), and the lane that stores piece pc of row `row` reads its eight values
-        // back (two ds_read_b128) and packs them there -- 8 conversions per lane instead of, per register, a DPP move, a
-        // conversion, two selects and a swizzled address (16 x 6 vector instructions; the kernel issues a vector
-        // instruction in 57 % of its cycles).  Same values, same rounding: word i = pack(column 2i, column 2i + 1).
         float* tile = reinterpret_cast<float*>(smem) + w * 32 * 32;   // this wave's 4 KiB of the dead K^ / V tiles
         {
             float* wr = tile + (4 * hh) * 32 + li;
@@ -354,60 +311,6 @@ void block_attn_kernel(const char* __restrict__ qhat,
                 }
             }
         }
-#else
-        unsigned int* tile = reinterpret_cast<unsigned int*>(smem) + w * 32 * 16;   // this wave's 2 KiB of the K^ tile
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float mine = z[r];
-            const float nbr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mine), 0xB1,
-                                                                                 0xF, 0xF, true));  // lane ^ 1
-            if ((li & 1) == 0) {
-                const int row = hept_acc_row(r, hh), dw = li >> 1;
-                unsigned int word = hept_pack_bf16(mine, nbr);
-                if (li == D) word = __float_as_uint(mine + 1e-20f);  // example/hept.py:14 (D is even)
-                if (li > D) word = 0u;
-                tile[row * 16 + (((dw >> 2) ^ ((row >> 2) & 3)) << 2) + (dw & 3)] = word;
-            }
-        }
-        // (one wave's LDS accesses execute in order: the tile is complete when the reads below are issued)
-        unsigned int* __restrict__ pt =
-            reinterpret_cast<unsigned int*>(part) + (size_t)t * hr.tstride_rows * 16 + (size_t)(h - hr.hsub) * 16;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (lane >> 2) + 16 * j, pc = lane & 3;
-            const int q2 = w * 32 + row;
-            if (FULL || q2 < B) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * 16 + ((pc ^ ((row >> 2) & 3)) << 2));
-                const int dst = qidx_s[q2];
-                if (pa.direct) {
-                    bool remote;
-                    char* rowp = direct_row(pa, dst, h - hr.h0, 64, remote) + pc * 16;
-                    if (remote) store16_system(rowp, v);
-                    else *reinterpret_cast<u32x4*>(rowp) = v;
-                } else {
-                    store16_rows(pt + (size_t)dst * hr.hout * 16 + pc * 4, v);
-                }
-            }
-        }
-#endif   // HEPT_ATTN_EPI_DPP
-#else
-        unsigned int* __restrict__ pt =
-            reinterpret_cast<unsigned int*>(part) + (size_t)t * hr.tstride_rows * 16 + (size_t)(h - hr.hsub) * 16 + (li >> 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float mine = z[r];
-            const float nbr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mine), 0xB1,
-                                                                                 0xF, 0xF, true));  // lane ^ 1
-            const int q2 = w * 32 + hept_acc_row(r, hh);
-            if ((FULL || q2 < B) && (li & 1) == 0) {
-                const int dst = qidx_s[q2];
-                unsigned int word = hept_pack_bf16(mine, nbr);
-                if (li == D) word = __float_as_uint(mine + 1e-20f);  // example/hept.py:14 (D is even)
-                if (li > D) word = 0u;
-                pt[(size_t)dst * hr.hout * 16] = word;
-            }
-        }
-#endif
     } else {
         // ---- scatter: row = 32 floats = one 128-B line per query, lanes 0..31 contiguous
         float* __restrict__ pt = part + (size_t)t * hr.tstride_rows * 32 + (size_t)(h - hr.hsub) * 32 + li;
@@ -424,7 +327,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
                     if (remote) store4_system(rowp, __float_as_uint(val));
                     else *reinterpret_cast<float*>(rowp) = val;
                 } else {
-                    store4_rows(pt + (size_t)dst * hr.hout * 32, val);
+                    pt[(size_t)dst * hr.hout * 32] = val;
                 }
             }
         }
@@ -472,10 +375,7 @@ void block_attn_kernel(const char* __restrict__ qhat,
 #ifndef HEPT_SPLIT_CK8
 #define HEPT_SPLIT_CK8 128
 #endif
-#ifndef HEPT_SPLIT_CK4
-#define HEPT_SPLIT_CK4 64
-#endif
-constexpr int split_ck(int nkt) { return nkt == 8 ? HEPT_SPLIT_CK8 : (nkt == 4 ? HEPT_SPLIT_CK4 : (nkt >= 2 ? 64 : 32)); }
+constexpr int split_ck(int nkt) { return nkt == 8 ? HEPT_SPLIT_CK8 : (nkt >= 2 ? 64 : 32); }   // (128 keys at B = 128: slower, r06_experiments.txt)
 #ifndef HEPT_SPLIT_PP
 #define HEPT_SPLIT_PP 2
 #endif
@@ -752,7 +652,6 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
     //      LDS (the planes are dead: f32, one ds_write_b32 per register at an immediate offset), and a lane stores a 16-B
     //      piece, eight lanes a whole row: four store instructions per wave with four address computations instead of
     //      sixteen 4-byte ones with a shuffle and a 64-bit multiply each (~110 vector instructions of the wave's ~870).
-#ifndef HEPT_SPLIT_EPI_DWORD
     __syncthreads();   // every wave is done with the last chunk's planes
     float* tile = reinterpret_cast<float*>(smem) + w * 32 * 32;
     {
@@ -781,26 +680,6 @@ __global__ __launch_bounds__(64 * NKT) void block_attn_split_kernel(const float*
             }
         }
     }
-#else
-    float* __restrict__ pt = part + (size_t)t * hr.tstride_rows * 32 + (size_t)(h - hr.hsub) * 32 + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q2 = w * 32 + hept_acc_row(r, hh);
-        const int dst = __shfl(qsrc, hept_acc_row(r, hh));  // lane li holds the source row of query 32 w + li
-        if (FULL || q2 < B) {
-            float val = z[r];
-            if (li == D) val += 1e-20f;  // example/hept.py:14
-            if (pa.direct) {   // see block_attn_kernel
-                bool remote;
-                char* rowp = direct_row(pa, dst, h - hr.h0, 128, remote) + li * 4;
-                if (remote) store4_system(rowp, __float_as_uint(val));
-                else *reinterpret_cast<float*>(rowp) = val;
-            } else {
-                store4_rows(pt + (size_t)dst * hr.hout * 32, val);
-            }
-        }
-    }
-#endif
     if (pa.direct) {   // see block_attn_kernel
         drain_remote_stores();
         if (pa.counter) signal_when_all_done(pa.counter, pa.peers, pa.world, pa.flag_idx, pa.epoch, gridDim.x - pa.push_wgs);
