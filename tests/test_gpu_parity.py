@@ -631,3 +631,34 @@ def test_unrescaled_checkpoint_coordinates_stay_finite(precision, gpu_device):
         dead = torch.from_numpy(fx["out"] == inp["out_bias"].numpy()[None, :]).all(dim=1)
         assert torch.equal(got[dead], ref[dead])
         assert frac >= G7_MIN_ROWS_AT_G3_TOL
+
+
+@pytest.mark.parametrize("workload", ["tracking-60k", "pileup-8clouds"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32_diff", "bf16"])
+def test_full_size_properties_linearity_in_the_values_and_determinism(workload, precision, gpu_device):
+    """Size-independent properties at the benchmark's full sizes (no oracle involved).  For fixed q, k the operator is
+    LINEAR in v before the bias: numerators are sums of weight x value, the denominators do not see v (example/hept.py:13-17),
+    so f(a v1 + b v2) - bias = a (f(v1) - bias) + b (f(v2) - bias) with the same blocks (the hashes do not see v either).
+    And it is deterministic: two calls are torch.equal (no float atomics, the sort is exact, the region sort's arrival order
+    does not reach the output)."""
+    from hept_amd.synthetic import workload_inputs, WORKLOADS
+
+    inp = workload_inputs(workload, seed=0)
+    bs = WORKLOADS[workload]["block_size"]
+    g = {k: v.to(gpu_device) for k, v in inp.items() if torch.is_tensor(v)}
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    v2 = torch.randn(g["v"].shape, generator=gen).to(gpu_device)
+
+    def f(v):
+        return ops.forward(g["q"], g["k"], v, g["coords"], g["combined_shifts"], g["w_rpe_weight"], g["alpha"],
+                           g["out_weight"], g["out_bias"], block_size=bs, w_per_dist=10, precision=precision)
+
+    a, b = 0.75, -1.5
+    o1, o2, o12 = f(g["v"]), f(v2), f(a * g["v"] + b * v2)
+    assert torch.equal(o1, f(g["v"]))                                   # determinism
+    bias = g["out_bias"]
+    lhs, rhs = o12 - bias, a * (o1 - bias) + b * (o2 - bias)
+    scale = float(rhs.abs().max())
+    err = float((lhs - rhs).abs().max()) / scale
+    # f32 tiles: the round-off of three weighted means; 16-bit tiles: values and stored numerators are rounded to bf16
+    assert err <= (2e-5 if precision != "bf16" else 2e-2), err
